@@ -1,0 +1,376 @@
+"""CPU oracle: a from-scratch functional restatement of the reference's denoising hot path.
+
+TEST INFRASTRUCTURE ONLY (see ``oracle/__init__.py``).  Parity status: **pinned** —
+``tests/test_oracle_golden.py`` checks every function here against golden vectors that
+``tools/make_golden.py`` produced by importing the reference itself in the build container
+(fixtures committed under ``tests/golden/``), plus the one value-level test the reference
+ships (patch/unpatch round trip, ``tests/test_shapes.py:26-36`` in the reference).
+
+Everything is written as plain functions over a flat ``{name: tensor}`` weight dict (the
+reference modules' ``state_dict`` key names), in whatever float dtype the inputs carry, so the
+same code serves as the fp32 oracle, as an fp64 adjudicator and as the timed ``cpu_baseline``.
+
+Reference anchors (paths relative to the reference repo root):
+  schedules/ddim .......... avdiff/utils/schedule_utils.py:14-49, 52-57, 64-86, 132-143, 146-200
+  patch / chunk ........... avdiff/utils/ops.py:17-45, 48-93, 100-119, 122-144
+  audio token helpers ..... avdiff/models/infer/sample_clip.py:184-188, 191-215
+  RMSNorm/MHA/MLP/Block ... avdiff/models/mmdt.py:33-42, 51-61, 66-83, 88-99, 134-149
+  noise head .............. avdiff/models/heads/noise_heads.py:185-229
+  adapters + t-emb concat . avdiff/models/infer/sample_clip.py:48-56, 59-70
+  sampler loop body ....... avdiff/models/infer/sample_clip.py:318-348 (V->A), 359-389 (A->V)
+  TimestepEmbedder(mlp) ... avdiff/models/adapters.py:137-158
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+
+Tensor = torch.Tensor
+Weights = Dict[str, Tensor]
+
+
+# --------------------------------------------------------------------------------------
+# schedule tables (schedule_utils.py:14-57, 132-143) — always fp32 like the reference
+# --------------------------------------------------------------------------------------
+
+def beta_table(steps: int, kind: str = "cosine", min_beta: float = 1e-4, max_beta: float = 2e-2) -> Tensor:
+    k = kind.lower()
+    if k == "linear":
+        b = torch.linspace(min_beta, max_beta, steps, dtype=torch.float32)
+    elif k == "sigmoid":
+        ramp = torch.sigmoid(torch.linspace(-6, 6, steps, dtype=torch.float32))
+        b = min_beta + (max_beta - min_beta) * ramp
+    elif k == "cosine":
+        grid = torch.linspace(0, steps, steps + 1, dtype=torch.float32)
+        f = torch.cos(((grid / steps + 0.008) / 1.008) * math.pi / 2) ** 2
+        f = f / f[0]
+        b = 1 - f[1:] / f[:-1]
+    else:
+        raise ValueError(f"Unknown schedule kind: {kind}")
+    return b.clamp(1e-8, 0.999)
+
+
+def alpha_bar_table(betas: Tensor) -> Tensor:
+    return torch.cumprod(1.0 - betas.to(torch.float32), dim=0)
+
+
+def sampling_schedule(t_train: int, t_sample: int) -> Tensor:
+    # linspace from T-1 down to -1 inclusive, round-half-even, int64 (schedule_utils.py:132-143)
+    return torch.round(torch.linspace(t_train - 1, -1, t_sample + 1)).to(torch.long)
+
+
+# --------------------------------------------------------------------------------------
+# sinusoidal timestep embedding (schedule_utils.py:64-86): [cos | sin], cos first
+# --------------------------------------------------------------------------------------
+
+def timestep_embedding(t: Tensor, dim: int, max_period: int = 10000, dtype=torch.float32) -> Tensor:
+    tf = t if t.is_floating_point() else t.to(torch.float32)
+    half = dim // 2
+    # the reference builds freqs in fp32 regardless of anything else
+    freqs = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+    ang = tf[:, None] * freqs[None, :]
+    out = torch.cat([ang.cos(), ang.sin()], dim=1)
+    if dim % 2:
+        out = torch.nn.functional.pad(out, (0, 1))
+    return out.to(dtype)
+
+
+# --------------------------------------------------------------------------------------
+# DDIM update (schedule_utils.py:146-200).  eta>0 needs externally supplied noise.
+# --------------------------------------------------------------------------------------
+
+def ddim_update(x_t: Tensor, t_now: Tensor, t_prev: Tensor, eps_hat: Tensor, alpha_bar: Tensor,
+                eta: float = 0.0, noise: Optional[Tensor] = None) -> Tensor:
+    ab = alpha_bar.to(x_t.dtype)
+    a_t = ab[t_now.clamp(min=0).long()]
+    a_p = torch.where(t_prev >= 0, ab[t_prev.clamp(min=0).long()], torch.ones_like(a_t))
+    shape = [-1] + [1] * (x_t.dim() - 1)
+    a_t = a_t.view(shape)
+    a_p = a_p.view(shape)
+    x0 = (x_t - (1.0 - a_t).clamp(min=0).sqrt() * eps_hat) / a_t.sqrt().clamp(min=1e-8)
+    if eta > 0.0:
+        frac = ((1.0 - a_p) / (1.0 - a_t).clamp(min=1e-8)).clamp(min=0)
+        omr = (1.0 - a_t / a_p.clamp(min=1e-8)).clamp(min=0)
+        sigma = eta * (frac * omr).sqrt()
+        if noise is None:
+            raise ValueError("oracle ddim_update with eta>0 needs explicit noise")
+    else:
+        sigma = torch.zeros_like(a_t)
+        noise = torch.zeros_like(x_t)
+    c_eps = (1.0 - a_p - sigma ** 2).clamp(min=0).sqrt()
+    return a_p.sqrt() * x0 + c_eps * eps_hat + sigma * noise
+
+
+# --------------------------------------------------------------------------------------
+# tokenisers (ops.py:100-144; sample_clip.py:184-215)
+# --------------------------------------------------------------------------------------
+
+def video_patch_index(C: int, T: int, H: int, W: int, t: int, h: int, w: int) -> Tensor:
+    """Flat gather map: tokens.flatten()[i] = latent.flatten()[idx[i]] for one sample.
+
+    Token order (T',H',W') row-major; feature order (C,t,h,w) row-major — ops.py:114-116.
+    """
+    if T % t or H % h or W % w:
+        raise AssertionError("tube sizes must divide latent dims")
+    base = torch.arange(C * T * H * W).view(C, T // t, t, H // h, h, W // w, w)
+    return base.permute(1, 3, 5, 0, 2, 4, 6).reshape(-1)
+
+
+def tube_patch(z: Tensor, t: int, h: int, w: int) -> Tensor:
+    B, C, T, H, W = z.shape
+    idx = video_patch_index(C, T, H, W, t, h, w)
+    n = (T // t) * (H // h) * (W // w)
+    return z.reshape(B, -1)[:, idx].reshape(B, n, C * t * h * w)
+
+
+def tube_unpatch(tok: Tensor, C: int, T: int, H: int, W: int, t: int, h: int, w: int) -> Tensor:
+    B, n, D = tok.shape
+    if D != C * t * h * w:
+        raise AssertionError("token width mismatch")
+    if n != (T // t) * (H // h) * (W // w):
+        raise AssertionError("token count mismatch")
+    idx = video_patch_index(C, T, H, W, t, h, w)
+    out = torch.empty(B, C * T * H * W, dtype=tok.dtype)
+    out[:, idx] = tok.reshape(B, -1)
+    return out.view(B, C, T, H, W)
+
+
+def audio_tokens(z_a: Tensor, length: int, stride: int) -> Tensor:
+    """[B,Ca,F] -> [B,Na,Ca*length]; Na = (F-length)//stride + 1; trailing frames dropped."""
+    B, Ca, F = z_a.shape
+    na = (F - length) // stride + 1
+    starts = torch.arange(na) * stride
+    win = z_a[:, :, starts[:, None] + torch.arange(length)[None, :]]   # [B,Ca,Na,l]
+    return win.permute(0, 2, 1, 3).reshape(B, na, Ca * length)
+
+
+def audio_untokens(tok: Tensor, Ca: int, length: int, frames: int, stride: int) -> Tensor:
+    """Overlap-add with a rectangular window and overlap-count normalisation, then crop / zero-pad
+    to ``frames`` (sample_clip.py:191-215 → ops.py:48-93)."""
+    B, na, D = tok.shape
+    assert D == Ca * length
+    win = tok.view(B, na, Ca, length).permute(0, 2, 1, 3)              # [B,Ca,Na,l]
+    L = (na - 1) * stride + length
+    acc = torch.zeros(B, Ca, L, dtype=tok.dtype)
+    cnt = torch.zeros(L, dtype=tok.dtype)
+    for i in range(na):
+        acc[..., i * stride:i * stride + length] += win[:, :, i]
+        cnt[i * stride:i * stride + length] += 1
+    acc = acc / cnt.clamp(min=1e-8)
+    if L >= frames:
+        return acc[..., :frames].contiguous()
+    return torch.nn.functional.pad(acc, (0, frames - L))
+
+
+# --------------------------------------------------------------------------------------
+# MMDiT core (mmdt.py)
+# --------------------------------------------------------------------------------------
+
+def gelu_erf(x: Tensor) -> Tensor:
+    return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
+
+
+def rmsnorm(x: Tensor, scale: Tensor, eps: float = 1e-6) -> Tensor:
+    # eps is added to the RMS (outside the sqrt) — mmdt.py:39-42
+    rms = x.pow(2).sum(-1, keepdim=True).sqrt() / math.sqrt(x.shape[-1])
+    return scale * x / (rms + eps)
+
+
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
+    y = x @ w.transpose(-1, -2)
+    return y if b is None else y + b
+
+
+def self_attention(x: Tensor, w_in: Tensor, b_in: Tensor, w_out: Tensor, b_out: Tensor, n_heads: int) -> Tensor:
+    """nn.MultiheadAttention(batch_first=True), q=k=v=x, no mask, eval (mmdt.py:51-61)."""
+    B, N, d = x.shape
+    dh = d // n_heads
+    qkv = linear(x, w_in, b_in).view(B, N, 3, n_heads, dh)
+    q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))          # [B,H,N,dh]
+    s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
+    p = torch.softmax(s, dim=-1)
+    o = (p @ v).transpose(1, 2).reshape(B, N, d)
+    return linear(o, w_out, b_out)
+
+
+def mmdit_block(x: Tensor, W: Weights, pre: str, n_heads: int) -> Tensor:
+    h = rmsnorm(x, W[pre + "norm1.scale"])
+    x = x + self_attention(h, W[pre + "attn.mha.in_proj_weight"], W[pre + "attn.mha.in_proj_bias"],
+                           W[pre + "attn.mha.out_proj.weight"], W[pre + "attn.mha.out_proj.bias"], n_heads)
+    h = rmsnorm(x, W[pre + "norm2.scale"])
+    h = gelu_erf(linear(h, W[pre + "mlp.fc1.weight"], W[pre + "mlp.fc1.bias"]))
+    return x + linear(h, W[pre + "mlp.fc2.weight"], W[pre + "mlp.fc2.bias"])
+
+
+def mmdit_forward(x: Tensor, W: Weights, n_layers: int, n_heads: int) -> Tensor:
+    for i in range(n_layers):
+        x = mmdit_block(x, W, f"blocks.{i}.", n_heads)
+    return rmsnorm(x, W["final_norm.scale"])
+
+
+# --------------------------------------------------------------------------------------
+# MultiModalNoiseHead (noise_heads.py:185-229) for num_modality_specific_layers == 1
+# --------------------------------------------------------------------------------------
+
+def layernorm(x: Tensor, g: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
+    mu = x.mean(-1, keepdim=True)
+    var = (x - mu).pow(2).mean(-1, keepdim=True)
+    return (x - mu) / (var + eps).sqrt() * g + b
+
+
+def noise_head(h: Tensor, W: Weights, modality: str, n_shared: int = 2) -> Tensor:
+    shp = h.shape
+    y = linear(h.reshape(-1, shp[-1]), W[f"input_proj.{modality}.weight"], W[f"input_proj.{modality}.bias"])
+    for j in range(n_shared):
+        y = linear(y, W[f"shared.{j}.0.weight"], W[f"shared.{j}.0.bias"])
+        y = gelu_erf(layernorm(y, W[f"shared.{j}.1.weight"], W[f"shared.{j}.1.bias"]))
+    y = linear(y, W[f"out_proj.{modality}.weight"], W[f"out_proj.{modality}.bias"])
+    return y.view(*shp[:-1], y.shape[-1])
+
+
+# --------------------------------------------------------------------------------------
+# TimestepEmbedder(mode="mlp") (adapters.py:137-158): sinusoid -> Linear -> SiLU -> Linear
+# --------------------------------------------------------------------------------------
+
+def timestep_mlp(t: Tensor, W: Weights, dim: int) -> Tensor:
+    e = timestep_embedding(t, dim, dtype=W["mlp.0.weight"].dtype)
+    y = linear(e, W["mlp.0.weight"], W["mlp.0.bias"])
+    y = y * torch.sigmoid(y)
+    return linear(y, W["mlp.2.weight"], W["mlp.2.bias"])
+
+
+# --------------------------------------------------------------------------------------
+# one CFG denoising step, batched (sample_clip.py loop bodies)
+# --------------------------------------------------------------------------------------
+
+def embed_with_time(tok: Tensor, w: Tensor, b: Tensor, t: Tensor, tdim: int) -> Tensor:
+    x = linear(tok, w, b)
+    e = timestep_embedding(t, tdim, dtype=x.dtype)[:, None, :].expand(-1, x.shape[1], -1)
+    return torch.cat([x, e], dim=-1)
+
+
+def eps_pair(Xt: Tensor, Xp: Tensor, target_first: bool, core: Weights, head: Weights, target: str,
+             n_layers: int, n_heads: int) -> Tuple[Tensor, Tensor]:
+    """cond / null ε̂ for the target modality.  Sequence order is always [video ; audio]."""
+    nt = Xt.shape[1]
+
+    def run(prompt_rows: Tensor) -> Tensor:
+        seq = torch.cat([Xt, prompt_rows], 1) if target_first else torch.cat([prompt_rows, Xt], 1)
+        hfull = mmdit_forward(seq, core, n_layers, n_heads)
+        ht = hfull[:, :nt] if target_first else hfull[:, -nt:]
+        return noise_head(ht, head, target)
+
+    return run(Xp), run(torch.zeros_like(Xp))
+
+
+def denoise_step_a2v(z_v: Tensor, z_a0: Tensor, t_now: Tensor, t_prev: Tensor, alpha_bar: Tensor, *,
+                     adapt_v: Weights, adapt_a: Weights, core: Weights, head: Weights,
+                     n_layers: int, n_heads: int, tdim: int = 256, tube=(2, 4, 4), chunk=(4, 4),
+                     guidance: float = 3.5, eta: float = 0.0, return_eps: bool = False):
+    """Audio prompt -> video target (sample_clip.py:359-389), any batch size."""
+    B, C, T, H, Wd = z_v.shape
+    tok_v = tube_patch(z_v, *tube)
+    tok_a = audio_tokens(z_a0, *chunk)
+    Xv = embed_with_time(tok_v, adapt_v["proj.weight"], adapt_v["proj.bias"], t_now, tdim)
+    Xa = embed_with_time(tok_a, adapt_a["proj.weight"], adapt_a["proj.bias"], torch.zeros_like(t_now), tdim)
+    e_c, e_n = eps_pair(Xv, Xa, True, core, head, "video", n_layers, n_heads)
+    eps_tok = e_n + guidance * (e_c - e_n)
+    eps_lat = tube_unpatch(eps_tok, C, T, H, Wd, *tube)
+    z_next = ddim_update(z_v, t_now, t_prev, eps_lat, alpha_bar, eta)
+    return (z_next, eps_tok) if return_eps else z_next
+
+
+def denoise_step_v2a(z_a: Tensor, z_v0: Tensor, t_now: Tensor, t_prev: Tensor, alpha_bar: Tensor, *,
+                     adapt_v: Weights, adapt_a: Weights, core: Weights, head: Weights,
+                     n_layers: int, n_heads: int, tdim: int = 256, tube=(2, 4, 4), chunk=(4, 4),
+                     guidance: float = 3.0, eta: float = 0.0, return_eps: bool = False):
+    """Video prompt -> audio target (sample_clip.py:318-348), any batch size."""
+    B, Ca, F = z_a.shape
+    tok_v = tube_patch(z_v0, *tube)
+    tok_a = audio_tokens(z_a, *chunk)
+    Xv = embed_with_time(tok_v, adapt_v["proj.weight"], adapt_v["proj.bias"], torch.zeros_like(t_now), tdim)
+    Xa = embed_with_time(tok_a, adapt_a["proj.weight"], adapt_a["proj.bias"], t_now, tdim)
+    e_c, e_n = eps_pair(Xa, Xv, False, core, head, "audio", n_layers, n_heads)
+    eps_tok = e_n + guidance * (e_c - e_n)
+    eps_lat = audio_untokens(eps_tok, Ca, chunk[0], F, chunk[1])
+    z_next = ddim_update(z_a, t_now, t_prev, eps_lat, alpha_bar, eta)
+    return (z_next, eps_tok) if return_eps else z_next
+
+
+def sample_a2v(z_v: Tensor, z_a0: Tensor, sched: Tensor, alpha_bar: Tensor, **kw) -> Tensor:
+    """Chained A->V loop over a sampling schedule (no codec/VAE): returns the final latent."""
+    B = z_v.shape[0]
+    for i in range(len(sched) - 1):
+        z_v = denoise_step_a2v(z_v, z_a0, sched[i].repeat(B), sched[i + 1].repeat(B), alpha_bar, **kw)
+    return z_v
+
+
+# --------------------------------------------------------------------------------------
+# synthetic weights with the reference's shapes and init families (no reference code involved)
+# --------------------------------------------------------------------------------------
+
+def _xavier(gen: torch.Generator, out_f: int, in_f: int) -> Tensor:
+    a = math.sqrt(6.0 / (in_f + out_f))
+    return (torch.rand(out_f, in_f, generator=gen) * 2 - 1) * a
+
+
+def _kaiming_default(gen: torch.Generator, out_f: int, in_f: int) -> Tuple[Tensor, Tensor]:
+    a = 1.0 / math.sqrt(in_f)
+    return (torch.rand(out_f, in_f, generator=gen) * 2 - 1) * a, (torch.rand(out_f, generator=gen) * 2 - 1) * a
+
+
+def synth_weights(seed: int = 0, d: int = 512, n_layers: int = 8, mlp_ratio: float = 4.0,
+                  tok_v: int = 256, tok_a: int = 32, tdim: int = 256, head_hidden: int = 512,
+                  n_shared: int = 2, bias_jitter: float = 0.02) -> Dict[str, Weights]:
+    """Seeded random weights shaped like ``build_components`` output (sample_clip.py:75-109).
+
+    Biases/norm scales get a small jitter so bias/scale plumbing bugs cannot hide behind zeros/ones.
+    """
+    g = torch.Generator().manual_seed(seed)
+    hid = int(d * mlp_ratio)
+
+    def jit(n, base=0.0):
+        return base + bias_jitter * torch.randn(n, generator=g)
+
+    core: Weights = {}
+    for i in range(n_layers):
+        p = f"blocks.{i}."
+        core[p + "norm1.scale"] = jit(d, 1.0)
+        core[p + "attn.mha.in_proj_weight"] = _xavier(g, 3 * d, d)
+        core[p + "attn.mha.in_proj_bias"] = jit(3 * d)
+        w, b = _kaiming_default(g, d, d)
+        core[p + "attn.mha.out_proj.weight"] = w
+        core[p + "attn.mha.out_proj.bias"] = jit(d)
+        core[p + "norm2.scale"] = jit(d, 1.0)
+        core[p + "mlp.fc1.weight"] = _xavier(g, hid, d)
+        core[p + "mlp.fc1.bias"] = jit(hid)
+        core[p + "mlp.fc2.weight"] = _xavier(g, d, hid)
+        core[p + "mlp.fc2.bias"] = jit(d)
+    core["final_norm.scale"] = jit(d, 1.0)
+
+    head: Weights = {}
+    for m, od in (("video", tok_v), ("audio", tok_a)):
+        head[f"input_proj.{m}.weight"] = _xavier(g, head_hidden, d)
+        head[f"input_proj.{m}.bias"] = jit(head_hidden)
+        head[f"out_proj.{m}.weight"] = _xavier(g, od, head_hidden)
+        head[f"out_proj.{m}.bias"] = jit(od)
+    for j in range(n_shared):
+        head[f"shared.{j}.0.weight"] = _xavier(g, head_hidden, head_hidden)
+        head[f"shared.{j}.0.bias"] = jit(head_hidden)
+        head[f"shared.{j}.1.weight"] = jit(head_hidden, 1.0)
+        head[f"shared.{j}.1.bias"] = jit(head_hidden)
+
+    wv, bv = _kaiming_default(g, d - tdim, tok_v)
+    wa, ba = _kaiming_default(g, d - tdim, tok_a)
+    return {
+        "core": core,
+        "head": head,
+        "adapt_v": {"proj.weight": wv, "proj.bias": bv},
+        "adapt_a": {"proj.weight": wa, "proj.bias": ba},
+    }
+
+
+def cast_weights(ws: Dict[str, Weights], dtype) -> Dict[str, Weights]:
+    return {k: {n: t.to(dtype) for n, t in v.items()} for k, v in ws.items()}

@@ -1,0 +1,144 @@
+"""CPU: pins the oracle (oracle/ref_cpu.py) to golden vectors produced by the reference itself
+(tools/make_golden.py) and to the reference's own value-level test (patch/unpatch round trip,
+reference tests/test_shapes.py:26-36)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, split_weights
+from oracle import ref_cpu as R
+
+TOL = 1e-4   # max|Δ| <= TOL * max(1, max|ref|)   
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_g1_schedules_bit_exact():
+    g = load_golden("g1_schedules.npz")
+    for kind in ("cosine", "linear", "sigmoid"):
+        b = R.beta_table(1000, kind, 1e-4, 0.02)
+        assert np.array_equal(b.numpy(), g[f"betas/{kind}"]), kind
+        assert np.array_equal(R.alpha_bar_table(b).numpy(), g[f"abar/{kind}"]), kind
+    for S in (10, 25, 50, 60, 100):
+        assert np.array_equal(R.sampling_schedule(1000, S).numpy(), g[f"sched/{S}"])
+    assert np.array_equal(R.sampling_schedule(50, 7).numpy(), g["sched/T50_S7"])
+    ab = g["abar/cosine"]
+    # spot values quoted in SURVEY §8c
+    assert abs(ab[0] - 0.99995875) < 1e-7 and abs(ab[500] - 0.49228531) < 1e-7
+    assert g["sched/60"][0] == 999 and g["sched/60"][1] == 982 and g["sched/60"][-1] == -1
+
+
+def test_g2_timestep_embedding():
+    g = load_golden("g2_temb.npz")
+    t = T(g["t"])
+    for dim, key in ((256, "e256"), (64, "e64"), (7, "e7")):
+        assert np.array_equal(R.timestep_embedding(t, dim).numpy(), g[key]), dim
+    e0 = R.timestep_embedding(torch.zeros(1, dtype=torch.long), 256)[0]
+    assert torch.equal(e0[:128], torch.ones(128)) and torch.equal(e0[128:], torch.zeros(128))
+
+
+def test_g3_index_maps_exact():
+    g = load_golden("g3_index.npz")
+    for key in [k for k in g if k.startswith("patch/")]:
+        C, Tt, H, W = map(int, key.split("/")[1].split("x"))
+        z = torch.arange(C * Tt * H * W, dtype=torch.float32).view(1, C, Tt, H, W)
+        tok = R.tube_patch(z, 2, 4, 4)
+        assert np.array_equal(tok.numpy().astype(np.int32), g[key])
+        assert torch.equal(R.tube_unpatch(tok, C, Tt, H, W, 2, 4, 4), z)
+    za = torch.arange(2 * 8 * 150, dtype=torch.float32).view(2, 8, 150)
+    tok = R.audio_tokens(za, 4, 4)
+    assert np.array_equal(tok.numpy().astype(np.int32), g["audio_tok/150"])
+    un = R.audio_untokens(tok + 1.0, 8, 4, 150, 4)
+    assert np.array_equal(un.numpy().astype(np.int32), g["audio_untok/150"])
+    assert torch.equal(un[..., 148:], torch.zeros(2, 8, 2))       # zero tail (sample_clip.py:213-214)
+    zb = T(g["audio22/z"])
+    assert np.array_equal(R.audio_tokens(zb, 4, 4).numpy(), g["audio22/tok"])
+    assert np.array_equal(R.audio_untokens(T(g["audio22/tok"]), 8, 4, 22, 4).numpy(), g["audio22/untok"])
+    assert np.array_equal(R.audio_tokens(zb, 4, 2).numpy(), g["audio22s2/tok"])
+    assert np.allclose(R.audio_untokens(T(g["audio22s2/tok"]), 8, 4, 22, 2).numpy(), g["audio22s2/untok"], atol=1e-6)
+
+
+def test_reference_roundtrip_case():
+    # same shapes/atol as the reference's tests/test_shapes.py:26-36
+    torch.manual_seed(0)
+    z = torch.randn(2, 8, 12, 16, 16)
+    tok = R.tube_patch(z, 2, 4, 4)
+    assert tok.shape == (2, 6 * 4 * 4, 256)
+    assert torch.allclose(z, R.tube_unpatch(tok, 8, 12, 16, 16, 2, 4, 4), atol=1e-6)
+    with pytest.raises(AssertionError):
+        R.tube_patch(torch.zeros(1, 8, 3, 16, 16), 2, 4, 4)
+
+
+def test_g4_rmsnorm():
+    g = load_golden("g4_rmsnorm.npz")
+    y = R.rmsnorm(T(g["x"]), T(g["scale"]))
+    assert rel_err(y, g["y"]) < 1e-6
+    assert torch.equal(y[2], torch.zeros(512))
+
+
+def test_g5_block_and_core(small_model):
+    g, W, meta = small_model
+    core = W["core"]
+    x = T(g["x"])
+    assert rel_err(R.mmdit_block(x, core, "blocks.0.", meta["n_heads"]), g["y_block0"]) < TOL
+    assert rel_err(R.mmdit_forward(x, core, meta["n_layers"], meta["n_heads"]), g["y"]) < TOL
+    assert rel_err(R.mmdit_forward(T(g["x_b"]), core, meta["n_layers"], meta["n_heads"]), g["y_b"]) < TOL
+
+
+def test_g6_head(small_model):
+    _, W, _ = small_model
+    g = load_golden("g6_head_small.npz")
+    assert rel_err(R.noise_head(T(g["hv"]), W["head"], "video"), g["out_v"]) < TOL
+    assert rel_err(R.noise_head(T(g["ha"]), W["head"], "audio"), g["out_a"]) < TOL
+
+
+def test_g7_ddim():
+    g = load_golden("g7_ddim.npz")
+    y = R.ddim_update(T(g["x_t"]), T(g["t_now"]), T(g["t_prev"]), T(g["eps"]), T(g["abar"]))
+    assert rel_err(y, g["x_prev"]) < 1e-6
+    # t_prev = -1 -> alpha_bar_prev = 1 -> result is x0_pred exactly
+    assert torch.isfinite(y).all()
+
+
+@pytest.mark.parametrize("guide", [0.0, 1.0, 3.5])
+def test_g8_cfg_step(small_model, guide):
+    _, W, meta = small_model
+    g = load_golden("g8_cfg_step_small.npz")
+    kw = dict(adapt_v=W["adapt_v"], adapt_a=W["adapt_a"], core=W["core"], head=W["head"],
+              n_layers=meta["n_layers"], n_heads=meta["n_heads"], tdim=meta["tdim"], guidance=guide)
+    z_v, z_a, tn, tp, ab = (T(g[k]) for k in ("z_v", "z_a", "t_now", "t_prev", "abar"))
+    zn, et = R.denoise_step_a2v(z_v, z_a, tn, tp, ab, return_eps=True, **kw)
+    assert rel_err(et, g[f"a2v/g{guide}/eps_tok"]) < TOL
+    assert rel_err(zn, g[f"a2v/g{guide}/z_next"]) < TOL
+    zn, et = R.denoise_step_v2a(z_a, z_v, tn, tp, ab, return_eps=True, **kw)
+    assert rel_err(et, g[f"v2a/g{guide}/eps_tok"]) < TOL
+    assert rel_err(zn, g[f"v2a/g{guide}/z_next"]) < TOL
+
+
+def test_g9_chained_sampler(small_model):
+    _, W, meta = small_model
+    g = load_golden("g9_chain_small.npz")
+    z = R.sample_a2v(T(g["z_init"]), T(g["z_a0"]), T(g["sched"]), T(g["abar"]),
+                     adapt_v=W["adapt_v"], adapt_a=W["adapt_a"], core=W["core"], head=W["head"],
+                     n_layers=meta["n_layers"], n_heads=meta["n_heads"], tdim=meta["tdim"],
+                     guidance=float(g["guidance"]))
+    ref = T(g["z_final"]).double()
+    rel_l2 = float((z.double() - ref).norm() / ref.norm())
+    assert rel_l2 < 1e-3, rel_l2       # chained tolerance (first step gain x20,290)
+
+
+def test_g10_timestep_mlp():
+    g = load_golden("g10_tmlp.npz")
+    W = split_weights(g)["w"]
+    assert rel_err(R.timestep_mlp(T(g["t"]), W, 64), g["y"]) < 1e-5
+
+
+def test_fp64_oracle_agrees_with_fp32(small_model):
+    g, W, meta = small_model
+    W64 = R.cast_weights(W, torch.float64)
+    y64 = R.mmdit_forward(T(g["x"]).double(), W64["core"], meta["n_layers"], meta["n_heads"])
+    assert rel_err(y64, g["y"]) < 1e-5

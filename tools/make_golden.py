@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by importing the *reference* implementation (build container only).
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tools/make_golden.py [--full-size-report]
+
+The reference tree (/root/reference) is read-only and never travels to the GPU box; only the small
+``.npz`` fixtures written to ``tests/golden/`` do.  A fixture holds inputs, weights and the outputs
+the reference produced for them — no reference source.  If /root/reference is absent the script
+exits with a message (tests then rely on the committed fixtures alone).
+
+Fixture list: G1 schedules, G2 timestep embedding, G3 token index maps,
+G4 RMSNorm, G5 Block/MMDiT, G6 MultiModalNoiseHead, G7 ddim_step, G8 one CFG step both directions,
+G9 chained A->V via the reference's own ``sample_one_direction``, G10 TimestepEmbedder(mlp).
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REF = Path("/root/reference")
+OUT = Path(__file__).resolve().parent.parent / "tests" / "golden"
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _sd(mod):
+    return {k: _np(v) for k, v in mod.state_dict().items()}
+
+
+def _save(name, **arrays):
+    OUT.mkdir(parents=True, exist_ok=True)
+    path = OUT / name
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {path.name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays")
+
+
+def _flat(prefix, d):
+    return {f"{prefix}/{k}": v for k, v in d.items()}
+
+
+def small_cfg(load_config):
+    """mvp.yaml + a2v.yaml shrunk to a model whose weights fit in a small fixture."""
+    cfg = load_config(str(REF / "configs/mvp.yaml"), str(REF / "configs/a2v.yaml"))
+    cfg = copy.deepcopy(cfg)
+    cfg["paths"] = {}
+    cfg["video"]["size"] = [64, 64]            # latent 8x8
+    cfg["data"]["clip_seconds"] = 1.0          # 16 frames -> T'=4
+    cfg["audio"]["latent"]["frames_per_clip"] = 22
+    cfg["tokenizer"]["width"] = 128
+    cfg["embeddings"]["timestep_dim"] = 64
+    cfg["model"]["core"].update(d_model=128, n_layers=1, n_heads=2, mlp_ratio=2.0)
+    for m in ("video", "audio"):
+        cfg["model"]["heads"][m]["hidden_dim"] = 64
+    cfg["diffusion"]["video"]["sampler_steps"] = 4
+    cfg["diffusion"]["audio"]["sampler_steps"] = 4
+    return cfg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full-size-report", action="store_true",
+                    help="also compare oracle vs reference at mvp.yaml size (slow, writes a JSON report)")
+    args = ap.parse_args()
+    if not REF.exists():
+        print("reference tree not present; nothing to do (committed fixtures stay authoritative)")
+        return 0
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, str(REF))
+    from avdiff.utils import schedule_utils as su, ops
+    from avdiff.utils.io import load_config
+    from avdiff.models.mmdt import MMDiT, Block, RMSNorm
+    from avdiff.models.heads.noise_heads import MultiModalNoiseHead
+    from avdiff.models.adapters import TimestepEmbedder, TimestepCfg
+    from avdiff.models.infer import sample_clip as sc
+
+    torch.set_grad_enabled(False)
+
+    # ---- G1 schedules -------------------------------------------------------------------
+    g1 = {}
+    for kind in ("cosine", "linear", "sigmoid"):
+        b = su.make_beta_schedule(1000, kind=kind, min_beta=1e-4, max_beta=0.02)
+        _, ab = su.alphas_cumprod_from_betas(b)
+        g1[f"betas/{kind}"] = _np(b)
+        g1[f"abar/{kind}"] = _np(ab)
+    for S in (10, 25, 50, 60, 100):
+        g1[f"sched/{S}"] = _np(su.make_sampling_schedule(1000, S))
+    g1["sched/T50_S7"] = _np(su.make_sampling_schedule(50, 7))
+    _save("g1_schedules.npz", **g1)
+
+    # ---- G2 timestep embedding ----------------------------------------------------------
+    t = torch.tensor([0, 1, 17, 500, 982, 999], dtype=torch.long)
+    _save("g2_temb.npz", t=_np(t), e256=_np(su.timestep_embedding(t, 256)), e64=_np(su.timestep_embedding(t, 64)),
+          e7=_np(su.timestep_embedding(t, 7)))
+
+    # ---- G3 index maps ------------------------------------------------------------------
+    g3 = {}
+    for (C, T, H, W) in ((8, 12, 16, 16), (8, 12, 32, 32), (8, 4, 8, 8)):
+        z = torch.arange(C * T * H * W, dtype=torch.float32).view(1, C, T, H, W)
+        tok = ops.tube_patch_video(z, 2, 4, 4)
+        back = ops.tube_unpatch_video(tok, C=C, T=T, H=H, W=W, t=2, h=4, w=4)
+        assert torch.equal(back, z)
+        g3[f"patch/{C}x{T}x{H}x{W}"] = _np(tok).astype(np.int32)
+    za = torch.arange(2 * 8 * 150, dtype=torch.float32).view(2, 8, 150)
+    tok_a = sc.latents_to_tokens_audio(za, 4, 4)
+    g3["audio_tok/150"] = _np(tok_a).astype(np.int32)
+    g3["audio_untok/150"] = _np(sc.tokens_to_latents_audio(tok_a + 1.0, Ca=8, l_chunk=4, Fa=150, stride=4)).astype(np.int32)
+    zb = torch.randn(2, 8, 22, generator=torch.Generator().manual_seed(3))
+    tb = sc.latents_to_tokens_audio(zb, 4, 4)
+    g3["audio22/z"] = _np(zb)
+    g3["audio22/tok"] = _np(tb)
+    g3["audio22/untok"] = _np(sc.tokens_to_latents_audio(tb, Ca=8, l_chunk=4, Fa=22, stride=4))
+    # overlapping windows (stride < length) exercise the overlap-count normalisation
+    tc = sc.latents_to_tokens_audio(zb, 4, 2)
+    g3["audio22s2/tok"] = _np(tc)
+    g3["audio22s2/untok"] = _np(sc.tokens_to_latents_audio(tc, Ca=8, l_chunk=4, Fa=22, stride=2))
+    _save("g3_index.npz", **g3)
+
+    # ---- G4 RMSNorm ---------------------------------------------------------------------
+    gen = torch.Generator().manual_seed(4)
+    x = torch.randn(6, 512, generator=gen)
+    x[1] *= 1e-7          # near-zero row: eps (outside sqrt) dominates
+    x[2] = 0.0
+    x[3] *= 1e3
+    n = RMSNorm(512)
+    n.scale.copy_(1.0 + 0.1 * torch.randn(512, generator=gen))
+    _save("g4_rmsnorm.npz", x=_np(x), scale=_np(n.scale), y=_np(n(x)))
+
+    # ---- reduced model ------------------------------------------------------------------
+    cfg = small_cfg(load_config)
+    torch.manual_seed(0)
+    vid_vae, aud_codec, adapt_v, adapt_a, core, head, tdim = sc.build_components(cfg, torch.device("cpu"))
+    # perturb zero-init biases / unit norm scales so they are exercised
+    g = torch.Generator().manual_seed(5)
+    for mod in (core, head):
+        for name, p in mod.named_parameters():
+            if name.endswith("bias") or name.endswith("scale") or (".1.weight" in name):
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+    Wsmall = {**_flat("core", _sd(core)), **_flat("head", _sd(head)),
+              **_flat("adapt_v", _sd(adapt_v)), **_flat("adapt_a", _sd(adapt_a))}
+    meta = dict(d=128, n_layers=1, n_heads=2, tdim=64, mlp_ratio=2.0, head_hidden=64)
+
+    # ---- G5 Block / MMDiT ---------------------------------------------------------------
+    gen = torch.Generator().manual_seed(6)
+    x5 = torch.randn(2, 13, 128, generator=gen)
+    y_blk = core.blocks[0](x5)
+    y_core = core(x5)
+    x5b = torch.randn(3, 70, 128, generator=gen) * 2.0     # > one 64-key tile, ragged
+    _save("g5_mmdit_small.npz", x=_np(x5), y_block0=_np(y_blk), y=_np(y_core), x_b=_np(x5b), y_b=_np(core(x5b)),
+          meta=np.array(json.dumps(meta)), **Wsmall)
+
+    # ---- G6 MultiModalNoiseHead ---------------------------------------------------------
+    hv = torch.randn(2, 8, 128, generator=gen)
+    ha = torch.randn(2, 5, 128, generator=gen)
+    o = head({"video": hv, "audio": ha})
+    _save("g6_head_small.npz", hv=_np(hv), ha=_np(ha), out_v=_np(o["video"]), out_a=_np(o["audio"]))
+
+    # ---- G7 ddim_step -------------------------------------------------------------------
+    _, abar = su.alphas_cumprod_from_betas(su.make_beta_schedule(1000, "cosine", 1e-4, 0.02))
+    xt = torch.randn(5, 8, 2, 4, 4, generator=gen)
+    eh = torch.randn(5, 8, 2, 4, 4, generator=gen)
+    tn = torch.tensor([999, 500, 19, 982, 16], dtype=torch.long)
+    tp = torch.tensor([979, 480, -1, 966, -1], dtype=torch.long)
+    _save("g7_ddim.npz", x_t=_np(xt), eps=_np(eh), t_now=_np(tn), t_prev=_np(tp), abar=_np(abar),
+          x_prev=_np(su.ddim_step(xt, tn, tp, eh, abar, eta=0.0)))
+
+    # ---- G8 one CFG step in both directions (reference loop-body statements, batched) ----
+    B = 2
+    Cv, t_p, p = 8, 2, 4
+    l_chunk = s_chunk = 4
+    z_v = torch.randn(B, 8, 4, 8, 8, generator=gen)
+    z_a = torch.randn(B, 8, 22, generator=gen)
+    tn = torch.tensor([982, 500], dtype=torch.long)
+    tp = torch.tensor([966, 480], dtype=torch.long)
+    zero_t = torch.zeros(B, dtype=torch.long)
+    g8 = dict(z_v=_np(z_v), z_a=_np(z_a), t_now=_np(tn), t_prev=_np(tp), abar=_np(abar))
+    for guide in (0.0, 1.0, 3.5):
+        # A->V  (sample_clip.py:363-389)
+        tok_v = sc.latents_to_tokens_video(z_v, t_p=t_p, p=p)
+        tok_a = sc.latents_to_tokens_audio(z_a, l_chunk=l_chunk, s_chunk=s_chunk)
+        Nv = tok_v.size(1)
+        Xv = sc.add_sinusoidal_timestep(adapt_v(tok_v), tn, tdim)
+        Xa = sc.add_sinusoidal_timestep(adapt_a(tok_a), zero_t, tdim)
+        hc = core(torch.cat([Xv, Xa], 1))
+        ec = head({"video": hc[:, :Nv], "audio": hc[:, Nv:]})["video"]
+        hn = core(torch.cat([Xv, torch.zeros_like(Xa)], 1))
+        en = head({"video": hn[:, :Nv], "audio": hn[:, Nv:]})["video"]
+        et = en + guide * (ec - en)
+        el = ops.tube_unpatch_video(et, C=Cv, T=4, H=8, W=8, t=t_p, h=p, w=p)
+        g8[f"a2v/g{guide}/eps_tok"] = _np(et)
+        g8[f"a2v/g{guide}/z_next"] = _np(su.ddim_step(z_v, tn, tp, el, abar, eta=0.0))
+        if guide == 3.5:
+            g8["a2v/X"] = _np(torch.cat([Xv, Xa], 1))
+            g8["a2v/eps_cond"] = _np(ec)
+            g8["a2v/eps_null"] = _np(en)
+        # V->A  (sample_clip.py:322-348)
+        Xv = sc.add_sinusoidal_timestep(adapt_v(tok_v), zero_t, tdim)
+        Xa = sc.add_sinusoidal_timestep(adapt_a(tok_a), tn, tdim)
+        hc = core(torch.cat([Xv, Xa], 1))
+        ec = head({"video": hc[:, :Nv], "audio": hc[:, Nv:]})["audio"]
+        hn = core(torch.cat([torch.zeros_like(Xv), Xa], 1))
+        en = head({"video": hn[:, :Nv], "audio": hn[:, Nv:]})["audio"]
+        et = en + guide * (ec - en)
+        el = sc.tokens_to_latents_audio(et, Ca=8, l_chunk=l_chunk, Fa=22, stride=s_chunk)
+        g8[f"v2a/g{guide}/eps_tok"] = _np(et)
+        g8[f"v2a/g{guide}/z_next"] = _np(su.ddim_step(z_a, tn, tp, el, abar, eta=0.0))
+    _save("g8_cfg_step_small.npz", **g8)
+
+    # ---- G9 chained A->V through the reference's own sampler (B=1, 4 steps) ---------------
+    rec = {}
+    orig_enc, orig_dec = aud_codec.encode, vid_vae.decode
+
+    def enc_hook(w):
+        z = orig_enc(w)
+        rec["z_a0"] = z.clone()
+        return z
+
+    def dec_hook(z, *a, **k):
+        rec["z_final"] = z.clone()
+        return orig_dec(z, *a, **k)
+
+    aud_codec.encode, vid_vae.decode = enc_hook, dec_hook
+    wav = (0.1 * torch.randn(16000, generator=torch.Generator().manual_seed(9))).numpy().astype(np.float32)
+    torch.manual_seed(1234)
+    res = sc.sample_one_direction(cfg=cfg, vid_vae=vid_vae, aud_codec=aud_codec, adapt_v=adapt_v, adapt_a=adapt_a,
+                                  core=core, head=head, tstep_dim=tdim, prompt_modality="audio",
+                                  prompt_video=None, prompt_audio=wav, device=torch.device("cpu"))
+    aud_codec.encode, vid_vae.decode = orig_enc, orig_dec
+    torch.manual_seed(1234)
+    z_init = torch.randn(1, 8, 4, 8, 8)         # the sampler's only RNG draw (sample_clip.py:304)
+    _save("g9_chain_small.npz", z_init=_np(z_init), z_a0=_np(rec["z_a0"]), z_final=_np(rec["z_final"]),
+          sched=_np(su.make_sampling_schedule(1000, 4)), abar=_np(abar), guidance=np.float32(3.5),
+          frames_shape=np.array(res["video"].shape))
+
+    # ---- G10 TimestepEmbedder(mode="mlp") -------------------------------------------------
+    torch.manual_seed(10)
+    te = TimestepEmbedder(TimestepCfg(dim=64, mode="mlp"))
+    tt = torch.tensor([0, 3, 500, 999], dtype=torch.long)
+    _save("g10_tmlp.npz", t=_np(tt), y=_np(te(tt)), **_flat("w", _sd(te)))
+
+    # ---- optional: full-size live comparison oracle vs reference --------------------------
+    if args.full_size_report:
+        sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+        from oracle import ref_cpu as R
+        rep = {}
+        cfgF = load_config(str(REF / "configs/mvp.yaml"), str(REF / "configs/a2v.yaml"))
+        cfgF["paths"] = {}
+        torch.manual_seed(0)
+        _, _, av, aa, coreF, headF, tdF = sc.build_components(cfgF, torch.device("cpu"))
+        Wc = {k: v for k, v in coreF.state_dict().items()}
+        Wh = {k: v for k, v in headF.state_dict().items()}
+        for N in (133, 421):
+            x = torch.randn(2, N, 512, generator=torch.Generator().manual_seed(N))
+            ref = coreF(x)
+            mine = R.mmdit_forward(x, Wc, 8, 8)
+            rep[f"mmdit_N{N}_maxabs"] = float((ref - mine).abs().max())
+            rep[f"mmdit_N{N}_refmax"] = float(ref.abs().max())
+            hv = ref[:, : N - 37]
+            rep[f"head_N{N}_maxabs"] = float((headF({"video": hv})["video"] - R.noise_head(hv, Wh, "video")).abs().max())
+        (OUT / "fullsize_report.json").write_text(json.dumps(rep, indent=1))
+        print(json.dumps(rep, indent=1))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
