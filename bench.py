@@ -1,0 +1,241 @@
+#!/usr/bin/env python3
+"""Headline benchmark: denoising steps/sec @256x256 multimodal-cond, batch=32 per GPU, on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one CFG denoising step for a batch of 32 samples (reference loop body
+avdiff/models/infer/sample_clip.py:359-389: tokenise -> adapters -> t-emb -> MMDiT x2 (cond+null, stacked to 2B) ->
+noise head -> CFG -> un-patch -> DDIM), workload C3 of BASELINE.json (256x256 -> 384 video + 37 audio tokens,
+mvp.yaml model dims d=512 L=8 H=8), fp32, synthetic inputs, random-init weights, inputs resident in HBM.
+Weak scaling: every rank steps its own 32 samples; the only collective is one RCCL broadcast of the
+conditioning latents before the loop.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import torch
+
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+
+
+def step_flops_per_sample(nv: int, na: int, d: int = 512, L: int = 8, hid: int = 2048, tok: int = 256,
+                          head_hidden: int = 512, tdim: int = 256) -> float:
+    """Algorithmic FLOPs of one CFG step for one sample (head on target rows only)."""
+    n = nv + na
+    per_fwd = L * n * (2 * d * 3 * d + 2 * d * d + 2 * 2 * d * hid + 4 * n * d)
+    head = nv * (2 * d * head_hidden + 2 * 2 * head_hidden * head_hidden + 2 * head_hidden * tok)
+    adapt = nv * 2 * tok * (d - tdim)
+    return 2 * (per_fwd + head) + adapt
+
+
+def build_modules(device, seed=0):
+    import multimodal_diffusion_amd as A
+    torch.manual_seed(seed)
+    cfg = {
+        "tokenizer": {"width": 512},
+        "embeddings": {"timestep_dim": 256},
+        "model": {"core": dict(d_model=512, n_layers=8, n_heads=8, mlp_ratio=4.0, dropout=0.1, attn_dropout=0.0,
+                               norm="rmsnorm", rope=False, token_dropout=0.0),
+                  "heads": {"video": dict(out_dim=256, hidden_dim=512, activation="gelu"),
+                            "audio": dict(out_dim=32, hidden_dim=512, activation="gelu")}},
+    }
+    _, _, av, aa, core, head, tdim = A.build_components(cfg, torch.device("cpu"))
+    # non-trivial biases / norm scales so nothing is skipped by zeros
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for mod in (core, head):
+            for name, p in mod.named_parameters():
+                if p.dim() == 1:
+                    p.add_(0.02 * torch.randn(p.shape, generator=g))
+    mods = [m.to(device).eval() for m in (av, aa, core, head)]
+    return mods, tdim
+
+
+def cpu_state(mods):
+    av, aa, core, head = mods
+    f = lambda m: {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    return dict(adapt_v=f(av), adapt_a=f(aa), core=f(core), head=f(head))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=256, help="video size (square); 256 = BASELINE C3")
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU")
+    ap.add_argument("--sampler-steps", type=int, default=50)
+    ap.add_argument("--guidance", type=float, default=3.5)
+    ap.add_argument("--graph", action="store_true", help="replay a captured 2-step HIP graph instead of eager launches")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    args = ap.parse_args()
+
+    from multimodal_diffusion_amd import dist as D, schedule_utils as su, _lib as L
+    import multimodal_diffusion_amd as A
+
+    rank, world, local = D.init_from_env("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    B, size, S = args.batch, args.size, args.sampler_steps
+    lat = (B, 8, 12, size // 8, size // 8)
+    nv, na = 6 * (size // 32) ** 2, 37
+    mods, tdim = build_modules(dev)
+    av, aa, core, head = mods
+    abar = su.alphas_cumprod_from_betas(su.make_beta_schedule(1000, "cosine", 1e-4, 0.02))[1]
+    sched = su.make_sampling_schedule(1000, S)
+
+    # conditioning: root draws the global batch of prompt latents, ONE broadcast, each rank keeps its shard
+    gshape = (B * world, 8, 150)
+    cond = torch.randn(gshape, generator=torch.Generator().manual_seed(2)) if rank == 0 else None
+    cond_all = D.broadcast_conditioning(cond, gshape, dev)
+    z_a0 = D.local_conditioning(cond_all, rank, world)
+    z0 = torch.randn(lat, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+
+    eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=tdim, target="video",
+                          latent_shape=lat, prompt_tokens=na, alpha_bar=abar, guidance=args.guidance)
+    eng.set_prompt(z_a0)
+    eng.begin(sched)
+    za, zb = z0.clone(), torch.empty_like(z0)
+
+    graph = None
+    if args.graph:
+        eng.advance(za, zb)          # lazy init outside capture
+        eng.rewind()
+        za.copy_(z0)
+        graph = eng.capture_pair(za, zb)
+
+    state = {"i": 0}
+
+    def run_steps(k):
+        nonlocal za, zb
+        done = 0
+        while done < k:
+            if state["i"] % S == 0:          # new trajectory: restart the schedule from fresh noise
+                eng.rewind()
+                za.copy_(z0)
+            if graph is not None and (S - state["i"] % S) >= 2 and k - done >= 2:
+                graph.replay()
+                state["i"] += 2
+                done += 2
+            else:
+                eng.advance(za, zb)
+                za, zb = zb, za
+                state["i"] += 1
+                done += 1
+
+    run_steps(args.warmup)
+    state["i"] = 0
+    D.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    torch.cuda.synchronize()
+    D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    assert torch.isfinite(za).all(), "non-finite latent after the timed region"
+
+    out = None
+    if rank == 0:
+        fl = step_flops_per_sample(nv, na) * B
+        out = {
+            "metric": "denoising steps/sec @256x256 multimodal-cond batch=32",
+            "value": world * args.steps / dt,
+            "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C3: {size}x{size} audio->video CFG denoising step (cond+null MMDiT d512 L8 H8 + noise head + "
+                                   f"DDIM), {nv}+{na} tokens, batch {B} per GPU, DDIM {S} steps, guidance {args.guidance}",
+                       "global_batch": B * world, "tokens": nv + na, "sampler_steps": S,
+                       "parallelism": f"dp{world}", "launch": "hipgraph" if args.graph else "eager"},
+            "sample_steps_per_s": world * B * args.steps / dt,
+            "algorithmic_tflops": fl * world * args.steps / dt / 1e12,
+        }
+
+    # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream, separate instrumented pass
+    if rank == 0 and not args.no_roofline:
+        L.prof_enable(True)
+        state["i"] = 0
+        saved = graph
+        graph = None
+        run_steps(5)
+        graph = saved
+        torch.cuda.synchronize()
+        L.prof_enable(False)
+        rep = L.prof_report()
+        dom = max((k for k in rep if k.startswith("gemm")), key=lambda k: rep[k][1])
+        n, ms, work = rep[dom]
+        achieved = work / (ms * 1e-3) / 1e12
+        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
+                           "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                           "launches": n, "avg_launch_us": 1e3 * ms / max(n, 1),
+                           "flops_per_launch": work / max(n, 1)}
+        tot_ms = sum(v[1] for v in rep.values())
+        kern = {}
+        for k, (cnt, kms, w) in rep.items():
+            if cnt == 0:
+                continue
+            e = {"launches_per_step": cnt / 5, "ms_per_step": kms / 5, "share": kms / tot_ms}
+            if k.startswith("gemm") or k.startswith("attn"):
+                e["tflops"] = w / (kms * 1e-3) / 1e12
+                e["frac_of_f32_mfma_peak"] = e["tflops"] / PEAK_F32_MATRIX_TFLOPS
+            else:
+                e["gbs"] = w / (kms * 1e-3) / 1e9
+                e["frac_of_hbm_peak"] = e["gbs"] / PEAK_HBM_GBS
+            kern[k] = e
+        out["kernels"] = kern
+
+    # ---- CPU baseline: the oracle (a from-scratch torch port of the reference step) on this host's cores
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import ref_cpu as R
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        W = cpu_state(mods)
+        zc = z0.cpu()
+        zac = z_a0.cpu()
+        tn = torch.full((B,), int(sched[0]))
+        tp = torch.full((B,), int(sched[1]))
+        kw = dict(adapt_v=W["adapt_v"], adapt_a=W["adapt_a"], core=W["core"], head=W["head"], n_layers=8, n_heads=8,
+                  guidance=args.guidance)
+        with torch.no_grad():
+            ref = R.denoise_step_a2v(zc, zac, tn, tp, abar, **kw)           # warm-up, also the parity reference
+            c0 = time.perf_counter()
+            for _ in range(args.cpu_steps):
+                R.denoise_step_a2v(zc, zac, tn, tp, abar, **kw)
+            cdt = (time.perf_counter() - c0) / args.cpu_steps
+        got = eng.step(z0, tn.to(dev), tp.to(dev)).cpu()
+        err = float((got - ref).abs().max() / max(1.0, float(ref.abs().max())))
+        out["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "steps/s", "cores": cores, "kind": "port",
+                               "sample": f"{args.cpu_steps} timed steps (+1 warm-up) of the same batch-{B} {size}x{size} step, "
+                                         f"fp32 torch CPU oracle, {cores} threads",
+                               "ms_per_step": 1e3 * cdt}
+        out["parity_rel_err_vs_cpu_oracle"] = err
+
+    if rank == 0:
+        print(json.dumps(out))
+    D.barrier()
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,237 @@
+/* avdiff_hip.h — C ABI of libavdiff_hip.so: the MI355X (gfx950) denoising hot path of
+ * mauruszach/multimodal_diffusion behind the reference's Python nn.Module / sampler API.
+ *
+ * The reference has no FFI/plugin layer: its boundary for this path is a set of
+ * Python call signatures.  Each entry point below names the reference call it stands under
+ * (paths relative to the reference repo).  The host side (the multimodal_diffusion_amd package) binds these
+ * with ctypes and keeps the reference's class names, constructor kwargs, forward signatures and
+ * state_dict keys.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative AVD_E* code on failure;
+ *     avd_last_error() returns a thread-local human-readable message for the last failure.
+ *   - all tensor pointers are DEVICE pointers owned by the caller, fp32, contiguous unless a leading
+ *     dimension is given, 16-byte aligned; int64 for timesteps (as in the reference).
+ *   - nothing allocates, synchronises or copies to the host: every call only enqueues kernels on
+ *     `stream` (a hipStream_t passed as void*), so calls are stream-ordered and hipGraph-capturable.
+ *   - inputs are never written; outputs never alias inputs unless stated.
+ */
+#ifndef AVDIFF_HIP_H
+#define AVDIFF_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AVD_ABI_VERSION 1
+
+#define AVD_OK            0
+#define AVD_EINVAL       -1   /* bad shape / argument (reference: AssertionError / ValueError) */
+#define AVD_EUNSUPPORTED -2   /* shape outside what the gfx950 kernels are built for */
+#define AVD_ELAUNCH      -3   /* HIP launch error */
+#define AVD_EWORKSPACE   -4   /* workspace too small */
+
+#define AVD_ACT_NONE 0
+#define AVD_ACT_GELU 1        /* exact erf GELU (torch.nn.functional.gelu default) */
+#define AVD_ACT_SILU 2
+
+typedef void* avd_stream_t;   /* hipStream_t */
+
+int         avd_abi_version(void);
+const char* avd_last_error(void);
+/* gfx arch name of device 0 as seen by the library ("gfx950"); diagnostic only. */
+int         avd_device_arch(char* buf, int buflen);
+
+/* ---- a6: RMSNorm — avdiff/models/mmdt.py:33-42 (RMSNorm.forward)
+ * y = scale * x / (||x||_2 / sqrt(d) + eps), eps OUTSIDE the sqrt. x,y: [rows,d]. */
+int avd_rmsnorm_f32(const float* x, const float* scale, float* y, int64_t rows, int d, float eps,
+                    avd_stream_t stream);
+
+/* ---- a3/a6/a7: Linear (+bias)(+act)(+residual) — torch.nn.Linear as used at
+ * avdiff/models/mmdt.py:60 (packed in_proj / out_proj inside nn.MultiheadAttention), :77-83 (MLP fc1/fc2),
+ * avdiff/models/heads/noise_heads.py:206-223, avdiff/models/infer/sample_clip.py:54-56 (LinearAdapter).
+ * C[M,N] = act(A[M,K] · W[N,K]^T + bias[N]) + residual[M,N].   bias/residual may be NULL.
+ * lda/ldr/ldc are row strides in floats (multiples of 4).  K % 4 == 0, N % 4 == 0.
+ * f32-input MFMA (v_mfma_f32_32x32x2_f32): exact fp32 products, fp32 accumulate. */
+int avd_gemm_bias_act_f32(const float* A, int64_t lda, const float* W, const float* bias,
+                          const float* residual, int64_t ldr, float* C, int64_t ldc,
+                          int64_t M, int N, int K, int act, avd_stream_t stream);
+
+/* ---- a6: multi-head self-attention core — nn.MultiheadAttention(batch_first=True) at
+ * avdiff/models/mmdt.py:51-61 between in_proj and out_proj: out = softmax(q k^T * scale) v per head,
+ * no mask, eval.  qkv: [B,N,3*H*Dh] (q | k | v along the last dim, heads contiguous inside each),
+ * out: [B,N,H*Dh].  Dh must be 64.  n_query <= N limits the query rows computed (rows >= n_query of
+ * `out` are left untouched); pass N for the reference behaviour. */
+int avd_attn_fwd_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float scale,
+                     int n_query, avd_stream_t stream);
+
+/* ---- a7: LayerNorm(d, eps, affine) followed by an activation — the Linear→LayerNorm→GELU block of
+ * avdiff/models/heads/noise_heads.py:141-147.  x,y: [rows,d]. */
+int avd_layernorm_act_f32(const float* x, const float* gamma, const float* beta, float* y,
+                          int64_t rows, int d, float eps, int act, avd_stream_t stream);
+
+/* ---- a4: sinusoidal timestep embedding — avdiff/utils/schedule_utils.py:64-86.
+ * out[B,dim] = [cos(t*f) | sin(t*f)], f_i = exp(-ln(max_period)*i/half); odd dim zero-padded.
+ * freqs: optional device table [dim/2] of f_i built by the host exactly as the reference builds it
+ * (cos/sin at t ~ 1000 turn a 1-ulp difference in exp into 6e-5); NULL computes f_i in the kernel. */
+int avd_timestep_embedding_f32(const int64_t* t, const float* freqs, float* out, int B, int dim, float max_period,
+                               avd_stream_t stream);
+
+/* ---- a1 / a8: tube patch / unpatch — avdiff/utils/ops.py:100-119, 122-144.
+ * z: [B,C,T,H,W]  <->  tok: [B, (T/t)(H/h)(W/w), C*t*h*w].  w % 4 == 0 and W % 4 == 0. */
+int avd_tube_patch_f32(const float* z, float* tok, int B, int C, int T, int H, int W, int t, int h, int w,
+                       avd_stream_t stream);
+int avd_tube_unpatch_f32(const float* tok, float* z, int B, int C, int T, int H, int W, int t, int h, int w,
+                         avd_stream_t stream);
+
+/* ---- a2 / a8': audio chunk tokens and their overlap-add inverse —
+ * avdiff/models/infer/sample_clip.py:184-188 and :191-215 (-> avdiff/utils/ops.py:17-45, 48-93).
+ * z: [B,Ca,F] -> tok: [B,Na,Ca*len], Na = (F-len)/stride + 1.  Inverse: rectangular-window overlap-add,
+ * divided by the overlap count, cropped / zero-padded to F frames. */
+int avd_audio_tokens_f32(const float* z, float* tok, int B, int Ca, int F, int len, int stride,
+                         avd_stream_t stream);
+int avd_audio_untokens_f32(const float* tok, float* z, int B, int Ca, int F, int len, int stride,
+                           avd_stream_t stream);
+
+/* ---- a8: DDIM update — avdiff/utils/schedule_utils.py:146-200 (ddim_step).
+ * x_t, eps_hat, x_prev: [B, per_sample]; t_now,t_prev: int64[B] (t_prev may be -1 => abar_prev = 1);
+ * alpha_bar: fp32[T_train].  eta > 0 requires `noise` (same shape as x_t); eta == 0 ignores it. */
+int avd_ddim_step_f32(const float* x_t, const float* eps_hat, const int64_t* t_now, const int64_t* t_prev,
+                      const float* alpha_bar, int T_train, float eta, const float* noise,
+                      float* x_prev, int B, int64_t per_sample, avd_stream_t stream);
+
+/* ---- a8 fused: CFG combine + tube un-patch + DDIM — avdiff/models/infer/sample_clip.py:381-389.
+ * eps2: [2B,Nv,C*t*h*w] (cond batch then null batch); eps = null + g*(cond-null); un-patched on the fly.
+ * z, z_out: [B,C,T,H,W]. */
+int avd_cfg_unpatch_ddim_f32(const float* eps2, const float* z, const int64_t* t_now, const int64_t* t_prev,
+                             const float* alpha_bar, int T_train, float guidance, float eta,
+                             const float* noise, float* z_out,
+                             int B, int C, int T, int H, int W, int t, int h, int w, avd_stream_t stream);
+
+/* ---- a8' fused: CFG combine + audio overlap-add + DDIM — sample_clip.py:342-348.
+ * eps2: [2B,Na,Ca*len]; z,z_out: [B,Ca,F]. */
+int avd_cfg_untoken_ddim_audio_f32(const float* eps2, const float* z, const int64_t* t_now,
+                                   const int64_t* t_prev, const float* alpha_bar, int T_train,
+                                   float guidance, float eta, const float* noise, float* z_out,
+                                   int B, int Ca, int F, int len, int stride, avd_stream_t stream);
+
+/* ---- a1+a3+a4+a5 fused front end — sample_clip.py:363-371,377 (A->V) / :322-333,338 (V->A).
+ * Builds the CFG-stacked sequence X2[2B, Nt+Np, d] in one pass:
+ *   target rows : [ adapter(tokens(z_target)) | temb(t_now[b]) ]   (same in both halves)
+ *   prompt rows : Xp[b] in the cond half, zeros in the null half (whole d-wide rows, as the reference)
+ * target_kind 0 = video latent [B,C,T,H,W] with tubes (p0,p1,p2)=(t,h,w); 1 = audio latent [B,Ca,F]
+ * with chunk (p0,p1)=(len,stride).  target_first != 0 puts target rows before prompt rows
+ * (the reference's order is always [video ; audio]).
+ * Xp: [B,Np,d] = adapter(prompt tokens) | temb(0), computed once per run by the caller.
+ * tok_ws: scratch [B*Nt, tok_dim].  Wt: [d-tdim, tok_dim], bt: [d-tdim]. */
+typedef struct {
+    int target_kind;      /* 0 video, 1 audio */
+    int target_first;
+    int B, d, tdim;
+    int C, T, H, W;       /* video latent dims (target_kind 0) — or Ca=C, F=T for audio */
+    int p0, p1, p2;
+    int Nt, Np;
+    const float* temb_freqs;   /* optional device table [tdim/2], see avd_timestep_embedding_f32; may be NULL */
+} avd_embed_desc;
+/* floats of scratch `tok_ws` must hold (tokens + the [B,tdim] timestep embedding); -1 on a bad descriptor */
+int64_t avd_embed_workspace_floats(const avd_embed_desc* desc);
+int avd_embed_cfg_pair_f32(const avd_embed_desc* desc, const float* z_target, const float* Wt, const float* bt,
+                           const int64_t* t_now, const float* Xp, float* tok_ws, float* X2,
+                           avd_stream_t stream);
+
+/* ---- composites: whole modules / the whole step as one host call (stateless; weights by pointer table).
+ * These enqueue exactly the kernels above in order; they exist to keep the per-step host cost at one FFI
+ * call and to make a step one hipGraph-capturable unit. */
+typedef struct {                       /* avdiff/models/mmdt.py:88-99 (Block) state_dict, device ptrs */
+    const float* norm1_scale;          /* blocks.{i}.norm1.scale              [d]      */
+    const float* in_proj_weight;       /* blocks.{i}.attn.mha.in_proj_weight  [3d,d]   */
+    const float* in_proj_bias;         /* blocks.{i}.attn.mha.in_proj_bias    [3d]     */
+    const float* out_proj_weight;      /* blocks.{i}.attn.mha.out_proj.weight [d,d]    */
+    const float* out_proj_bias;        /* blocks.{i}.attn.mha.out_proj.bias   [d]      */
+    const float* norm2_scale;          /* blocks.{i}.norm2.scale              [d]      */
+    const float* fc1_weight;           /* blocks.{i}.mlp.fc1.weight           [hid,d]  */
+    const float* fc1_bias;             /* blocks.{i}.mlp.fc1.bias             [hid]    */
+    const float* fc2_weight;           /* blocks.{i}.mlp.fc2.weight           [d,hid]  */
+    const float* fc2_bias;             /* blocks.{i}.mlp.fc2.bias             [d]      */
+} avd_block_weights;
+
+typedef struct {                       /* avdiff/models/mmdt.py:116-149 (MMDiT) */
+    int d, n_layers, n_heads, mlp_hidden;
+    float norm_eps;                    /* 1e-6 */
+    const avd_block_weights* blocks;   /* HOST array [n_layers] of device-pointer tables */
+    const float* final_norm_scale;     /* final_norm.scale [d] */
+} avd_core_weights;
+
+typedef struct {                       /* avdiff/models/heads/noise_heads.py:94-229, one modality path */
+    int d_in, hidden, d_out, n_shared;
+    float ln_eps;                      /* 1e-5 */
+    int act;                           /* AVD_ACT_GELU */
+    const float* input_proj_weight;    /* input_proj.{m}.weight [hidden,d_in] */
+    const float* input_proj_bias;
+    const float* const* shared_lin_weight;  /* HOST array [n_shared]: shared.{j}.0.weight [hidden,hidden] */
+    const float* const* shared_lin_bias;
+    const float* const* shared_ln_weight;   /* shared.{j}.1.weight [hidden] */
+    const float* const* shared_ln_bias;
+    const float* out_proj_weight;      /* out_proj.{m}.weight [d_out,hidden] */
+    const float* out_proj_bias;
+} avd_head_weights;
+
+/* bytes of scratch avd_core_forward_f32 needs for a [B,N,d] input */
+int64_t avd_core_workspace_bytes(const avd_core_weights* w, int B, int N);
+/* MMDiT.forward(x) -> y, x,y: [B,N,d] (y may alias x).  n_out_rows: number of leading rows per sample whose
+ * output is needed (N = reference behaviour; fewer lets the last block skip dead rows when the caller only
+ * consumes the first n_out_rows — the engine passes the target-row count). out_row0: first needed row. */
+int avd_core_forward_f32(const avd_core_weights* w, const float* x, float* y, int B, int N,
+                         int out_row0, int n_out_rows, void* workspace, int64_t workspace_bytes,
+                         avd_stream_t stream);
+
+int64_t avd_head_workspace_bytes(const avd_head_weights* w, int64_t rows);
+/* MultiModalNoiseHead path for ONE modality over `rows` token rows taken from h with segmented addressing:
+ * row r lives at h + (r / seg_rows) * seg_stride + (r % seg_rows) * ldh.  out: [rows, d_out] contiguous. */
+int avd_head_forward_f32(const avd_head_weights* w, const float* h, int64_t ldh, int64_t seg_rows,
+                         int64_t seg_stride, int64_t rows, float* out, void* workspace,
+                         int64_t workspace_bytes, avd_stream_t stream);
+
+typedef struct {                       /* one whole CFG denoising step (sample_clip.py:359-389 / 318-348) */
+    avd_embed_desc embed;
+    const avd_core_weights* core;
+    const avd_head_weights* head;      /* the TARGET modality's path */
+    const float* adapt_w; const float* adapt_b;   /* target adapter */
+    const float* alpha_bar; int T_train;
+    float guidance, eta;
+} avd_step_desc;
+int64_t avd_step_workspace_bytes(const avd_step_desc* s);
+/* z_out = DDIM(z, eps_cfg(z, Xp, t_now), t_now -> t_prev).  z_out must not alias z. */
+int avd_denoise_step_f32(const avd_step_desc* s, const float* z, const float* Xp, const int64_t* t_now,
+                         const int64_t* t_prev, const float* noise, float* z_out,
+                         void* workspace, int64_t workspace_bytes, avd_stream_t stream);
+
+/* device-side sampling-schedule cursor so a captured step can be replayed without host writes:
+ * t_now[b] = sched[*cursor], t_prev[b] = sched[*cursor+1] for all b, then (*cursor)++ . */
+int avd_sched_advance(const int64_t* sched, int n_sched, int32_t* cursor, int64_t* t_now, int64_t* t_prev,
+                      int B, avd_stream_t stream);
+
+/* ---- measurement hooks (bench.py): when enabled, every kernel launch made by this library is bracketed by
+ * hipEvents recorded on the launch stream and tagged with a kernel class and its algorithmic work
+ * (FLOPs for the MFMA kernels, bytes for the HBM-bound ones).  Disabled by default; zero cost when off.
+ * Not for use while a stream is being captured into a graph. */
+#define AVD_PROF_GEMM_128x128 0
+#define AVD_PROF_GEMM_128x64  1
+#define AVD_PROF_GEMM_64x64   2
+#define AVD_PROF_GEMM_128x32  3
+#define AVD_PROF_ATTN         4
+#define AVD_PROF_RMSNORM      5
+#define AVD_PROF_LAYERNORM    6
+#define AVD_PROF_CFG_DDIM     7
+#define AVD_PROF_TOKENS       8   /* patch / assemble / temb / misc */
+#define AVD_PROF_NTAGS        9
+int avd_prof_enable(int on);      /* on=1 start recording (clears previous records), on=0 stop */
+/* synchronises the recorded events and accumulates per tag: launches, total milliseconds, algorithmic work */
+int avd_prof_report(int64_t* launches, double* total_ms, double* work, int ntags);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVDIFF_HIP_H */

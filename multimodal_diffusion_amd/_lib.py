@@ -1,0 +1,160 @@
+"""ctypes binding of ``libavdiff_hip.so`` (C ABI declared in ``include/avdiff_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the stream; every compute call goes through the C ABI
+with raw device pointers.  There is NO fallback: if the shared library is missing or a tensor is not on a
+ROCm device the call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional
+
+import torch
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = Path(os.environ.get("AVDIFF_HIP_LIB", _HERE / "csrc" / "libavdiff_hip.so"))
+
+ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+EINVAL, EUNSUPPORTED, ELAUNCH, EWORKSPACE = -1, -2, -3, -4
+
+
+class AvdError(RuntimeError):
+    """A HIP-side failure (launch error, unsupported shape, workspace)."""
+
+
+class EmbedDesc(C.Structure):
+    _fields_ = [("target_kind", C.c_int), ("target_first", C.c_int), ("B", C.c_int), ("d", C.c_int),
+                ("tdim", C.c_int), ("C", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("p0", C.c_int), ("p1", C.c_int), ("p2", C.c_int), ("Nt", C.c_int), ("Np", C.c_int),
+                ("temb_freqs", C.c_void_p)]
+
+
+class BlockWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "norm1_scale", "in_proj_weight", "in_proj_bias", "out_proj_weight", "out_proj_bias",
+        "norm2_scale", "fc1_weight", "fc1_bias", "fc2_weight", "fc2_bias")]
+
+
+class CoreWeights(C.Structure):
+    _fields_ = [("d", C.c_int), ("n_layers", C.c_int), ("n_heads", C.c_int), ("mlp_hidden", C.c_int),
+                ("norm_eps", C.c_float), ("blocks", C.POINTER(BlockWeights)), ("final_norm_scale", C.c_void_p)]
+
+
+class HeadWeights(C.Structure):
+    _fields_ = [("d_in", C.c_int), ("hidden", C.c_int), ("d_out", C.c_int), ("n_shared", C.c_int),
+                ("ln_eps", C.c_float), ("act", C.c_int),
+                ("input_proj_weight", C.c_void_p), ("input_proj_bias", C.c_void_p),
+                ("shared_lin_weight", C.POINTER(C.c_void_p)), ("shared_lin_bias", C.POINTER(C.c_void_p)),
+                ("shared_ln_weight", C.POINTER(C.c_void_p)), ("shared_ln_bias", C.POINTER(C.c_void_p)),
+                ("out_proj_weight", C.c_void_p), ("out_proj_bias", C.c_void_p)]
+
+
+class StepDesc(C.Structure):
+    _fields_ = [("embed", EmbedDesc), ("core", C.POINTER(CoreWeights)), ("head", C.POINTER(HeadWeights)),
+                ("adapt_w", C.c_void_p), ("adapt_b", C.c_void_p), ("alpha_bar", C.c_void_p), ("T_train", C.c_int),
+                ("guidance", C.c_float), ("eta", C.c_float)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); must list every symbol include/avdiff_hip.h declares
+SIGNATURES = {
+    "avd_abi_version": (_I, []),
+    "avd_last_error": (C.c_char_p, []),
+    "avd_device_arch": (_I, [C.c_char_p, _I]),
+    "avd_rmsnorm_f32": (_I, [_P, _P, _P, _L, _I, _F, _P]),
+    "avd_gemm_bias_act_f32": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _L, _I, _I, _I, _P]),
+    "avd_attn_fwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "avd_layernorm_act_f32": (_I, [_P, _P, _P, _P, _L, _I, _F, _I, _P]),
+    "avd_timestep_embedding_f32": (_I, [_P, _P, _P, _I, _I, _F, _P]),
+    "avd_tube_patch_f32": (_I, [_P, _P] + [_I] * 8 + [_P]),
+    "avd_tube_unpatch_f32": (_I, [_P, _P] + [_I] * 8 + [_P]),
+    "avd_audio_tokens_f32": (_I, [_P, _P] + [_I] * 5 + [_P]),
+    "avd_audio_untokens_f32": (_I, [_P, _P] + [_I] * 5 + [_P]),
+    "avd_ddim_step_f32": (_I, [_P, _P, _P, _P, _P, _I, _F, _P, _P, _I, _L, _P]),
+    "avd_cfg_unpatch_ddim_f32": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _P, _P] + [_I] * 8 + [_P]),
+    "avd_cfg_untoken_ddim_audio_f32": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _P, _P] + [_I] * 5 + [_P]),
+    "avd_embed_workspace_floats": (_L, [C.POINTER(EmbedDesc)]),
+    "avd_embed_cfg_pair_f32": (_I, [C.POINTER(EmbedDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
+    "avd_core_workspace_bytes": (_L, [C.POINTER(CoreWeights), _I, _I]),
+    "avd_core_forward_f32": (_I, [C.POINTER(CoreWeights), _P, _P, _I, _I, _I, _I, _P, _L, _P]),
+    "avd_head_workspace_bytes": (_L, [C.POINTER(HeadWeights), _L]),
+    "avd_head_forward_f32": (_I, [C.POINTER(HeadWeights), _P, _L, _L, _L, _L, _P, _P, _L, _P]),
+    "avd_step_workspace_bytes": (_L, [C.POINTER(StepDesc)]),
+    "avd_denoise_step_f32": (_I, [C.POINTER(StepDesc), _P, _P, _P, _P, _P, _P, _P, _L, _P]),
+    "avd_sched_advance": (_I, [_P, _I, _P, _P, _P, _I, _P]),
+    "avd_prof_enable": (_I, [_I]),
+    "avd_prof_report": (_I, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
+}
+
+PROF_TAGS = ("gemm_f32_kernel<128,128,64,64>", "gemm_f32_kernel<128,64,64,32>", "gemm_f32_kernel<64,64,32,32>",
+             "gemm_f32_kernel<128,32,32,32>", "attn_f32_kernel", "rmsnorm_kernel", "layernorm_act_kernel",
+             "cfg_unpatch_ddim_kernel", "token_kernels")
+
+
+def prof_enable(on: bool) -> None:
+    check(lib().avd_prof_enable(1 if on else 0))
+
+
+def prof_report():
+    """{kernel class: (launches, total_ms, algorithmic work)} for the launches recorded since prof_enable(True)."""
+    n = len(PROF_TAGS)
+    cnt, ms, work = (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)()
+    check(lib().avd_prof_report(cnt, ms, work, n))
+    return {PROF_TAGS[i]: (int(cnt[i]), float(ms[i]), float(work[i])) for i in range(n)}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load the HIP library (once).  Raises if it has not been built — there is no CPU path."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise AvdError(
+                f"{LIB_PATH} not found: build it with `make -C multimodal_diffusion_amd/csrc` "
+                "(or __graft_entry__.build()); this package has no CPU/PyTorch fallback")
+        handle = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)   # AttributeError if the .so is stale / missing a symbol
+            fn.restype, fn.argtypes = res, args
+        if handle.avd_abi_version() != 1:
+            raise AvdError(f"ABI version mismatch: library {handle.avd_abi_version()}, binding 1")
+        _lib = handle
+    return _lib
+
+
+def check(rc: int) -> None:
+    if rc == 0:
+        return
+    msg = lib().avd_last_error().decode("utf-8", "replace")
+    if rc == EINVAL:
+        raise ValueError(msg)
+    raise AvdError(f"[avd {rc}] {msg}")
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def dev_f32(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:
+    """Validate a tensor handed to a kernel: ROCm device, fp32, contiguous (made so if not)."""
+    if not t.is_cuda:
+        raise AvdError(f"{name} is on {t.device}: the HIP hot path needs ROCm device tensors (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32 (the reference path is fp32), got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def dev_i64(t: torch.Tensor, device: torch.device, name: str = "timesteps") -> torch.Tensor:
+    if t.dtype != torch.long:
+        t = t.long()
+    if t.device != device:
+        t = t.to(device)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,210 @@
+// fp32 multi-head self-attention core for the MMDiT blocks (head_dim 64, no mask, eval):
+//   out[b,n,h,:] = softmax_j(q[b,n,h]·k[b,j,h] * scale) · v[b,j,h]
+// Stands under nn.MultiheadAttention's scaled-dot-product step (avdiff/models/mmdt.py:51-61) between the packed
+// in_proj and out_proj GEMMs.  The "cross-attention over conditioning tokens" of the task description is the
+// off-diagonal block of this one joint softmax over [target ; prompt] tokens (sample_clip.py:371-375).
+//
+// Design (MI355X, flash-style, both contractions on v_mfma_f32_32x32x2_f32 = exact fp32):
+//  * one wave owns 32 query rows; a block is NW waves sharing 64-key K/V tiles through LDS.
+//  * the score tile is computed TRANSPOSED, S^T = K·Q^T, so a lane holds 16 keys of ONE query column:
+//    the row max / row sum are in-register reductions plus a single cross-half shuffle.
+//  * the MFMA k index may be summed in any order, so the accumulator register s of S^T (key row
+//    kappa(s,half)) is used directly as the B operand of step s of O^T = V^T·P^T — P never moves between
+//    lanes or through LDS; V is read from LDS row kappa(s,half), 32 consecutive floats per half-wave
+//    (conflict-free ds_read_b32).
+//  * K fragments are ds_read_b128 from [key][64+4]-padded rows (conflict-free), four MFMA steps per read.
+//  * K/V tiles are register-prefetched (global loads issued before the tile's MFMAs) into a single LDS
+//    buffer; 2 waves/SIMD co-reside so one wave's softmax VALU work hides under its partner's MFMAs.
+#include "avd_common.h"
+
+namespace avd {
+
+constexpr int ATT_DH = 64;
+constexpr int ATT_KT = 64;            // keys per tile
+constexpr int ATT_KLD = ATT_DH + 4;   // padded K row
+constexpr int ATT_VLD = ATT_DH;
+constexpr float ATT_NEG = -1.0e30f;
+constexpr float LOG2E = 1.4426950408889634f;
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                              int N, int H, float scale, int n_query) {
+    constexpr int NT = NW * 64;
+    constexpr int CH = ATT_KT * (ATT_DH / 4) / NT;   // float4 chunks per thread per matrix
+    __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * ATT_KLD];
+    __shared__ __attribute__((aligned(16))) float Vs[ATT_KT * ATT_VLD];
+
+    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int d = H * ATT_DH;
+    const int64_t rs = 3 * (int64_t)d;
+    const float* base = qkv + (int64_t)b * N * rs + h * ATT_DH;
+    const float* kp = base + d;
+    const float* vp = base + 2 * d;
+
+    // ---- Q fragment: lane (q = l31, half hi) holds Q[q][32*hi + s], s = 0..31, pre-scaled ----
+    const int q_row = qb * (NW * 32) + wave * 32 + l31;
+    float qf[32];
+    {
+        const int qr = q_row < N ? q_row : N - 1;
+        const float* src = base + (int64_t)qr * rs + 32 * hi;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * c);
+            qf[4 * c + 0] = t[0] * scale;
+            qf[4 * c + 1] = t[1] * scale;
+            qf[4 * c + 2] = t[2] * scale;
+            qf[4 * c + 3] = t[3] * scale;
+        }
+    }
+
+    f32x4 rk[CH], rv[CH];
+    auto load_tile = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = tid + i * NT;
+            const int key = kt * ATT_KT + (c >> 4);
+            const int col = (c & 15) * 4;
+            if (key < N) {
+                rk[i] = *reinterpret_cast<const f32x4*>(kp + (int64_t)key * rs + col);
+                rv[i] = *reinterpret_cast<const f32x4*>(vp + (int64_t)key * rs + col);
+            } else {
+                rk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int c = tid + i * NT;
+            const int kl = c >> 4, col = (c & 15) * 4;
+            *reinterpret_cast<f32x4*>(&Ks[kl * ATT_KLD + col]) = rk[i];
+            *reinterpret_cast<f32x4*>(&Vs[kl * ATT_VLD + col]) = rv[i];
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = ATT_NEG, l_run = 0.f;
+
+    const int nkt = (N + ATT_KT - 1) / ATT_KT;
+    load_tile(0);
+    store_tile();
+    __syncthreads();
+
+    const int k_rd = l31 * ATT_KLD + 32 * hi;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = (kt + 1) < nkt;
+        if (more) load_tile(kt + 1);
+
+        // ---- S^T = K·Q^T for keys [0,32) and [32,64) of the tile ----
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 ka = *reinterpret_cast<const f32x4*>(&Ks[k_rd + 4 * c]);
+            const f32x4 kb = *reinterpret_cast<const f32x4*>(&Ks[k_rd + 32 * ATT_KLD + 4 * c]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[j], qf[4 * c + j], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[j], qf[4 * c + j], s1, 0, 0, 0);
+            }
+        }
+        if (!more && (N & (ATT_KT - 1))) {   // ragged last tile: keys >= N contribute nothing
+            const int kbase = kt * ATT_KT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kbase + mfma32_row(r, hi);
+                if (key >= N) s0[r] = ATT_NEG;
+                if (key + 32 >= N) s1[r] = ATT_NEG;
+            }
+        }
+
+        // ---- online softmax for this lane's query column ----
+        float mt = s0[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s0[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s1[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f((s0[r] - m_new) * LOG2E);
+            s1[r] = __builtin_amdgcn_exp2f((s1[r] - m_new) * LOG2E);
+            ps += s0[r] + s1[r];
+        }
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+
+        // ---- O^T += V^T · P^T ; step s consumes key row kappa(s,hi) of each 32-key half ----
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int kr = mfma32_row(s, hi);
+            const float va0 = Vs[kr * ATT_VLD + l31];
+            const float va1 = Vs[kr * ATT_VLD + 32 + l31];
+            const float vb0 = Vs[(32 + kr) * ATT_VLD + l31];
+            const float vb1 = Vs[(32 + kr) * ATT_VLD + 32 + l31];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, s0[s], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, s0[s], o1, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb0, s1[s], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb1, s1[s], o1, 0, 0, 0);
+        }
+
+        __syncthreads();
+        if (more) {
+            store_tile();
+            __syncthreads();
+        }
+    }
+
+    // ---- normalise and store: lane (q, hi) holds O[q][8*g + 4*hi + (0..3)] in regs 4g..4g+3 ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < n_query) {
+        float* dst = out + ((int64_t)b * N + q_row) * d + h * ATT_DH + 4 * hi;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 a = {o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv};
+            f32x4 c = {o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv};
+            *reinterpret_cast<f32x4*>(dst + 8 * g4) = a;
+            *reinterpret_cast<f32x4*>(dst + 32 + 8 * g4) = c;
+        }
+    }
+}
+
+int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st) {
+    AVD_REQUIRE(qkv && out, AVD_EINVAL, "attn: null pointer");
+    AVD_REQUIRE(B > 0 && N > 0 && H > 0, AVD_EINVAL, "attn: bad dims B=%d N=%d H=%d", B, N, H);
+    AVD_REQUIRE(Dh == ATT_DH, AVD_EUNSUPPORTED, "attn: head_dim %d unsupported (kernel is built for 64)", Dh);
+    AVD_REQUIRE(n_query >= 0 && n_query <= N, AVD_EINVAL, "attn: n_query=%d outside [0,%d]", n_query, N);
+    AVD_REQUIRE(aligned16(qkv) && aligned16(out), AVD_EUNSUPPORTED, "attn: pointers must be 16-byte aligned");
+    AVD_REQUIRE(H <= 65535 && B <= 65535, AVD_EUNSUPPORTED, "attn: grid too large");
+    if (n_query == 0) return AVD_OK;
+    // 2-wave blocks (64 query rows) waste the fewest padded rows on the ragged N of this model
+    // (421 -> 448); 4-wave blocks halve K/V re-reads when N is a comfortable multiple of 128.
+    ProfScope prof(AVD_PROF_ATTN, 4.0 * (double)B * H * (double)n_query * N * ATT_DH, st);
+    const int pad2 = ((n_query + 63) / 64) * 64, pad4 = ((n_query + 127) / 128) * 128;
+    if (pad4 == pad2) {
+        hipLaunchKernelGGL(attn_f32_kernel<4>, dim3(pad4 / 128, H, B), dim3(256), 0, st, qkv, out, N, H, scale, n_query);
+    } else {
+        hipLaunchKernelGGL(attn_f32_kernel<2>, dim3(pad2 / 64, H, B), dim3(128), 0, st, qkv, out, N, H, scale, n_query);
+    }
+    AVD_CHECK_LAUNCH("attn_f32");
+    return AVD_OK;
+}
+
+}  // namespace avd
+
+extern "C" int avd_attn_fwd_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float scale,
+                                int n_query, avd_stream_t stream) {
+    return avd::attn_f32(qkv, out, B, N, H, Dh, scale, n_query, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,82 @@
+// Internal helpers shared by the gfx950 kernels of libavdiff_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/avdiff_hip.h"
+
+namespace avd {
+
+int set_error(int code, const char* fmt, ...);
+
+#define AVD_REQUIRE(cond, code, ...)                       \
+    do {                                                   \
+        if (!(cond)) return avd::set_error((code), __VA_ARGS__); \
+    } while (0)
+
+#define AVD_CHECK_LAUNCH(name)                                                          \
+    do {                                                                                \
+        hipError_t e__ = hipGetLastError();                                             \
+        if (e__ != hipSuccess)                                                          \
+            return avd::set_error(AVD_ELAUNCH, "%s: %s", (name), hipGetErrorString(e__)); \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWave = 64;
+
+// row index of accumulator register r for the lane half hi in a 32x32 MFMA C/D tile
+__device__ __forceinline__ int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+template <int ACT>
+__device__ __forceinline__ float apply_act(float x) {
+    if constexpr (ACT == AVD_ACT_GELU) return gelu_erf(x);
+    else if constexpr (ACT == AVD_ACT_SILU) return silu(x);
+    else return x;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Segmented row addressing: logical row r of a [rows, ld] matrix whose rows come in groups of `seg`
+// consecutive rows, groups `stride` floats apart (seg <= 0 means plain row-major).
+struct RowMap {
+    int64_t ld;
+    int64_t seg;
+    int64_t stride;
+    __host__ __device__ __forceinline__ int64_t off(int64_t r) const {
+        return seg > 0 ? (r / seg) * stride + (r % seg) * ld : r * ld;
+    }
+};
+
+// measurement hooks (see avd_prof_enable): RAII bracket around one launch
+extern bool g_prof_on;
+void prof_mark(int tag, double work, hipStream_t st, bool begin);
+struct ProfScope {
+    int tag; hipStream_t st; bool on;
+    ProfScope(int t, double work, hipStream_t s) : tag(t), st(s), on(g_prof_on) { if (on) prof_mark(tag, work, st, true); }
+    ~ProfScope() { if (on) prof_mark(tag, 0.0, st, false); }
+};
+
+// internal launchers used by the composites (same kernels as the public entry points)
+int gemm_f32(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm,
+             float* C, RowMap cm, int64_t M, int N, int K, int act, hipStream_t st);
+
+int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st);
+int rmsnorm_f32(const float* x, RowMap xm, const float* scale, float* y, RowMap ym, int64_t rows, int d, float eps,
+                hipStream_t st);
+int layernorm_act_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int d, float eps,
+                      int act, hipStream_t st);
+
+}  // namespace avd

@@ -1,0 +1,312 @@
+// Library plumbing (errors, version) and the stateless composites: MMDiT forward, noise-head forward, the fused
+// front end and one whole CFG denoising step.  A composite only enqueues the kernels of the other files, in
+// order, on the caller's stream — one FFI call per module / per step, hipGraph-capturable.
+#include "avd_common.h"
+
+#include <string.h>
+#include <vector>
+
+namespace avd {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ---------------------------------------------------------------- measurement hooks
+bool g_prof_on = false;
+namespace {
+struct ProfRec { hipEvent_t a, b; int tag; double work; };
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t take_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+}  // namespace
+void prof_mark(int tag, double work, hipStream_t st, bool begin) {
+    if (begin) {
+        ProfRec r{take_event(), take_event(), tag, work};
+        (void)hipEventRecord(r.a, st);
+        g_recs.push_back(r);
+    } else if (!g_recs.empty()) {
+        (void)hipEventRecord(g_recs.back().b, st);
+    }
+}
+
+int temb_f32(const int64_t* t, const float* freqs, float* out, int B, int dim, float max_period, hipStream_t st);
+int tube_patch_f32(const float* z, float* tok, int B, int C, int T, int H, int W, int t, int h, int w, hipStream_t st);
+int audio_tokens_f32(const float* z, float* tok, int B, int Ca, int F, int len, int stride, hipStream_t st);
+int assemble_f32(float* X2, const float* temb, const float* Xp, int B, int N, int d, int tdim, int Nt, int Np,
+                 int target_first, hipStream_t st);
+int cfg_unpatch_ddim_f32(const float* eps2, const float* z, const int64_t* t_now, const int64_t* t_prev,
+                         const float* abar, int T_train, float guidance, float eta, const float* noise, float* z_out,
+                         int B, int C, int T, int H, int W, int t, int h, int w, hipStream_t st);
+int cfg_untoken_ddim_audio_f32(const float* eps2, const float* z, const int64_t* t_now, const int64_t* t_prev,
+                               const float* abar, int T_train, float guidance, float eta, const float* noise,
+                               float* z_out, int B, int Ca, int F, int len, int stride, hipStream_t st);
+
+static inline int64_t align_up(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+struct Carver {
+    char* base;
+    int64_t used, cap;
+    float* take(int64_t floats) {
+        float* p = reinterpret_cast<float*>(base + used);
+        used += align_up(floats * (int64_t)sizeof(float));
+        return p;
+    }
+};
+
+// ---------------------------------------------------------------- MMDiT.forward
+static int64_t core_ws_bytes(const avd_core_weights* w, int64_t M) {
+    const int wide = 3 * w->d > w->mlp_hidden ? 3 * w->d : w->mlp_hidden;
+    return align_up(M * w->d * 4) + align_up(M * wide * 4);
+}
+
+static int check_core(const avd_core_weights* w) {
+    AVD_REQUIRE(w && w->blocks && w->final_norm_scale, AVD_EINVAL, "core: null weight table");
+    AVD_REQUIRE(w->d > 0 && w->n_layers > 0 && w->n_heads > 0 && w->mlp_hidden > 0, AVD_EINVAL, "core: bad dims");
+    AVD_REQUIRE(w->d % w->n_heads == 0, AVD_EINVAL, "core: d_model %d not divisible by n_heads %d", w->d, w->n_heads);
+    AVD_REQUIRE(w->d / w->n_heads == 64, AVD_EUNSUPPORTED, "core: head_dim %d unsupported (64 only)", w->d / w->n_heads);
+    AVD_REQUIRE(w->d % 4 == 0 && w->mlp_hidden % 4 == 0, AVD_EUNSUPPORTED, "core: widths must be multiples of 4");
+    return AVD_OK;
+}
+
+static int core_forward(const avd_core_weights* w, const float* x, float* y, int B, int N, int out_row0,
+                        int n_out_rows, void* ws, int64_t ws_bytes, hipStream_t st) {
+    if (int rc = check_core(w)) return rc;
+    AVD_REQUIRE(x && y && B > 0 && N > 0, AVD_EINVAL, "core: bad input");
+    AVD_REQUIRE(out_row0 >= 0 && n_out_rows > 0 && out_row0 + n_out_rows <= N, AVD_EINVAL, "core: bad output row window");
+    const int64_t M = (int64_t)B * N;
+    AVD_REQUIRE(ws && ws_bytes >= core_ws_bytes(w, M), AVD_EWORKSPACE, "core: workspace %lld < %lld bytes",
+                (long long)ws_bytes, (long long)core_ws_bytes(w, M));
+    const int d = w->d, hid = w->mlp_hidden, H = w->n_heads;
+    Carver cv{static_cast<char*>(ws), 0, ws_bytes};
+    float* hbuf = cv.take(M * d);                                   // norm output, then attention output
+    float* wide = cv.take(M * (3 * d > hid ? 3 * d : hid));         // packed qkv, then MLP hidden
+    const RowMap rd{d, 0, 0}, r3{3 * d, 0, 0}, rh{hid, 0, 0};
+    const float scale = 1.0f / sqrtf((float)(d / H));
+    const float* cur = x;                                           // residual stream lives in y after the first write
+    for (int l = 0; l < w->n_layers; ++l) {
+        const avd_block_weights& b = w->blocks[l];
+        const bool last = l == w->n_layers - 1;
+        // dead-row elimination: after the last block's K/V are formed only the rows the caller consumes matter
+        const int nq = (last && out_row0 == 0) ? n_out_rows : N;
+        if (int rc = rmsnorm_f32(cur, rd, b.norm1_scale, hbuf, rd, M, d, w->norm_eps, st)) return rc;
+        if (int rc = gemm_f32(hbuf, rd, b.in_proj_weight, b.in_proj_bias, nullptr, rd, wide, r3, M, 3 * d, d, AVD_ACT_NONE, st)) return rc;
+        if (int rc = attn_f32(wide, hbuf, B, N, H, d / H, scale, nq, st)) return rc;
+        if (int rc = gemm_f32(hbuf, rd, b.out_proj_weight, b.out_proj_bias, cur, rd, y, rd, M, d, d, AVD_ACT_NONE, st)) return rc;
+        cur = y;
+        if (int rc = rmsnorm_f32(y, rd, b.norm2_scale, hbuf, rd, M, d, w->norm_eps, st)) return rc;
+        if (int rc = gemm_f32(hbuf, rd, b.fc1_weight, b.fc1_bias, nullptr, rd, wide, rh, M, hid, d, AVD_ACT_GELU, st)) return rc;
+        if (int rc = gemm_f32(wide, rh, b.fc2_weight, b.fc2_bias, y, rd, y, rd, M, d, hid, AVD_ACT_NONE, st)) return rc;
+    }
+    return rmsnorm_f32(y, rd, w->final_norm_scale, y, rd, M, d, w->norm_eps, st);
+}
+
+// ---------------------------------------------------------------- MultiModalNoiseHead (one modality path)
+static int64_t head_ws_bytes(const avd_head_weights* w, int64_t rows) { return 2 * align_up(rows * w->hidden * 4); }
+
+static int head_forward(const avd_head_weights* w, const float* h, RowMap hm, int64_t rows, float* out, void* ws,
+                        int64_t ws_bytes, hipStream_t st) {
+    AVD_REQUIRE(w && h && out, AVD_EINVAL, "head: null pointer");
+    AVD_REQUIRE(w->d_in > 0 && w->hidden > 0 && w->d_out > 0 && w->n_shared >= 0, AVD_EINVAL, "head: bad dims");
+    AVD_REQUIRE(w->input_proj_weight && w->out_proj_weight, AVD_EINVAL, "head: null weights");
+    AVD_REQUIRE(w->n_shared == 0 || (w->shared_lin_weight && w->shared_lin_bias && w->shared_ln_weight && w->shared_ln_bias),
+                AVD_EINVAL, "head: null shared-trunk tables");
+    AVD_REQUIRE(ws && ws_bytes >= head_ws_bytes(w, rows), AVD_EWORKSPACE, "head: workspace too small");
+    Carver cv{static_cast<char*>(ws), 0, ws_bytes};
+    float* t1 = cv.take(rows * w->hidden);
+    float* t2 = cv.take(rows * w->hidden);
+    const RowMap rh{w->hidden, 0, 0}, ro{w->d_out, 0, 0};
+    if (int rc = gemm_f32(h, hm, w->input_proj_weight, w->input_proj_bias, nullptr, rh, t1, rh, rows, w->hidden, w->d_in, AVD_ACT_NONE, st)) return rc;
+    for (int j = 0; j < w->n_shared; ++j) {
+        if (int rc = gemm_f32(t1, rh, w->shared_lin_weight[j], w->shared_lin_bias[j], nullptr, rh, t2, rh, rows, w->hidden, w->hidden, AVD_ACT_NONE, st)) return rc;
+        if (int rc = layernorm_act_f32(t2, w->shared_ln_weight[j], w->shared_ln_bias[j], t1, rows, w->hidden, w->ln_eps, w->act, st)) return rc;
+    }
+    return gemm_f32(t1, rh, w->out_proj_weight, w->out_proj_bias, nullptr, ro, out, ro, rows, w->d_out, w->hidden, AVD_ACT_NONE, st);
+}
+
+// ---------------------------------------------------------------- fused front end
+static int check_embed(const avd_embed_desc* e) {
+    AVD_REQUIRE(e, AVD_EINVAL, "embed: null descriptor");
+    AVD_REQUIRE(e->B > 0 && e->d > 0 && e->tdim >= 0 && e->tdim < e->d, AVD_EINVAL, "embed: bad widths");
+    AVD_REQUIRE(e->d % 4 == 0 && e->tdim % 4 == 0, AVD_EUNSUPPORTED, "embed: d and tdim must be multiples of 4");
+    AVD_REQUIRE(e->Nt > 0 && e->Np >= 0, AVD_EINVAL, "embed: bad token counts");
+    if (e->target_kind == 0) {
+        AVD_REQUIRE(e->p0 > 0 && e->p1 > 0 && e->p2 > 0 && e->T % e->p0 == 0 && e->H % e->p1 == 0 && e->W % e->p2 == 0,
+                    AVD_EINVAL, "tube sizes must divide latent dims");
+        AVD_REQUIRE(e->Nt == (e->T / e->p0) * (e->H / e->p1) * (e->W / e->p2), AVD_EINVAL, "embed: token count mismatch");
+    } else if (e->target_kind == 1) {
+        AVD_REQUIRE(e->p0 > 0 && e->p1 > 0 && e->T >= e->p0, AVD_EINVAL, "embed: bad audio chunking");
+        AVD_REQUIRE(e->Nt == (e->T - e->p0) / e->p1 + 1, AVD_EINVAL, "embed: token count mismatch");
+    } else {
+        return set_error(AVD_EINVAL, "embed: unknown target_kind %d", e->target_kind);
+    }
+    return AVD_OK;
+}
+static int embed_tok_dim(const avd_embed_desc* e) {
+    return e->target_kind == 0 ? e->C * e->p0 * e->p1 * e->p2 : e->C * e->p0;
+}
+static int64_t embed_ws_floats(const avd_embed_desc* e) {
+    return align_up((int64_t)e->B * e->Nt * embed_tok_dim(e) * 4) / 4 + align_up((int64_t)e->B * (e->tdim > 0 ? e->tdim : 1) * 4) / 4;
+}
+
+static int embed_cfg_pair(const avd_embed_desc* e, const float* z, const float* Wt, const float* bt,
+                          const int64_t* t_now, const float* Xp, float* tok_ws, float* X2, hipStream_t st) {
+    if (int rc = check_embed(e)) return rc;
+    AVD_REQUIRE(z && Wt && t_now && tok_ws && X2 && (e->Np == 0 || Xp), AVD_EINVAL, "embed: null pointer");
+    const int B = e->B, d = e->d, N = e->Nt + e->Np, D = embed_tok_dim(e);
+    float* tok = tok_ws;
+    float* temb = tok_ws + align_up((int64_t)B * e->Nt * D * 4) / 4;
+    if (e->target_kind == 0) {
+        if (int rc = tube_patch_f32(z, tok, B, e->C, e->T, e->H, e->W, e->p0, e->p1, e->p2, st)) return rc;
+    } else {
+        if (int rc = audio_tokens_f32(z, tok, B, e->C, e->T, e->p0, e->p1, st)) return rc;
+    }
+    // adapter GEMM straight into the cond half's target rows (segmented C: one segment per sample)
+    float* c0 = X2 + (e->target_first ? 0 : (int64_t)e->Np * d);
+    const RowMap cm{d, e->Nt, (int64_t)N * d};
+    if (int rc = gemm_f32(tok, RowMap{D, 0, 0}, Wt, bt, nullptr, cm, c0, cm, (int64_t)B * e->Nt, d - e->tdim, D, AVD_ACT_NONE, st)) return rc;
+    if (e->tdim > 0)
+        if (int rc = temb_f32(t_now, e->temb_freqs, temb, B, e->tdim, 10000.f, st)) return rc;
+    return assemble_f32(X2, temb, Xp, B, N, d, e->tdim, e->Nt, e->Np, e->target_first, st);
+}
+
+// ---------------------------------------------------------------- one CFG denoising step
+struct StepPlan {
+    int64_t x2, tok, core, head, eps, total;
+    int N, D;
+    int64_t rows;     // 2B*Nt
+};
+static int plan_step(const avd_step_desc* s, StepPlan& p) {
+    AVD_REQUIRE(s && s->core && s->head, AVD_EINVAL, "step: null descriptor");
+    if (int rc = check_embed(&s->embed)) return rc;
+    if (int rc = check_core(s->core)) return rc;
+    const avd_embed_desc& e = s->embed;
+    AVD_REQUIRE(e.d == s->core->d && s->head->d_in == e.d, AVD_EINVAL, "step: width mismatch between embed/core/head");
+    p.N = e.Nt + e.Np;
+    p.D = embed_tok_dim(&e);
+    AVD_REQUIRE(s->head->d_out == p.D, AVD_EINVAL, "step: head d_out %d != token dim %d", s->head->d_out, p.D);
+    p.rows = (int64_t)2 * e.B * e.Nt;
+    p.x2 = align_up((int64_t)2 * e.B * p.N * e.d * 4);
+    p.tok = align_up(embed_ws_floats(&e) * 4);
+    p.core = core_ws_bytes(s->core, (int64_t)2 * e.B * p.N);
+    p.head = head_ws_bytes(s->head, p.rows);
+    p.eps = align_up(p.rows * p.D * 4);
+    p.total = p.x2 + p.tok + p.core + p.head + p.eps;
+    return AVD_OK;
+}
+
+}  // namespace avd
+
+using namespace avd;
+
+extern "C" int avd_abi_version(void) { return AVD_ABI_VERSION; }
+extern "C" const char* avd_last_error(void) { return g_err; }
+
+extern "C" int avd_device_arch(char* buf, int buflen) {
+    AVD_REQUIRE(buf && buflen > 0, AVD_EINVAL, "device_arch: bad buffer");
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, 0);
+    if (e != hipSuccess) return set_error(AVD_ELAUNCH, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    strncpy(buf, prop.gcnArchName, buflen - 1);
+    buf[buflen - 1] = 0;
+    return AVD_OK;
+}
+
+extern "C" int64_t avd_core_workspace_bytes(const avd_core_weights* w, int B, int N) {
+    if (!w || B <= 0 || N <= 0) return -1;
+    return core_ws_bytes(w, (int64_t)B * N);
+}
+extern "C" int avd_core_forward_f32(const avd_core_weights* w, const float* x, float* y, int B, int N, int out_row0,
+                                    int n_out_rows, void* workspace, int64_t workspace_bytes, avd_stream_t stream) {
+    return core_forward(w, x, y, B, N, out_row0, n_out_rows, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t avd_head_workspace_bytes(const avd_head_weights* w, int64_t rows) {
+    if (!w || rows < 0) return -1;
+    return head_ws_bytes(w, rows);
+}
+extern "C" int avd_head_forward_f32(const avd_head_weights* w, const float* h, int64_t ldh, int64_t seg_rows,
+                                    int64_t seg_stride, int64_t rows, float* out, void* workspace,
+                                    int64_t workspace_bytes, avd_stream_t stream) {
+    return head_forward(w, h, RowMap{ldh, seg_rows, seg_stride}, rows, out, workspace, workspace_bytes,
+                        static_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t avd_embed_workspace_floats(const avd_embed_desc* e) {
+    if (check_embed(e)) return -1;
+    return embed_ws_floats(e);
+}
+extern "C" int avd_embed_cfg_pair_f32(const avd_embed_desc* desc, const float* z_target, const float* Wt,
+                                      const float* bt, const int64_t* t_now, const float* Xp, float* tok_ws, float* X2,
+                                      avd_stream_t stream) {
+    return embed_cfg_pair(desc, z_target, Wt, bt, t_now, Xp, tok_ws, X2, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t avd_step_workspace_bytes(const avd_step_desc* s) {
+    StepPlan p;
+    if (plan_step(s, p)) return -1;
+    return p.total;
+}
+
+extern "C" int avd_denoise_step_f32(const avd_step_desc* s, const float* z, const float* Xp, const int64_t* t_now,
+                                    const int64_t* t_prev, const float* noise, float* z_out, void* workspace,
+                                    int64_t workspace_bytes, avd_stream_t stream) {
+    StepPlan p;
+    if (int rc = plan_step(s, p)) return rc;
+    AVD_REQUIRE(z && z_out && t_now && t_prev && s->alpha_bar && s->adapt_w, AVD_EINVAL, "step: null pointer");
+    AVD_REQUIRE(z != z_out, AVD_EINVAL, "step: z_out must not alias z");
+    AVD_REQUIRE(workspace && workspace_bytes >= p.total, AVD_EWORKSPACE, "step: workspace %lld < %lld bytes",
+                (long long)workspace_bytes, (long long)p.total);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const avd_embed_desc& e = s->embed;
+    char* w = static_cast<char*>(workspace);
+    float* X2 = reinterpret_cast<float*>(w);
+    float* tok = reinterpret_cast<float*>(w + p.x2);
+    void* core_ws = w + p.x2 + p.tok;
+    void* head_ws = w + p.x2 + p.tok + p.core;
+    float* eps2 = reinterpret_cast<float*>(w + p.x2 + p.tok + p.core + p.head);
+
+    if (int rc = embed_cfg_pair(&e, z, s->adapt_w, s->adapt_b, t_now, Xp, tok, X2, st)) return rc;
+    const int row0 = e.target_first ? 0 : e.Np;
+    if (int rc = core_forward(s->core, X2, X2, 2 * e.B, p.N, row0, e.Nt, core_ws, p.core, st)) return rc;
+    // head over the target rows only (per-token independent, so skipping prompt rows is exact)
+    const RowMap hm{e.d, e.Nt, (int64_t)p.N * e.d};
+    if (int rc = head_forward(s->head, X2 + (int64_t)row0 * e.d, hm, p.rows, eps2, head_ws, p.head, st)) return rc;
+    if (e.target_kind == 0)
+        return cfg_unpatch_ddim_f32(eps2, z, t_now, t_prev, s->alpha_bar, s->T_train, s->guidance, s->eta, noise, z_out,
+                                    e.B, e.C, e.T, e.H, e.W, e.p0, e.p1, e.p2, st);
+    return cfg_untoken_ddim_audio_f32(eps2, z, t_now, t_prev, s->alpha_bar, s->T_train, s->guidance, s->eta, noise, z_out,
+                                      e.B, e.C, e.T, e.p0, e.p1, st);
+}
+
+extern "C" int avd_prof_enable(int on) {
+    if (on) {   // recycle the previous run's events; records survive a disable so they can be reported
+        for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+        g_recs.clear();
+    }
+    g_prof_on = on != 0;
+    return AVD_OK;
+}
+
+extern "C" int avd_prof_report(int64_t* launches, double* total_ms, double* work, int ntags) {
+    AVD_REQUIRE(launches && total_ms && work && ntags >= AVD_PROF_NTAGS, AVD_EINVAL, "prof_report: need %d tags", AVD_PROF_NTAGS);
+    for (int i = 0; i < ntags; ++i) { launches[i] = 0; total_ms[i] = 0.0; work[i] = 0.0; }
+    for (auto& r : g_recs) {
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e != hipSuccess) return set_error(AVD_ELAUNCH, "prof_report: %s", hipGetErrorString(e));
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, r.a, r.b);
+        if (e != hipSuccess) return set_error(AVD_ELAUNCH, "prof_report: %s", hipGetErrorString(e));
+        launches[r.tag] += 1; total_ms[r.tag] += ms; work[r.tag] += r.work;
+    }
+    return AVD_OK;
+}

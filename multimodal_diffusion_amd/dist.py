@@ -1,0 +1,74 @@
+"""Multi-GPU layout for the sampler: independent samples shard over ranks, one broadcast of the conditioning.
+
+Samples never interact inside the loop (attention is within-sample, norms per token, DDIM elementwise), so the
+only collective is a root→all broadcast of the conditioning latents before the loop (RCCL over xGMI when the
+backend is "nccl"; gloo on CPU for tests).  No per-step communication.  One process per GPU.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    """(rank, world, local_rank) from torchrun's env; initialises the default group when world > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [lo, hi) slice of the global batch owned by ``rank`` (sizes differ by at most one)."""
+    if global_batch < 0 or world <= 0 or not 0 <= rank < world:
+        raise ValueError("bad shard request")
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def broadcast_conditioning(cond: Optional[torch.Tensor], shape: Tuple[int, ...], device: torch.device,
+                           src: int = 0) -> torch.Tensor:
+    """Root holds ``cond`` [B_global, ...]; every rank returns the full tensor after ONE broadcast."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world == 1:
+        if cond is None:
+            raise ValueError("single-process run needs the conditioning tensor")
+        return cond.to(device)
+    rank = dist.get_rank()
+    buf = cond.to(device=device, dtype=torch.float32).contiguous() if rank == src else \
+        torch.empty(shape, dtype=torch.float32, device=device)
+    if tuple(buf.shape) != tuple(shape):
+        raise ValueError("conditioning shape mismatch on the source rank")
+    dist.broadcast(buf, src=src)
+    return buf
+
+
+def local_conditioning(cond_global: torch.Tensor, rank: int, world: int) -> torch.Tensor:
+    lo, hi = shard_range(cond_global.shape[0], rank, world)
+    return cond_global[lo:hi].contiguous()
+
+
+def max_over_ranks(value: float, device: torch.device) -> float:
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()

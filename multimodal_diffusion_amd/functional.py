@@ -1,0 +1,163 @@
+"""Tensor-level wrappers over the C ABI (one function per ``avd_*`` kernel entry point).
+
+Each wrapper validates shapes the way the reference op it stands under does (AssertionError / ValueError),
+allocates the output with torch (plumbing) and enqueues the HIP kernel on torch's current stream.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib as L
+
+Tensor = torch.Tensor
+
+
+def _st(t: Tensor) -> int:
+    return L.stream_ptr(t.device)
+
+
+def rmsnorm(x: Tensor, scale: Tensor, eps: float = 1e-6) -> Tensor:
+    """RMSNorm with eps outside the sqrt — avdiff/models/mmdt.py:39-42."""
+    x = L.dev_f32(x, "x")
+    scale = L.dev_f32(scale, "scale")
+    d = x.shape[-1]
+    y = torch.empty_like(x)
+    L.check(L.lib().avd_rmsnorm_f32(x.data_ptr(), scale.data_ptr(), y.data_ptr(), x.numel() // d, d, eps, _st(x)))
+    return y
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: int = L.ACT_NONE,
+           residual: Optional[Tensor] = None) -> Tensor:
+    """act(x @ weight.T + bias) + residual on the fp32 matrix cores (torch.nn.Linear semantics)."""
+    x = L.dev_f32(x, "x")
+    weight = L.dev_f32(weight, "weight")
+    n, k = weight.shape
+    if x.shape[-1] != k:
+        raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied ({tuple(x.shape)} x {k}->{n})")
+    m = x.numel() // k
+    out = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float32)
+    b = None if bias is None else L.dev_f32(bias, "bias")
+    r = None
+    if residual is not None:
+        r = L.dev_f32(residual, "residual")
+        if r.shape != out.shape:
+            raise RuntimeError("residual shape mismatch")
+    L.check(L.lib().avd_gemm_bias_act_f32(x.data_ptr(), k, weight.data_ptr(), L.ptr(b), L.ptr(r), n, out.data_ptr(), n,
+                                          m, n, k, act, _st(x)))
+    return out
+
+
+def attention(qkv: Tensor, n_heads: int, n_query: Optional[int] = None) -> Tensor:
+    """softmax(q k^T / sqrt(Dh)) v over packed qkv [B,N,3d] -> [B,N,d] (head_dim must be 64)."""
+    qkv = L.dev_f32(qkv, "qkv")
+    B, N, d3 = qkv.shape
+    d = d3 // 3
+    dh = d // n_heads
+    out = torch.empty(B, N, d, device=qkv.device, dtype=torch.float32) if n_query in (None, N) else \
+        torch.zeros(B, N, d, device=qkv.device, dtype=torch.float32)
+    L.check(L.lib().avd_attn_fwd_f32(qkv.data_ptr(), out.data_ptr(), B, N, n_heads, dh, 1.0 / math.sqrt(dh),
+                                     N if n_query is None else n_query, _st(qkv)))
+    return out
+
+
+def layernorm_act(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5, act: int = L.ACT_NONE) -> Tensor:
+    x = L.dev_f32(x, "x")
+    d = x.shape[-1]
+    y = torch.empty_like(x)
+    L.check(L.lib().avd_layernorm_act_f32(x.data_ptr(), L.dev_f32(weight).data_ptr(), L.dev_f32(bias).data_ptr(),
+                                          y.data_ptr(), x.numel() // d, d, eps, act, _st(x)))
+    return y
+
+
+_FREQS = {}
+
+
+def temb_freqs(dim: int, max_period: int, device: torch.device) -> Tensor:
+    """f_i = exp(-ln(max_period) * i / half), built on the host with the reference's fp32 op sequence
+    (schedule_utils.py:80) and uploaded once per (dim, max_period, device)."""
+    key = (dim, max_period, str(device))
+    if key not in _FREQS:
+        half = dim // 2
+        f = torch.exp(-math.log(max_period) * torch.arange(0, half, dtype=torch.float32) / half)
+        _FREQS[key] = f.to(device)
+    return _FREQS[key]
+
+
+def timestep_embedding(t: Tensor, dim: int, max_period: int = 10000) -> Tensor:
+    if not t.is_cuda:
+        raise L.AvdError("timesteps must be on the ROCm device (no CPU fallback)")
+    if t.is_floating_point():
+        # the reference accepts float timesteps; the kernel takes int64 like every caller on the hot path
+        if not torch.equal(t, t.round()):
+            raise L.AvdError("fractional timesteps are not supported by the HIP path")
+    t = L.dev_i64(t, t.device)
+    out = torch.empty(t.shape[0], dim, device=t.device, dtype=torch.float32)
+    fr = temb_freqs(dim, max_period, t.device) if dim >= 2 else None
+    L.check(L.lib().avd_timestep_embedding_f32(t.data_ptr(), L.ptr(fr), out.data_ptr(), t.shape[0], dim,
+                                               float(max_period), _st(out)))
+    return out
+
+
+def tube_patch(z: Tensor, t: int, h: int, w: int) -> Tensor:
+    z = L.dev_f32(z, "z")
+    B, C_, T, H, W = z.shape
+    assert T % t == 0 and H % h == 0 and W % w == 0, "tube sizes must divide latent dims"
+    n = (T // t) * (H // h) * (W // w)
+    tok = torch.empty(B, n, C_ * t * h * w, device=z.device, dtype=torch.float32)
+    L.check(L.lib().avd_tube_patch_f32(z.data_ptr(), tok.data_ptr(), B, C_, T, H, W, t, h, w, _st(z)))
+    return tok
+
+
+def tube_unpatch(tokens: Tensor, C_: int, T: int, H: int, W: int, t: int, h: int, w: int) -> Tensor:
+    tokens = L.dev_f32(tokens, "tokens")
+    B, N, D = tokens.shape
+    assert D == C_ * t * h * w, "token width mismatch"
+    assert N == (T // t) * (H // h) * (W // w), "token count mismatch"
+    z = torch.empty(B, C_, T, H, W, device=tokens.device, dtype=torch.float32)
+    L.check(L.lib().avd_tube_unpatch_f32(tokens.data_ptr(), z.data_ptr(), B, C_, T, H, W, t, h, w, _st(z)))
+    return z
+
+
+def audio_tokens(z_a: Tensor, length: int, stride: int) -> Tensor:
+    z_a = L.dev_f32(z_a, "z_a")
+    B, Ca, F = z_a.shape
+    na = (F - length) // stride + 1
+    tok = torch.empty(B, na, Ca * length, device=z_a.device, dtype=torch.float32)
+    L.check(L.lib().avd_audio_tokens_f32(z_a.data_ptr(), tok.data_ptr(), B, Ca, F, length, stride, _st(z_a)))
+    return tok
+
+
+def audio_untokens(tokens: Tensor, Ca: int, length: int, frames: int, stride: int) -> Tensor:
+    tokens = L.dev_f32(tokens, "tokens")
+    B, na, D = tokens.shape
+    assert D == Ca * length
+    if na != (frames - length) // stride + 1:
+        raise L.AvdError("audio_untokens: token count does not match (frames, length, stride)")
+    z = torch.empty(B, Ca, frames, device=tokens.device, dtype=torch.float32)
+    L.check(L.lib().avd_audio_untokens_f32(tokens.data_ptr(), z.data_ptr(), B, Ca, frames, length, stride, _st(z)))
+    return z
+
+
+def ddim_step(x_t: Tensor, t_now: Tensor, t_prev: Tensor, eps_hat: Tensor, alpha_bar: Tensor, eta: float = 0.0,
+              noise: Optional[Tensor] = None) -> Tensor:
+    x_t = L.dev_f32(x_t, "x_t")
+    eps_hat = L.dev_f32(eps_hat, "eps_hat")
+    if eps_hat.shape != x_t.shape:
+        raise RuntimeError("eps_hat must have the shape of x_t")
+    dev = x_t.device
+    ab = alpha_bar if (alpha_bar.is_cuda and alpha_bar.dtype == torch.float32) else alpha_bar.to(dev, torch.float32)
+    ab = ab.contiguous()
+    tn, tp = L.dev_i64(t_now, dev), L.dev_i64(t_prev, dev)
+    B = x_t.shape[0]
+    if tn.numel() != B or tp.numel() != B:
+        raise RuntimeError("t_now / t_prev must have one entry per sample")
+    if eta > 0.0 and noise is None:
+        noise = torch.randn_like(x_t)          # the reference draws randn_like here (schedule_utils.py:197)
+    nz = None if noise is None else L.dev_f32(noise, "noise")
+    out = torch.empty_like(x_t)
+    L.check(L.lib().avd_ddim_step_f32(x_t.data_ptr(), eps_hat.data_ptr(), tn.data_ptr(), tp.data_ptr(), ab.data_ptr(),
+                                      ab.numel(), float(eta), L.ptr(nz), out.data_ptr(), B, x_t.numel() // B, _st(x_t)))
+    return out

@@ -1,0 +1,192 @@
+"""MMDiT denoiser core — host-side mirror of ``avdiff/models/mmdt.py`` over the HIP C ABI.
+
+Same class names, constructor kwargs, ``forward`` signatures and ``state_dict`` keys as the reference
+(``blocks.{i}.norm1.scale``, ``blocks.{i}.attn.mha.in_proj_weight`` … ``final_norm.scale``), so a reference
+``core`` state dict loads with ``strict=True``.  The modules own parameters only; every FLOP runs in
+``libavdiff_hip.so``.  Inference only (the benchmarked path is ``@torch.no_grad`` + ``.eval()``,
+sample_clip.py:84-107,220): dropout / token-dropout in training mode, masks and RoPE raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import functional as Fn
+
+
+class RMSNorm(nn.Module):
+    """mmdt.py:33-42 — y = scale * x / (||x||/sqrt(d) + eps)."""
+
+    def __init__(self, d: int, eps: float = 1e-6):
+        super().__init__()
+        self.scale = nn.Parameter(torch.ones(d))
+        self.eps = eps
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return Fn.rmsnorm(x, self.scale, self.eps)
+
+
+def build_norm(kind: str, d: int) -> nn.Module:
+    if kind.lower() != "rmsnorm":
+        raise NotImplementedError("the HIP path implements norm='rmsnorm' (every shipped reference config uses it)")
+    return RMSNorm(d)
+
+
+class _OutProj(nn.Module):
+    """Parameter holder matching nn.MultiheadAttention.out_proj (NonDynamicallyQuantizableLinear)."""
+
+    def __init__(self, d: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(d, d))
+        self.bias = nn.Parameter(torch.zeros(d))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+
+
+class _PackedMHA(nn.Module):
+    """Parameter holder with nn.MultiheadAttention's key names and default init (packed q|k|v projection)."""
+
+    def __init__(self, d: int, n_heads: int):
+        super().__init__()
+        if d % n_heads:
+            raise AssertionError("embed_dim must be divisible by num_heads")
+        self.embed_dim, self.num_heads = d, n_heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = _OutProj(d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+
+
+class MHA(nn.Module):
+    """mmdt.py:51-61 — joint self-attention over [target ; prompt] tokens."""
+
+    def __init__(self, d_model: int, n_heads: int, attn_dropout: float = 0.0, resid_dropout: float = 0.0):
+        super().__init__()
+        self.mha = _PackedMHA(d_model, n_heads)
+        self.attn_dropout, self.resid_dropout = attn_dropout, resid_dropout
+
+    def forward(self, x, attn_mask=None, key_padding_mask=None, residual=None):
+        if attn_mask is not None or key_padding_mask is not None:
+            raise NotImplementedError("masks are never passed on the sampler path (sample_clip.py:374,378)")
+        if self.training and (self.attn_dropout > 0 or self.resid_dropout > 0):
+            raise NotImplementedError("HIP path is inference-only; call .eval()")
+        m = self.mha
+        qkv = Fn.linear(x, m.in_proj_weight, m.in_proj_bias)
+        o = Fn.attention(qkv, m.num_heads)
+        return Fn.linear(o, m.out_proj.weight, m.out_proj.bias, residual=residual)
+
+
+class _Lin(nn.Module):
+    def __init__(self, d_in: int, d_out: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty(d_out, d_in))
+        self.bias = nn.Parameter(torch.zeros(d_out))
+        nn.init.xavier_uniform_(self.weight)
+
+
+class MLP(nn.Module):
+    """mmdt.py:66-83 — fc1 -> GELU(erf) -> fc2, xavier weights / zero biases."""
+
+    def __init__(self, d_model: int, mlp_ratio: float = 4.0, dropout: float = 0.0):
+        super().__init__()
+        hidden = int(d_model * mlp_ratio)
+        self.fc1 = _Lin(d_model, hidden)
+        self.fc2 = _Lin(hidden, d_model)
+        self.dropout = dropout
+
+    def forward(self, x, residual=None):
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("HIP path is inference-only; call .eval()")
+        h = Fn.linear(x, self.fc1.weight, self.fc1.bias, act=L.ACT_GELU)
+        return Fn.linear(h, self.fc2.weight, self.fc2.bias, residual=residual)
+
+
+class Block(nn.Module):
+    """mmdt.py:88-99 — pre-norm attention + MLP with residuals (residual adds fused into the GEMM epilogues)."""
+
+    def __init__(self, d_model, n_heads, mlp_ratio, dropout, attn_dropout, norm):
+        super().__init__()
+        self.norm1 = build_norm(norm, d_model)
+        self.attn = MHA(d_model, n_heads, attn_dropout=attn_dropout, resid_dropout=dropout)
+        self.norm2 = build_norm(norm, d_model)
+        self.mlp = MLP(d_model, mlp_ratio=mlp_ratio, dropout=dropout)
+
+    def forward(self, x, attn_mask=None, key_padding_mask=None):
+        x = self.attn(self.norm1(x), attn_mask=attn_mask, key_padding_mask=key_padding_mask, residual=x)
+        return self.mlp(self.norm2(x), residual=x)
+
+
+@dataclass
+class MMDiTCfg:
+    d_model: int = 1024
+    n_layers: int = 16
+    n_heads: int = 16
+    mlp_ratio: float = 4.0
+    dropout: float = 0.1
+    attn_dropout: float = 0.0
+    norm: str = "rmsnorm"
+    rope: bool = False
+    token_dropout: float = 0.0
+
+
+class MMDiT(nn.Module):
+    """mmdt.py:116-149.  ``forward`` is ONE C-ABI call (``avd_core_forward_f32``) enqueuing all layer kernels."""
+
+    def __init__(self, d_model=1024, n_layers=16, n_heads=16, mlp_ratio=4.0,
+                 dropout=0.1, attn_dropout=0.0, norm="rmsnorm", rope=False, token_dropout=0.0):
+        super().__init__()
+        if rope:
+            raise NotImplementedError("rope=True is a no-op flag in the reference (never read); refusing silently-ignored options")
+        self.cfg = MMDiTCfg(d_model, n_layers, n_heads, mlp_ratio, dropout, attn_dropout, norm, rope, token_dropout)
+        self.blocks = nn.ModuleList([Block(d_model, n_heads, mlp_ratio, dropout, attn_dropout, norm)
+                                     for _ in range(n_layers)])
+        self.final_norm = build_norm(norm, d_model)
+        self._ws: Optional[torch.Tensor] = None
+
+    # ---- pointer table for the composite (rebuilt per call: parameters may have moved) ----
+    def weight_table(self):
+        dev = self.final_norm.scale.device
+        arr = (L.BlockWeights * len(self.blocks))()
+        keep = []
+        for i, b in enumerate(self.blocks):
+            ps = dict(norm1_scale=b.norm1.scale, in_proj_weight=b.attn.mha.in_proj_weight,
+                      in_proj_bias=b.attn.mha.in_proj_bias, out_proj_weight=b.attn.mha.out_proj.weight,
+                      out_proj_bias=b.attn.mha.out_proj.bias, norm2_scale=b.norm2.scale,
+                      fc1_weight=b.mlp.fc1.weight, fc1_bias=b.mlp.fc1.bias,
+                      fc2_weight=b.mlp.fc2.weight, fc2_bias=b.mlp.fc2.bias)
+            for k, p in ps.items():
+                t = L.dev_f32(p.detach(), k)
+                if t.device != dev:
+                    raise L.AvdError("all MMDiT parameters must live on one device")
+                keep.append(t)
+                setattr(arr[i], k, t.data_ptr())
+        fin = L.dev_f32(self.final_norm.scale.detach(), "final_norm.scale")
+        keep.append(fin)
+        hidden = self.blocks[0].mlp.fc1.weight.shape[0]
+        cw = L.CoreWeights(self.cfg.d_model, len(self.blocks), self.cfg.n_heads, hidden, self.final_norm.eps,
+                           C.cast(arr, C.POINTER(L.BlockWeights)), fin.data_ptr())
+        return cw, (arr, keep)
+
+    def forward(self, x: torch.Tensor, key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if key_padding_mask is not None:
+            raise NotImplementedError("key_padding_mask is never passed on the sampler path (sample_clip.py:374,378)")
+        if self.training and (self.cfg.token_dropout > 0 or self.cfg.dropout > 0 or self.cfg.attn_dropout > 0):
+            raise NotImplementedError("HIP path is inference-only; call .eval()")
+        x = L.dev_f32(x, "x")
+        B, N, d = x.shape
+        if d != self.cfg.d_model:
+            raise RuntimeError(f"expected last dim {self.cfg.d_model}, got {d}")
+        cw, keep = self.weight_table()
+        need = L.lib().avd_core_workspace_bytes(C.byref(cw), B, N)
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        y = torch.empty_like(x)
+        L.check(L.lib().avd_core_forward_f32(C.byref(cw), x.data_ptr(), y.data_ptr(), B, N, 0, N,
+                                             self._ws.data_ptr(), self._ws.numel(), L.stream_ptr(x.device)))
+        del keep
+        return y

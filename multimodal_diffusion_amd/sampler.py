@@ -1,0 +1,311 @@
+"""DDIM + CFG sampler — host-side mirror of ``avdiff/models/infer/sample_clip.py`` over the HIP C ABI.
+
+Keeps the reference names (``LinearAdapter``, ``add_sinusoidal_timestep``, ``build_components``,
+``latents_to_tokens_*``, ``tokens_to_latents_audio``, ``sample_one_direction``) and adds what the reference
+lacks: ``DenoiseEngine`` — a *batched* (B >= 1) on-device loop where one denoising step (sample_clip.py:359-389
+or :318-348) is a single ``avd_denoise_step_f32`` call with the cond/null branches stacked to 2B, the constant
+prompt rows embedded once, the timestep schedule resident on the device and the step optionally replayed
+from a captured HIP graph.
+
+File I/O and the CLI (sample_clip.py:112-174, 399-461) are out of scope; ``VideoVAE`` / ``AudioCodec`` are the
+loop *boundary*  and are taken as caller-supplied modules.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import functional as Fn
+from . import ops
+from . import schedule_utils as su
+from .mmdt import MMDiT
+from .noise_heads import MultiModalNoiseHead
+
+
+class LinearAdapter(nn.Module):
+    """Per-modality linear projection to token width (sample_clip.py:48-56); PyTorch-default Linear init."""
+
+    def __init__(self, d_in: int, d_out: int):
+        super().__init__()
+        self.proj = nn.Linear(d_in, d_out)     # parameter container only
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return Fn.linear(x, self.proj.weight, self.proj.bias)
+
+
+def add_sinusoidal_timestep(tokens: torch.Tensor, t_scalar: torch.Tensor, dim: int) -> torch.Tensor:
+    """[B,N,d] + t[B] -> [B,N,d+dim] by concatenation (sample_clip.py:59-70).  Stand-alone helper; the engine fuses
+    this into the sequence-assembly kernel instead."""
+    emb = su.timestep_embedding(L.dev_i64(t_scalar, tokens.device), dim)
+    out = torch.empty(tokens.shape[0], tokens.shape[1], tokens.shape[2] + dim, device=tokens.device, dtype=tokens.dtype)
+    out[..., :tokens.shape[2]] = tokens
+    out[..., tokens.shape[2]:] = emb[:, None, :]
+    return out
+
+
+def build_components(cfg: Dict, device: torch.device, vid_vae: Optional[nn.Module] = None,
+                     aud_codec: Optional[nn.Module] = None):
+    """(vid_vae, aud_codec, adapt_v, adapt_a, core, head, tstep_dim) as sample_clip.py:75-109.
+
+    The codec/VAE slots carry whatever the caller passes (``None`` by default): they sit outside the per-step path.
+    """
+    d = int(cfg["tokenizer"]["width"])
+    out_v = int(cfg["model"]["heads"]["video"]["out_dim"])
+    out_a = int(cfg["model"]["heads"]["audio"]["out_dim"])
+    tstep_dim = int(cfg["embeddings"].get("timestep_dim", 256))
+    adapt_v = LinearAdapter(out_v, d - tstep_dim).to(device)
+    adapt_a = LinearAdapter(out_a, d - tstep_dim).to(device)
+    core = MMDiT(**cfg["model"]["core"]).to(device).eval()
+    head = MultiModalNoiseHead(
+        input_dims={"video": d, "audio": d}, output_dims={"video": out_v, "audio": out_a},
+        hidden_dim=int(cfg["model"]["heads"]["video"]["hidden_dim"]), num_shared_layers=2,
+        num_modality_specific_layers=1, dropout=float(cfg["model"]["core"].get("dropout", 0.1)),
+        activation=cfg["model"]["heads"]["video"].get("activation", "gelu")).to(device).eval()
+    return vid_vae, aud_codec, adapt_v, adapt_a, core, head, tstep_dim
+
+
+def latents_to_tokens_video(z_v: torch.Tensor, t_p: int, p: int) -> torch.Tensor:
+    return ops.tube_patch_video(z_v, t=t_p, h=p, w=p)
+
+
+def latents_to_tokens_audio(z_a: torch.Tensor, l_chunk: int, s_chunk: int) -> torch.Tensor:
+    return Fn.audio_tokens(z_a, l_chunk, s_chunk)
+
+
+def tokens_to_latents_audio(tokens: torch.Tensor, Ca: int, l_chunk: int, Fa: int, stride: int) -> torch.Tensor:
+    """Overlap-add back to [B,Ca,Fa] (crop / zero-pad), sample_clip.py:191-215 — one kernel, no Python loops."""
+    return Fn.audio_untokens(tokens, Ca, l_chunk, Fa, stride)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# batched on-device loop
+# ----------------------------------------------------------------------------------------------------------
+
+class DenoiseEngine:
+    """One direction (``target`` in {"video","audio"}) of the CFG + DDIM loop for a batch of independent samples.
+
+    step(z, t_now, t_prev)   one step, explicit timesteps (int64 [B] on the device) — parity entry point
+    run(z, sched)            whole trajectory with the schedule cursor on the device; ``graph=True`` replays a
+                             captured HIP graph per step (no per-step host work beyond one graph launch)
+    """
+
+    def __init__(self, *, adapt_v: LinearAdapter, adapt_a: LinearAdapter, core: MMDiT, head: MultiModalNoiseHead,
+                 tstep_dim: int, target: str, latent_shape: Tuple[int, ...], prompt_tokens: int, alpha_bar: torch.Tensor,
+                 guidance: float, eta: float = 0.0, tube=(2, 4, 4), chunk=(4, 4)):
+        if target not in ("video", "audio"):
+            raise ValueError("target must be 'video' or 'audio'")
+        if eta < 0:
+            raise ValueError("eta must be >= 0")
+        self.target = target
+        self.core, self.head = core, head
+        self.adapt_t = adapt_v if target == "video" else adapt_a
+        self.adapt_p = adapt_a if target == "video" else adapt_v
+        self.tdim = int(tstep_dim)
+        self.d = core.cfg.d_model
+        self.tube, self.chunk = tuple(tube), tuple(chunk)
+        self.guidance, self.eta = float(guidance), float(eta)
+        self.device = core.final_norm.scale.device
+        if not self.device.type == "cuda":
+            raise L.AvdError("DenoiseEngine needs its modules on a ROCm device (no CPU fallback)")
+        self.latent_shape = tuple(int(s) for s in latent_shape)      # with batch dim
+        B = self.latent_shape[0]
+        e = L.EmbedDesc()
+        e.B, e.d, e.tdim = B, self.d, self.tdim
+        if target == "video":
+            _, Cc, T, H, W = self.latent_shape
+            t, h, w = self.tube
+            assert T % t == 0 and H % h == 0 and W % w == 0, "tube sizes must divide latent dims"
+            e.target_kind, e.target_first = 0, 1                     # sequence order is always [video ; audio]
+            e.C, e.T, e.H, e.W = Cc, T, H, W
+            e.p0, e.p1, e.p2 = t, h, w
+            e.Nt = (T // t) * (H // h) * (W // w)
+        else:
+            _, Ca, Fa = self.latent_shape
+            ln, st = self.chunk
+            e.target_kind, e.target_first = 1, 0
+            e.C, e.T, e.H, e.W = Ca, Fa, 1, 1
+            e.p0, e.p1, e.p2 = ln, st, 1
+            e.Nt = (Fa - ln) // st + 1
+        e.Np = int(prompt_tokens)
+        self._freqs = Fn.temb_freqs(self.tdim, 10000, self.device) if self.tdim >= 2 else None
+        e.temb_freqs = L.ptr(self._freqs)
+        self.embed = e
+        self.N = e.Nt + e.Np
+        self.alpha_bar = alpha_bar.to(self.device, torch.float32).contiguous()
+
+        self._core_tab, self._keep_core = core.weight_table()
+        self._head_tab, self._keep_head = head.weight_table(target)
+        self._aw = L.dev_f32(self.adapt_t.proj.weight.detach(), "adapter weight")
+        self._ab = L.dev_f32(self.adapt_t.proj.bias.detach(), "adapter bias")
+        s = L.StepDesc()
+        s.embed = e
+        s.core = C.pointer(self._core_tab)
+        s.head = C.pointer(self._head_tab)
+        s.adapt_w, s.adapt_b = self._aw.data_ptr(), self._ab.data_ptr()
+        s.alpha_bar, s.T_train = self.alpha_bar.data_ptr(), self.alpha_bar.numel()
+        s.guidance, s.eta = self.guidance, self.eta
+        self.desc = s
+        need = L.lib().avd_step_workspace_bytes(C.byref(s))
+        if need < 0:
+            raise ValueError(L.lib().avd_last_error().decode())
+        self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.Xp: Optional[torch.Tensor] = None
+
+    # ---- prompt rows: adapter(tokens(prompt latent)) | temb(0); constant over the trajectory ----
+    def set_prompt(self, prompt_latent: torch.Tensor) -> torch.Tensor:
+        z = L.dev_f32(prompt_latent, "prompt latent")
+        B = self.embed.B
+        if z.shape[0] != B:
+            raise ValueError("prompt batch size must match the engine's")
+        tok = latents_to_tokens_audio(z, *self.chunk) if self.target == "video" else \
+            latents_to_tokens_video(z, self.tube[0], self.tube[1])
+        if tok.shape[1] != self.embed.Np:
+            raise ValueError(f"prompt yields {tok.shape[1]} tokens, engine was built for {self.embed.Np}")
+        d, td = self.d, self.tdim
+        Xp = torch.empty(B, tok.shape[1], d, device=self.device, dtype=torch.float32)
+        w, b = self.adapt_p.proj.weight.detach(), self.adapt_p.proj.bias.detach()
+        # GEMM writes straight into the first d-tdim columns (ldc = d)
+        L.check(L.lib().avd_gemm_bias_act_f32(tok.data_ptr(), tok.shape[2], L.dev_f32(w).data_ptr(), L.dev_f32(b).data_ptr(),
+                                              None, 0, Xp.data_ptr(), d, B * tok.shape[1], d - td, tok.shape[2],
+                                              L.ACT_NONE, L.stream_ptr(self.device)))
+        if td:
+            Xp[..., d - td:] = su.timestep_embedding(torch.zeros(B, dtype=torch.long, device=self.device), td)[:, None, :]
+        self.Xp = Xp
+        return Xp
+
+    def step(self, z: torch.Tensor, t_now: torch.Tensor, t_prev: torch.Tensor,
+             noise: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.Xp is None:
+            raise RuntimeError("call set_prompt() first")
+        z = L.dev_f32(z, "z")
+        if tuple(z.shape) != self.latent_shape:
+            raise ValueError(f"latent shape {tuple(z.shape)} != engine shape {self.latent_shape}")
+        tn, tp = L.dev_i64(t_now, self.device), L.dev_i64(t_prev, self.device)
+        if self.eta > 0 and noise is None:
+            noise = torch.randn_like(z)
+        out = torch.empty_like(z) if out is None else out
+        L.check(L.lib().avd_denoise_step_f32(C.byref(self.desc), z.data_ptr(), self.Xp.data_ptr(), tn.data_ptr(),
+                                             tp.data_ptr(), L.ptr(noise), out.data_ptr(), self.workspace.data_ptr(),
+                                             self.workspace.numel(), L.stream_ptr(self.device)))
+        return out
+
+    def eps_tokens(self) -> torch.Tensor:
+        """cond/null ε̂ tokens [2B,Nt,D] left in the workspace by the last step (debug / parity only)."""
+        e = self.embed
+        D = self.head.output_dims[self.target]
+        n = 2 * e.B * e.Nt * D
+        tail = self.workspace[self.workspace.numel() - ((n * 4 + 255) // 256) * 256:]
+        return tail[: n * 4].view(torch.float32).view(2 * e.B, e.Nt, D).clone()
+
+    # ---- whole trajectory -------------------------------------------------------------------------------
+    def begin(self, sched: torch.Tensor) -> None:
+        """Upload a sampling schedule and put the device-side cursor at its start (no per-step H2D afterwards)."""
+        dev, B = self.device, self.embed.B
+        self._sched = sched.to(dev, torch.long).contiguous()
+        self._cursor = torch.zeros(1, dtype=torch.int32, device=dev)
+        self._tn = torch.empty(B, dtype=torch.long, device=dev)
+        self._tp = torch.empty(B, dtype=torch.long, device=dev)
+
+    def rewind(self) -> None:
+        self._cursor.zero_()
+
+    def advance(self, src: torch.Tensor, dst: torch.Tensor) -> None:
+        """dst = one step from src at the cursor's (t_now, t_prev); the cursor moves on, all on the stream."""
+        L.check(L.lib().avd_sched_advance(self._sched.data_ptr(), self._sched.numel(), self._cursor.data_ptr(),
+                                          self._tn.data_ptr(), self._tp.data_ptr(), self.embed.B,
+                                          L.stream_ptr(self.device)))
+        self.step(src, self._tn, self._tp, out=dst)
+
+    def capture_pair(self, za: torch.Tensor, zb: torch.Tensor) -> "torch.cuda.CUDAGraph":
+        """Capture two steps (za -> zb -> za) into one HIP graph; replaying it advances the trajectory by two."""
+        if self.eta > 0:
+            raise NotImplementedError("graph replay with eta > 0 would replay the same noise")
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.advance(za, zb)
+            self.advance(zb, za)
+        return g
+
+    def run(self, z: torch.Tensor, sched: torch.Tensor, graph: bool = False) -> torch.Tensor:
+        """Apply len(sched)-1 steps.  ``graph=True`` replays a captured two-step HIP graph."""
+        self.begin(sched)
+        za = L.dev_f32(z, "z").clone()
+        zb = torch.empty_like(za)
+        n_steps = self._sched.numel() - 1
+        if not graph or n_steps < 3:
+            for _ in range(n_steps):
+                self.advance(za, zb)
+                za, zb = zb, za
+            return za
+        self.advance(za, zb)                        # warm-up step outside capture
+        za, zb = zb, za
+        g = self.capture_pair(za, zb)               # capture enqueues nothing: the cursor still reads 1
+        for _ in range((n_steps - 1) // 2):
+            g.replay()
+        if (n_steps - 1) % 2:
+            self.advance(za, zb)
+            za = zb
+        return za
+
+
+# ----------------------------------------------------------------------------------------------------------
+# reference-signature entry point (B = 1, codec / VAE supplied by the caller)
+# ----------------------------------------------------------------------------------------------------------
+
+@torch.no_grad()
+def sample_one_direction(*, cfg: Dict, vid_vae, aud_codec, adapt_v: LinearAdapter, adapt_a: LinearAdapter,
+                         core: MMDiT, head: MultiModalNoiseHead, tstep_dim: int, prompt_modality: str,
+                         prompt_video: Optional[np.ndarray], prompt_audio: Optional[np.ndarray],
+                         device: torch.device) -> Dict[str, np.ndarray]:
+    """sample_clip.py:220-394 with the loop on the HIP engine.  The V->A branch uses the [1,3,T,H,W] layout the
+    reference's comment intends (its own permute at :288 is a bug that crashes in conv3d)."""
+    dcfg, scfg = cfg["diffusion"], cfg["sampling"]
+    eta = float(scfg.get("ddim_eta", 0.0))
+    t_p, p = int(cfg["tokenizer"]["video"]["tube"]["t"]), int(cfg["tokenizer"]["video"]["tube"]["h"])
+    l_chunk = int(cfg["tokenizer"]["audio"]["chunk"]["length"])
+    s_chunk = int(cfg["tokenizer"]["audio"]["chunk"]["stride"])
+    Cv, t_down, s_down = (int(cfg["video"]["latent"][k]) for k in ("channels", "t_down", "s_down"))
+    Ca, Fa = int(cfg["audio"]["latent"]["channels"]), int(cfg["audio"]["latent"]["frames_per_clip"])
+    fps, sr = int(cfg["video"]["fps"]), int(cfg["audio"]["sr"])
+    H, W = int(cfg["video"]["size"][0]), int(cfg["video"]["size"][1])
+
+    def table(m):
+        c = dcfg[m]
+        betas = su.make_beta_schedule(int(c["steps"]), kind=c["schedule"], min_beta=c["min_beta"], max_beta=c["max_beta"])
+        return su.alphas_cumprod_from_betas(betas)[1], su.make_sampling_schedule(int(c["steps"]), int(c["sampler_steps"]))
+
+    if prompt_modality == "video":
+        if prompt_video is None:
+            raise ValueError("prompt_video frames required for prompt_modality=video")
+        frames = torch.from_numpy(prompt_video).to(device).float() / 255.0          # [T,H,W,3]
+        z_p = vid_vae.encode(frames.permute(3, 0, 1, 2).unsqueeze(0).contiguous())   # [1,3,T,H,W] -> [1,Cv,T',H',W']
+        z = torch.randn(1, Ca, Fa, device=device)
+        target, guide = "audio", float(scfg["guidance_scale"].get("audio", 3.0))
+        n_prompt = (z_p.shape[2] // t_p) * (z_p.shape[3] // p) * (z_p.shape[4] // p)
+    elif prompt_modality == "audio":
+        if prompt_audio is None:
+            raise ValueError("prompt_audio required for prompt_modality=audio")
+        wav = torch.from_numpy(prompt_audio).to(device).view(1, 1, -1)
+        z_p = aud_codec.encode(wav)                                                  # [1,Ca,Fa]
+        T_in = prompt_video.shape[0] if prompt_video is not None else int(round(cfg["data"]["clip_seconds"] * fps))
+        z = torch.randn(1, Cv, max(1, T_in // t_down), H // s_down, W // s_down, device=device)
+        target, guide = "video", float(scfg["guidance_scale"].get("video", 3.0))
+        n_prompt = (z_p.shape[-1] - l_chunk) // s_chunk + 1
+    else:
+        raise ValueError("prompt_modality must be 'video' or 'audio'")
+
+    abar, sched = table(target)
+    eng = DenoiseEngine(adapt_v=adapt_v, adapt_a=adapt_a, core=core, head=head, tstep_dim=tstep_dim, target=target,
+                        latent_shape=tuple(z.shape), prompt_tokens=n_prompt, alpha_bar=abar, guidance=guide, eta=eta,
+                        tube=(t_p, p, p), chunk=(l_chunk, s_chunk))
+    eng.set_prompt(z_p.float())
+    z = eng.run(z, sched)
+    if target == "audio":
+        return {"audio": aud_codec.decode(z).squeeze(0).squeeze(0).detach().cpu().numpy(), "sr": sr}
+    x_hat = vid_vae.decode(z).clamp(0, 1)
+    return {"video": (x_hat[0].permute(1, 2, 3, 0).detach().cpu().numpy() * 255.0).astype(np.uint8), "fps": fps}
