@@ -26,6 +26,22 @@ if str(ROOT) not in sys.path:
 
 import torch
 
+def host_cores() -> int:
+    """CPU threads this process may actually use (cgroup quota / affinity), not the machine's core count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        q, p = Path("/sys/fs/cgroup/cpu.max").read_text().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return int(os.environ.get("AVD_CPU_THREADS", min(n, 16 * max(1, torch.cuda.device_count()) if n > 64 else n)))
+
+
 PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
 PEAK_HBM_GBS = 8000.0
 
@@ -132,9 +148,14 @@ def main():
                 eng.rewind()
                 za.copy_(z0)
             if graph is not None and (S - state["i"] % S) >= 2 and k - done >= 2:
-                graph.replay()
+                graph.replay()               # za -> zb -> za on the captured buffers
                 state["i"] += 2
                 done += 2
+            elif graph is not None:          # odd step in graph mode: keep the captured buffer roles
+                eng.advance(za, zb)
+                za.copy_(zb)
+                state["i"] += 1
+                done += 1
             else:
                 eng.advance(za, zb)
                 za, zb = zb, za
@@ -207,7 +228,7 @@ def main():
     # ---- CPU baseline: the oracle (a from-scratch torch port of the reference step) on this host's cores
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ref_cpu as R
-        cores = os.cpu_count() or 1
+        cores = host_cores()
         torch.set_num_threads(cores)
         W = cpu_state(mods)
         zc = z0.cpu()

@@ -15,14 +15,21 @@
 //  * the MFMA sums over k in a permuted order: lane half h of MFMA step j inside an 8-wide k group reads
 //    k = 8*g + 4*h + j for BOTH operands, so one ds_read_b128 feeds four MFMAs with no shuffles.
 //  * register-staged double buffering: tile k+1's global loads are issued before tile k's MFMAs, written to
-//    the other LDS buffer after them; one barrier per K tile.
+//    the other LDS buffer after them; one barrier per K tile.  Full K tiles load unconditionally; a ragged last
+//    tile (K % 32) takes a wave-uniform branch to a guarded load, so the steady state has no exec masking.
+//  * the epilogue is specialised at compile time (bias / bias+GELU / bias+residual, plain row-major, whole
+//    32x32 tiles in range) with a generic runtime-checked fallback for ragged edges and segmented rows.
 //  * block ids are remapped so each XCD (private L2) gets a contiguous range of tiles that share A panels.
 #include "avd_common.h"
+
+#include <stdlib.h>
 
 namespace avd {
 
 constexpr int GEMM_BK = 32;
 constexpr int GEMM_LD = GEMM_BK + 4;
+
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RES = 2, EPI_GENERIC = 3 };
 
 struct GemmArgs {
     const float* A;
@@ -39,7 +46,7 @@ struct GemmArgs {
     int nbn;
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int EPI, bool KTAIL>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     for (int i = 0; i < A_IT; ++i) {
         int64_t row = (int64_t)bm * BM + lrow + 32 * i;
         row = row < g.M ? row : g.M - 1;
-        a_src[i] = g.A + g.am.off(row) + lkc;
+        a_src[i] = g.A + (EPI == EPI_GENERIC ? g.am.off(row) : row * g.am.ld) + lkc;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -94,15 +101,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     const int nk = (g.K + GEMM_BK - 1) / GEMM_BK;
     f32x4 ra[A_IT], rb[B_IT];
 
+    // KTAIL=false (K % 32 == 0): unconditional loads — any branch here makes hipcc merge the paths behind a
+    // vmcnt(0) and the prefetch no longer overlaps the MFMAs.  KTAIL=true: per-chunk guard (K % 4 == 0).
     auto load_tile = [&](int kt) {
         const int k0 = kt * GEMM_BK;
-        const bool in = (k0 + lkc) < g.K;    // K % 4 == 0: a chunk is wholly in or out
+        if constexpr (!KTAIL) {
 #pragma unroll
-        for (int i = 0; i < A_IT; ++i)
-            ra[i] = in ? *reinterpret_cast<const f32x4*>(a_src[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + k0);
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i)
-            rb[i] = in ? *reinterpret_cast<const f32x4*>(b_src[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < B_IT; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_src[i] + k0);
+        } else {
+            const bool in = (k0 + lkc) < g.K;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i)
+                ra[i] = in ? *reinterpret_cast<const f32x4*>(a_src[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < B_IT; ++i)
+                rb[i] = in ? *reinterpret_cast<const f32x4*>(b_src[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
     };
     auto store_tile = [&](int buf) {
         float* as = As + buf * BM * GEMM_LD + st_off;
@@ -147,36 +163,55 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     }
 
     // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-    const bool has_res = g.R != nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int64_t m0 = (int64_t)bm * BM + wm * WM + i * 32;
         if (m0 >= g.M) continue;
+        const bool rows_full = m0 + 32 <= g.M;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n = bn * BN + wn * WN + j * 32 + l31;
-            const bool n_ok = n < g.N;
-            const float bv = (g.bias != nullptr && n_ok) ? g.bias[n] : 0.f;
+            const int n0 = bn * BN + wn * WN + j * 32;
+            if (n0 >= g.N) continue;
+            const int n = n0 + l31;
+            if (EPI != EPI_GENERIC && rows_full && n0 + 32 <= g.N) {
+                // fast path: whole 32x32 tile in range, plain row-major C (and R)
+                const float bv = g.bias ? g.bias[n] : 0.f;
+                float* crow = g.C + (m0 + 4 * hi) * g.cm.ld + n;
+                const float* rrow = EPI == EPI_RES ? g.R + (m0 + 4 * hi) * g.rm.ld + n : nullptr;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + mfma32_row(r, hi);
-                if (m < g.M && n_ok) {
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = (r & 3) + 8 * (r >> 2);
                     float v = acc[i][j][r] + bv;
-                    if (g.act == AVD_ACT_GELU) v = gelu_erf(v);
-                    else if (g.act == AVD_ACT_SILU) v = silu(v);
-                    if (has_res) v += g.R[g.rm.off(m) + n];
-                    g.C[g.cm.off(m) + n] = v;
+                    if (EPI == EPI_GELU) v = gelu_erf(v);
+                    if (EPI == EPI_RES) v += rrow[ro * g.rm.ld];
+                    crow[ro * g.cm.ld] = v;
+                }
+            } else {
+                const bool n_ok = n < g.N;
+                const float bv = (g.bias != nullptr && n_ok) ? g.bias[n] : 0.f;
+                const int act = EPI == EPI_GENERIC ? g.act : (EPI == EPI_GELU ? AVD_ACT_GELU : AVD_ACT_NONE);
+                const bool has_res = EPI == EPI_GENERIC ? (g.R != nullptr) : (EPI == EPI_RES);
+#pragma unroll 1
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t m = m0 + mfma32_row(r, hi);
+                    if (m < g.M && n_ok) {
+                        float v = acc[i][j][r] + bv;
+                        if (act == AVD_ACT_GELU) v = gelu_erf(v);
+                        else if (act == AVD_ACT_SILU) v = silu(v);
+                        if (has_res) v += g.R[g.rm.off(m) + n];
+                        g.C[g.cm.off(m) + n] = v;
+                    }
                 }
             }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch_gemm(const GemmArgs& a, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, int EPI, bool KTAIL>
+static int launch_gemm_epi(const GemmArgs& a, hipStream_t st) {
     constexpr int lds = 2 * (BM + BN) * GEMM_LD * (int)sizeof(float);
     static bool attr_set = false;
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN>;
+    auto kern = gemm_f32_kernel<BM, BN, WM, WN, EPI, KTAIL>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -196,6 +231,16 @@ static int launch_gemm(const GemmArgs& a, hipStream_t st) {
     return AVD_OK;
 }
 
+template <int BM, int BN, int WM, int WN>
+static int launch_gemm(const GemmArgs& a, hipStream_t st) {
+    if (a.K % GEMM_BK) return launch_gemm_epi<BM, BN, WM, WN, EPI_GENERIC, true>(a, st);
+    const bool plain = a.am.seg <= 0 && a.cm.seg <= 0 && (a.R == nullptr || a.rm.seg <= 0);
+    if (plain && a.act == AVD_ACT_NONE && a.R == nullptr) return launch_gemm_epi<BM, BN, WM, WN, EPI_BIAS, false>(a, st);
+    if (plain && a.act == AVD_ACT_GELU && a.R == nullptr) return launch_gemm_epi<BM, BN, WM, WN, EPI_GELU, false>(a, st);
+    if (plain && a.act == AVD_ACT_NONE && a.R != nullptr) return launch_gemm_epi<BM, BN, WM, WN, EPI_RES, false>(a, st);
+    return launch_gemm_epi<BM, BN, WM, WN, EPI_GENERIC, false>(a, st);
+}
+
 int gemm_f32(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm,
              float* C, RowMap cm, int64_t M, int N, int K, int act, hipStream_t st) {
     AVD_REQUIRE(A && W && C, AVD_EINVAL, "gemm: null pointer");
@@ -208,6 +253,11 @@ int gemm_f32(const float* A, RowMap am, const float* W, const float* bias, const
     if (M == 0) return AVD_OK;
     GemmArgs g{A, am, W, bias, R, rm, C, cm, M, N, K, act, 0};
     // tile choice: big square tiles when there is enough work to fill 256 CUs x 2 blocks, finer ones otherwise
+    static const int force = getenv("AVD_GEMM_TILE") ? atoi(getenv("AVD_GEMM_TILE")) : -1;   // tuning/debug only
+    if (force == 0) return launch_gemm<128, 128, 64, 64>(g, st);
+    if (force == 1) return launch_gemm<128, 64, 64, 32>(g, st);
+    if (force == 2) return launch_gemm<64, 64, 32, 32>(g, st);
+    if (force == 3) return launch_gemm<128, 32, 32, 32>(g, st);
     const int64_t big = ((M + 127) / 128) * ((N + 127) / 128);
     if (N >= 128 && big >= 512) return launch_gemm<128, 128, 64, 64>(g, st);
     if (N >= 64 && ((M + 127) / 128) * ((N + 63) / 64) >= 384) return launch_gemm<128, 64, 64, 32>(g, st);

@@ -120,11 +120,24 @@ def test_rmsnorm_and_layernorm_widths(dev, d):
 
 
 def test_timestep_embedding_golden(dev):
-    from multimodal_diffusion_amd import schedule_utils as su
+    from multimodal_diffusion_amd import schedule_utils as su, functional as Fn
     g = load_golden("g2_temb.npz")
     t = G(g["t"], dev)
     for dim, key in ((256, "e256"), (64, "e64"), (7, "e7")):
-        assert rel_err(su.timestep_embedding(t, dim).cpu(), g[key]) < 2e-6, dim
+        got = su.timestep_embedding(t, dim).cpu()
+        # (1) tight: kernel cos/sin against fp64 cos/sin of the SAME fp32 angle t*f (f = the uploaded table)
+        f = Fn.temb_freqs(dim, 10000, dev).cpu()
+        ang = (T(g["t"]).float()[:, None] * f[None, :]).double()
+        exact = torch.cat([ang.cos(), ang.sin()], 1)
+        if dim % 2:
+            exact = torch.nn.functional.pad(exact, (0, 1))
+        assert rel_err(got, exact) < 1e-6, dim
+        # (2) golden from the reference run in the build container.  f = exp(.) is evaluated by the HOST's vectorised
+        # fp32 exp, which differs by 1 ulp between CPU generations; at t = 999 that moves the angle by
+        # 999 * 2^-24 = 6e-5, so the reference itself is only reproducible to ~1.2e-4 across machines.
+        assert rel_err(got, g[key]) < 1.2e-4, dim
+    e0 = su.timestep_embedding(torch.zeros(3, dtype=torch.long, device=dev), 256).cpu()
+    assert torch.equal(e0[:, :128], torch.ones(3, 128)) and torch.equal(e0[:, 128:], torch.zeros(3, 128))
 
 
 def test_patch_unpatch_golden_and_roundtrip(dev):
@@ -261,7 +274,8 @@ def test_step_by_module_calls_matches_engine(dev, small_model):
     el = ops.tube_unpatch_video(et, C=8, T=4, H=8, W=8, t=2, h=4, w=4)
     zn = su.ddim_step(z_v, tn, tp, el, T(g["abar"]), eta=0.0)
     assert rel_err(zn.cpu(), g["a2v/g3.5/z_next"]) < TOL
-    assert rel_err(torch.cat([Xv, Xa], 1).cpu(), g["a2v/X"]) < 1e-5
+    # X holds the sinusoidal embedding at t=982: reproducible to ~1.2e-4 across hosts (see the temb test)
+    assert rel_err(torch.cat([Xv, Xa], 1).cpu(), g["a2v/X"]) < 1.2e-4
 
 
 @pytest.mark.parametrize("graph", [False, True])

@@ -1,0 +1,157 @@
+// Ablation lab for the fp32 MFMA GEMM main loop (timing only; VARIANT != 0 gives wrong results by design).
+//   0 = production structure   1 = no in-loop global loads   2 = no global loads, no LDS writes
+//   3 = MFMA + LDS reads only (no barrier)   4 = production structure (used with other BK)
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+template <int BM, int BN, int WM, int WN, int BK, int VARIANT, int WPS>
+__global__ __launch_bounds__(256, WPS) void k(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ C,
+                                             int M, int N, int K, int nbn) {
+    constexpr int LD = BK + 4;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int CPR = BK / 4;               // 16-byte chunks per row
+    constexpr int RPP = 256 / CPR;            // rows per pass
+    constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * BM * LD;
+    const int nwg = gridDim.x;
+    int wg;
+    { const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7; wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3); }
+    const int bm = wg / nbn, bn = wg % nbn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lrow = tid / CPR, lkc = (tid % CPR) * 4;
+    const float* a_src[A_IT]; const float* b_src[B_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) { int row = bm * BM + lrow + RPP * i; row = row < M ? row : M - 1; a_src[i] = A + (size_t)row * K + lkc; }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) { int n = bn * BN + lrow + RPP * i; n = n < N ? n : N - 1; b_src[i] = W + (size_t)n * K + lkc; }
+    const int st_off = lrow * LD + lkc;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = K / BK;
+    f32x4 ra[A_IT], rb[B_IT];
+    auto load_tile = [&](int kt) {
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + k0);
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_src[i] + k0);
+    };
+    auto store_tile = [&](int buf) {
+        float* as = As + buf * BM * LD + st_off; float* bs = Bs + buf * BN * LD + st_off;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<f32x4*>(as + i * RPP * LD) = ra[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<f32x4*>(bs + i * RPP * LD) = rb[i];
+    };
+    load_tile(0); store_tile(0); store_tile(1); __syncthreads();
+    const int a_rd = (wm * WM + l31) * LD + 4 * hi, b_rd = (wn * WN + l31) * LD + 4 * hi;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1; const bool more = (kt + 1) < nk;
+        if (VARIANT == 0 || VARIANT == 4) { if (more) load_tile(kt + 1); }
+        const float* as = As + cur * BM * LD + a_rd; const float* bs = Bs + cur * BN * LD + b_rd;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + i * 32 * LD + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + j * 32 * LD + kk * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (VARIANT <= 1 || VARIANT == 4) { if (more) store_tile(cur ^ 1); }
+        if (VARIANT != 3) __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = bn * BN + wn * WN + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = bm * BM + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m < M && n < N) C[(size_t)m * N + n] = acc[i][j][r];
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int VARIANT, int WPS>
+void run(const char* name, const float* A, const float* W, float* C, int M, int N, int K) {
+    const int lds = 2 * (BM + BN) * (BK + 4) * 4;
+    auto kern = k<BM, BN, WM, WN, BK, VARIANT, WPS>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) kern<<<nbm * nbn, 256, lds>>>(A, W, C, M, N, K, nbn);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    const int it = 20;
+    for (int i = 0; i < it; ++i) kern<<<nbm * nbn, 256, lds>>>(A, W, C, M, N, K, nbn);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
+    printf("%-36s M=%d N=%d K=%d lds=%d: %8.1f us %7.1f TF\n", name, M, N, K, lds, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
+}
+
+#include "../../include/avdiff_hip.h"
+static void run_lib(const char* name, const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N, int K, int act) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) if (avd_gemm_bias_act_f32(A, K, W, bias, R, N, C, N, M, N, K, act, nullptr)) { printf("lib error %s\n", avd_last_error()); exit(1); }
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    const int it = 20;
+    for (int i = 0; i < it; ++i) avd_gemm_bias_act_f32(A, K, W, bias, R, N, C, N, M, N, K, act, nullptr);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
+    printf("%-36s M=%d N=%d K=%d: %8.1f us %7.1f TF\n", name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
+}
+
+int main(int argc, char** argv) {
+    const int M = 26944;
+    const size_t maxe = (size_t)M * 2048;
+    float *A, *W, *C;
+    CK(hipMalloc(&A, maxe * 4)); CK(hipMalloc(&W, 2048 * 2048 * 4)); CK(hipMalloc(&C, maxe * 4));
+    std::vector<float> h(maxe);
+    for (size_t i = 0; i < maxe; ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
+    CK(hipMemcpy(A, h.data(), maxe * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(W, h.data(), 2048 * 2048 * 4, hipMemcpyHostToDevice));
+    // clock ramp: ~0.5 s of sustained MFMA work before anything is timed (first-run kernels read 15-20 % low)
+    for (int i = 0; i < 1000; ++i) avd_gemm_bias_act_f32(A, 512, W, W, nullptr, 1536, C, 1536, M, 1536, 512, 0, nullptr);
+    CK(hipDeviceSynchronize());
+    for (int pass = 0; pass < 4; ++pass) {
+        const int N = (pass & 1) ? 512 : 1536, K = (pass & 1) ? 2048 : 512;
+        run_lib("LIB bias", A, W, W, nullptr, C, M, N, K, 0);
+        run_lib("LIB bias+gelu", A, W, W, nullptr, C, M, N, K, 1);
+        run_lib("LIB bias+res (R=A)", A, W, W, A, C, M, N, K, 0);
+        run_lib("LIB bias+res in-place", A, W, W, C, C, M, N, K, 0);
+        run<128, 128, 64, 64, 32, 0, 2>("128x128 bk32 v0 prod", A, W, C, M, N, K);
+        run<128, 128, 64, 64, 32, 1, 2>("128x128 bk32 v1 no-gload", A, W, C, M, N, K);
+        run<128, 128, 64, 64, 32, 2, 2>("128x128 bk32 v2 no-gload,no-lds-wr", A, W, C, M, N, K);
+        run<128, 128, 64, 64, 32, 3, 2>("128x128 bk32 v3 mfma+ldsrd only", A, W, C, M, N, K);
+        run<128, 128, 64, 64, 64, 4, 1>("128x128 bk64 prod (1 blk/CU)", A, W, C, M, N, K);
+        run<64, 64, 32, 32, 32, 0, 4>("64x64 bk32 v0 prod", A, W, C, M, N, K);
+        run<64, 64, 32, 32, 32, 3, 4>("64x64 bk32 v3 mfma+ldsrd only", A, W, C, M, N, K);
+        run<64, 64, 32, 32, 64, 4, 4>("64x64 bk64 prod", A, W, C, M, N, K);
+        run<128, 64, 64, 32, 32, 0, 2>("128x64 bk32 v0 prod", A, W, C, M, N, K);
+        run<128, 64, 64, 32, 64, 4, 2>("128x64 bk64 prod", A, W, C, M, N, K);
+        run<256, 64, 64, 64, 32, 0, 2>("256x64(w64x64) bk32 v0", A, W, C, M, N, K);
+    }
+    return 0;
+}
