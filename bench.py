@@ -203,7 +203,7 @@ def main():
         torch.cuda.synchronize()
         L.prof_enable(False)
         rep = L.prof_report()
-        dom = max((k for k in rep if k.startswith("gemm")), key=lambda k: rep[k][1])
+        dom = max((k for k in rep if k.startswith("gemm")), key=lambda k: rep[k][1])   # most time => dominant
         n, ms, work = rep[dom]
         achieved = work / (ms * 1e-3) / 1e12
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,

@@ -214,22 +214,14 @@ int avd_sched_advance(const int64_t* sched, int n_sched, int32_t* cursor, int64_
                       int B, avd_stream_t stream);
 
 /* ---- measurement hooks (bench.py): when enabled, every kernel launch made by this library is bracketed by
- * hipEvents recorded on the launch stream and tagged with a kernel class and its algorithmic work
- * (FLOPs for the MFMA kernels, bytes for the HBM-bound ones).  Disabled by default; zero cost when off.
- * Not for use while a stream is being captured into a graph. */
-#define AVD_PROF_GEMM_128x128 0
-#define AVD_PROF_GEMM_128x64  1
-#define AVD_PROF_GEMM_64x64   2
-#define AVD_PROF_GEMM_128x32  3
-#define AVD_PROF_ATTN         4
-#define AVD_PROF_RMSNORM      5
-#define AVD_PROF_LAYERNORM    6
-#define AVD_PROF_CFG_DDIM     7
-#define AVD_PROF_TOKENS       8   /* patch / assemble / temb / misc */
-#define AVD_PROF_NTAGS        9
-int avd_prof_enable(int on);      /* on=1 start recording (clears previous records), on=0 stop */
+ * hipEvents recorded on the launch stream and tagged with its kernel name (template arguments included, so the
+ * tags line up with rocprofv3's per-kernel rows) and its algorithmic work (FLOPs for the MFMA kernels, bytes
+ * for the HBM-bound ones).  Disabled by default; zero cost when off.  Not for use during graph capture. */
+int         avd_prof_enable(int on);       /* on=1 start recording (clears previous records), on=0 stop */
+int         avd_prof_num_tags(void);
+const char* avd_prof_tag_name(int tag);
 /* synchronises the recorded events and accumulates per tag: launches, total milliseconds, algorithmic work */
-int avd_prof_report(int64_t* launches, double* total_ms, double* work, int ntags);
+int         avd_prof_report(int64_t* launches, double* total_ms, double* work, int ntags);
 
 #ifdef __cplusplus
 }

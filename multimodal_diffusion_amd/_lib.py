@@ -86,24 +86,22 @@ SIGNATURES = {
     "avd_denoise_step_f32": (_I, [C.POINTER(StepDesc), _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "avd_sched_advance": (_I, [_P, _I, _P, _P, _P, _I, _P]),
     "avd_prof_enable": (_I, [_I]),
+    "avd_prof_num_tags": (_I, []),
+    "avd_prof_tag_name": (C.c_char_p, [_I]),
     "avd_prof_report": (_I, [C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double), _I]),
 }
-
-PROF_TAGS = ("gemm_f32_kernel<128,128,64,64>", "gemm_f32_kernel<128,64,64,32>", "gemm_f32_kernel<64,64,32,32>",
-             "gemm_f32_kernel<128,32,32,32>", "attn_f32_kernel", "rmsnorm_kernel", "layernorm_act_kernel",
-             "cfg_unpatch_ddim_kernel", "token_kernels")
-
 
 def prof_enable(on: bool) -> None:
     check(lib().avd_prof_enable(1 if on else 0))
 
 
 def prof_report():
-    """{kernel class: (launches, total_ms, algorithmic work)} for the launches recorded since prof_enable(True)."""
-    n = len(PROF_TAGS)
-    cnt, ms, work = (C.c_int64 * n)(), (C.c_double * n)(), (C.c_double * n)()
+    """{kernel name: (launches, total_ms, algorithmic work)} for the launches recorded since prof_enable(True)."""
+    n = lib().avd_prof_num_tags()
+    cnt, ms, work = (C.c_int64 * max(n, 1))(), (C.c_double * max(n, 1))(), (C.c_double * max(n, 1))()
     check(lib().avd_prof_report(cnt, ms, work, n))
-    return {PROF_TAGS[i]: (int(cnt[i]), float(ms[i]), float(work[i])) for i in range(n)}
+    return {lib().avd_prof_tag_name(i).decode(): (int(cnt[i]), float(ms[i]), float(work[i])) for i in range(n)}
+
 
 _lib: Optional[C.CDLL] = None
 

@@ -191,8 +191,9 @@ int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float sc
     if (n_query == 0) return AVD_OK;
     // 2-wave blocks (64 query rows) waste the fewest padded rows on the ragged N of this model
     // (421 -> 448); 4-wave blocks halve K/V re-reads when N is a comfortable multiple of 128.
-    ProfScope prof(AVD_PROF_ATTN, 4.0 * (double)B * H * (double)n_query * N * ATT_DH, st);
     const int pad2 = ((n_query + 63) / 64) * 64, pad4 = ((n_query + 127) / 128) * 128;
+    static const int tag4 = prof_tag_id("attn_f32_kernel<4>"), tag2 = prof_tag_id("attn_f32_kernel<2>");
+    ProfScope prof(pad4 == pad2 ? tag4 : tag2, 4.0 * (double)B * H * (double)n_query * N * ATT_DH, st);
     if (pad4 == pad2) {
         hipLaunchKernelGGL(attn_f32_kernel<4>, dim3(pad4 / 128, H, B), dim3(256), 0, st, qkv, out, N, H, scale, n_query);
     } else {

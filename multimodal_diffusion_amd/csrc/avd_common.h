@@ -63,6 +63,7 @@ struct RowMap {
 // measurement hooks (see avd_prof_enable): RAII bracket around one launch
 extern bool g_prof_on;
 void prof_mark(int tag, double work, hipStream_t st, bool begin);
+int prof_tag_id(const char* fmt, ...);   // registers a kernel name once, returns its tag
 struct ProfScope {
     int tag; hipStream_t st; bool on;
     ProfScope(int t, double work, hipStream_t s) : tag(t), st(s), on(g_prof_on) { if (on) prof_mark(tag, work, st, true); }

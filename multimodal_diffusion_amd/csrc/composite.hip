@@ -4,6 +4,7 @@
 #include "avd_common.h"
 
 #include <string.h>
+#include <string>
 #include <vector>
 
 namespace avd {
@@ -24,11 +25,23 @@ namespace {
 struct ProfRec { hipEvent_t a, b; int tag; double work; };
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
+std::vector<std::string> g_tags;
 hipEvent_t take_event() {
     if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
 }  // namespace
+int prof_tag_id(const char* fmt, ...) {
+    char buf[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    for (size_t i = 0; i < g_tags.size(); ++i)
+        if (g_tags[i] == buf) return (int)i;
+    g_tags.emplace_back(buf);
+    return (int)g_tags.size() - 1;
+}
 void prof_mark(int tag, double work, hipStream_t st, bool begin) {
     if (begin) {
         ProfRec r{take_event(), take_event(), tag, work};
@@ -297,8 +310,12 @@ extern "C" int avd_prof_enable(int on) {
     return AVD_OK;
 }
 
+extern "C" int avd_prof_num_tags(void) { return (int)g_tags.size(); }
+extern "C" const char* avd_prof_tag_name(int tag) { return (tag >= 0 && tag < (int)g_tags.size()) ? g_tags[tag].c_str() : ""; }
+
 extern "C" int avd_prof_report(int64_t* launches, double* total_ms, double* work, int ntags) {
-    AVD_REQUIRE(launches && total_ms && work && ntags >= AVD_PROF_NTAGS, AVD_EINVAL, "prof_report: need %d tags", AVD_PROF_NTAGS);
+    AVD_REQUIRE(launches && total_ms && work && ntags >= (int)g_tags.size(), AVD_EINVAL, "prof_report: need %d tags",
+                (int)g_tags.size());
     for (int i = 0; i < ntags; ++i) { launches[i] = 0; total_ms[i] = 0.0; work[i] = 0.0; }
     for (auto& r : g_recs) {
         hipError_t e = hipEventSynchronize(r.b);

@@ -7,19 +7,22 @@
 //
 // Design (MI355X):
 //  * v_mfma_f32_32x32x2_f32: exact fp32 multiply-accumulate, 64 FLOP/clk/SIMD (the fp32 roof, 157 TF).
-//    A 32x32 tile costs ONE A and ONE B VGPR per MFMA, so LDS bandwidth is never the limiter; the kernel
-//    is built to keep the matrix pipe issuing back to back.
-//  * both operands are row-major with K contiguous (activations [M,K], torch weights [N,K]); tiles are staged
-//    global -> registers -> LDS as [rows][32+4] floats.  The +4 pad makes the ds_read_b128 fragment reads
-//    (16 distinct rows per lane group, 16 B each) and the ds_write_b128 stores conflict-free.
+//    A 32x32 tile costs ONE A and ONE B VGPR per MFMA, so LDS bandwidth is never the limiter; the kernels are
+//    built to keep the matrix pipe issuing back to back.
+//  * both operands are row-major with K contiguous (activations [M,K], torch weights [N,K]).
 //  * the MFMA sums over k in a permuted order: lane half h of MFMA step j inside an 8-wide k group reads
 //    k = 8*g + 4*h + j for BOTH operands, so one ds_read_b128 feeds four MFMAs with no shuffles.
-//  * register-staged double buffering: tile k+1's global loads are issued before tile k's MFMAs, written to
-//    the other LDS buffer after them; one barrier per K tile.  Full K tiles load unconditionally; a ragged last
-//    tile (K % 32) takes a wave-uniform branch to a guarded load, so the steady state has no exec masking.
-//  * the epilogue is specialised at compile time (bias / bias+GELU / bias+residual, plain row-major, whole
-//    32x32 tiles in range) with a generic runtime-checked fallback for ragged edges and segmented rows.
 //  * block ids are remapped so each XCD (private L2) gets a contiguous range of tiles that share A panels.
+//
+// Two kernels:
+//  gemm_f32_dma_kernel — the hot path (K % 32 == 0, plain row-major C/R).  K tiles go global -> LDS directly
+//    (global_load_lds_dwordx4, no VGPR staging, no ds_write): one wave instruction lands 8 rows x 128 B = 1 KiB
+//    lane-linearly, so the LDS image is unpadded [rows][32] floats and bank conflicts are removed by XOR-ing the
+//    16-byte chunk index with (row>>1)&7 on the per-lane SOURCE address and again on the fragment read.
+//    Two LDS stages; tile k+1 is in flight under tile k's MFMAs.  The epilogue parks each wave's tile in LDS and
+//    streams it out as whole 16-byte row segments with bias / exact-erf GELU / residual applied on float4s.
+//  gemm_f32_reg_kernel — generic fallback (ragged K, segmented C/R row maps, SiLU, N = 32 outputs):
+//    register-staged double buffering into [rows][32+4]-padded LDS, runtime-checked scalar epilogue.
 #include "avd_common.h"
 
 #include <stdlib.h>
@@ -29,7 +32,7 @@ namespace avd {
 constexpr int GEMM_BK = 32;
 constexpr int GEMM_LD = GEMM_BK + 4;
 
-enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RES = 2, EPI_GENERIC = 3 };
+enum { EPI_BIAS = 0, EPI_GELU = 1, EPI_RES = 2 };
 
 struct GemmArgs {
     const float* A;
@@ -46,11 +49,172 @@ struct GemmArgs {
     int nbn;
 };
 
-template <int BM, int BN, int WM, int WN, int EPI, bool KTAIL>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+__device__ __forceinline__ int xcd_remap(int b, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+#define AVD_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define AVD_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// =====================================================================================================
+// hot path: LDS-DMA staged main loop + LDS-staged float4 epilogue
+// =====================================================================================================
+template <int BM, int BN, int WM, int WN, int EPI, int WPS>
+__global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
+    constexpr int BK = GEMM_BK;
     constexpr int WAVES_N = BN / WN;
-    constexpr int WAVES_M = BM / WM;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+    static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_PIECES = BM / 32, B_PIECES = BN / 32;   // 1-KiB pieces (8 rows x 128 B) per wave
+    constexpr int STAGE = (BM + BN) * BK;                   // floats per stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
+    const int bm = wg / g.nbn, bn = wg % g.nbn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    // ---- DMA source addresses: piece p = tile rows 8p..8p+7; lane -> row 8p + lane/8, PHYSICAL chunk lane%8 ----
+    const int r8 = lane >> 3, pc = lane & 7;
+    const float* a_src[A_PIECES];
+    const float* b_src[B_PIECES];
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+        const int trow = (wave + 4 * i) * 8 + r8;
+        int64_t row = (int64_t)bm * BM + trow;
+        row = row < g.M ? row : g.M - 1;
+        a_src[i] = g.A + g.am.off(row) + ((pc ^ ((trow >> 1) & 7)) << 2);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) {
+        const int trow = (wave + 4 * i) * 8 + r8;
+        int n = bn * BN + trow;
+        n = n < g.N ? n : g.N - 1;
+        b_src[i] = g.W + (int64_t)n * g.K + ((pc ^ ((trow >> 1) & 7)) << 2);
+    }
+    auto stage = [&](int kt, int buf) {
+        float* as = smem + buf * STAGE;
+        float* bs = as + BM * BK;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(a_src[i] + k0), AVD_LDS_PTR(as + (wave + 4 * i) * 8 * BK), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(b_src[i] + k0), AVD_LDS_PTR(bs + (wave + 4 * i) * 8 * BK), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = g.K / BK;
+    stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+    __syncthreads();
+
+    // fragment read offsets (floats): row*32 + ((2kk+hi) ^ ((row>>1)&7))*4 — conflict-free ds_read_b128
+    int a_row[TM], a_sw[TM], b_row[TN], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * WM + i * 32 + l31;
+        a_row[i] = r * BK;
+        a_sw[i] = (r >> 1) & 7;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = wn * WN + j * 32 + l31;
+        b_row[j] = r * BK;
+        b_sw[j] = (r >> 1) & 7;
+    }
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const float* as = smem + cur * STAGE;
+        const float* bs = as + BM * BK;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(as + a_row[i] + (((2 * kk + hi) ^ a_sw[i]) << 2));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(bs + b_row[j] + (((2 * kk + hi) ^ b_sw[j]) << 2));
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the next stage has landed
+        __syncthreads();
+    }
+
+    // ---- epilogue: park the wave's WM x WN tile in its own LDS slab, stream it out as 16-byte row segments ----
+    constexpr int CLD = WN + 4;
+    float* slab = smem + wave * WM * CLD;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) slab[(i * 32 + mfma32_row(r, hi)) * CLD + j * 32 + l31] = acc[i][j][r];
+    __syncthreads();
+
+    constexpr int LPR = WN / 4;     // lanes per output row
+    constexpr int RPI = 64 / LPR;   // rows per wave instruction
+    constexpr int NIT = WM / RPI;
+    const int cr = lane / LPR, cc = (lane % LPR) * 4;
+    const int n = bn * BN + wn * WN + cc;
+    if (n >= g.N) return;           // N % 4 == 0: a float4 is wholly in or out
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+    const int64_t mbase = (int64_t)bm * BM + wm * WM + cr;
+    float* cptr = g.C + mbase * g.cm.ld + n;
+    const float* rptr = EPI == EPI_RES ? g.R + mbase * g.rm.ld + n : nullptr;
+    constexpr int CHUNK = NIT < 8 ? NIT : 8;
+#pragma unroll
+    for (int c0 = 0; c0 < NIT; c0 += CHUNK) {
+        f32x4 rv[CHUNK];
+        if (EPI == EPI_RES) {
+#pragma unroll
+            for (int u = 0; u < CHUNK; ++u) {
+                const int64_t m = mbase + (int64_t)(c0 + u) * RPI;
+                rv[u] = m < g.M ? *reinterpret_cast<const f32x4*>(rptr + (int64_t)(c0 + u) * RPI * g.rm.ld) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < CHUNK; ++u) {
+            const int it = c0 + u;
+            f32x4 v = *reinterpret_cast<const f32x4*>(slab + (cr + it * RPI) * CLD + cc);
+            v += bv;
+            if (EPI == EPI_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            }
+            if (EPI == EPI_RES) v += rv[u];
+            if (mbase + (int64_t)it * RPI < g.M) *reinterpret_cast<f32x4*>(cptr + (int64_t)it * RPI * g.cm.ld) = v;
+        }
+    }
+}
+
+// =====================================================================================================
+// generic fallback: register-staged double buffering, runtime-checked scalar epilogue
+// =====================================================================================================
+template <int BM, int BN, int WM, int WN, bool KTAIL>
+__global__ __launch_bounds__(256, 2) void gemm_f32_reg_kernel(GemmArgs g) {
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
 
@@ -58,21 +222,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     float* As = smem;                       // [2][BM][GEMM_LD]
     float* Bs = smem + 2 * BM * GEMM_LD;    // [2][BN][GEMM_LD]
 
-    // ---- XCD-aware, bijective block remap (blocks b and b+8 share an XCD) ----
-    const int nwg = gridDim.x;
-    int wg;
-    {
-        const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
-        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-    }
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int bm = wg / g.nbn, bn = wg % g.nbn;
-
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    // ---- global staging addresses: thread -> (row tid/8 + 32 i, 16-byte chunk tid%8) ----
+    // global staging addresses: thread -> (row tid/8 + 32 i, 16-byte chunk tid%8)
     const int lrow = tid >> 3, lkc = (tid & 7) * 4;
     const float* a_src[A_IT];
     const float* b_src[B_IT];
@@ -80,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     for (int i = 0; i < A_IT; ++i) {
         int64_t row = (int64_t)bm * BM + lrow + 32 * i;
         row = row < g.M ? row : g.M - 1;
-        a_src[i] = g.A + (EPI == EPI_GENERIC ? g.am.off(row) : row * g.am.ld) + lkc;
+        a_src[i] = g.A + g.am.off(row) + lkc;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -101,8 +258,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     const int nk = (g.K + GEMM_BK - 1) / GEMM_BK;
     f32x4 ra[A_IT], rb[B_IT];
 
-    // KTAIL=false (K % 32 == 0): unconditional loads — any branch here makes hipcc merge the paths behind a
-    // vmcnt(0) and the prefetch no longer overlaps the MFMAs.  KTAIL=true: per-chunk guard (K % 4 == 0).
+    // KTAIL=false (K % 32 == 0): unconditional loads — a branch here makes hipcc merge the paths behind a
+    // vmcnt(0) and the prefetch stops overlapping the MFMAs.  KTAIL=true: per-chunk guard (K % 4 == 0).
     auto load_tile = [&](int kt) {
         const int k0 = kt * GEMM_BK;
         if constexpr (!KTAIL) {
@@ -140,7 +297,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         const int cur = kt & 1;
         const bool more = (kt + 1) < nk;
         if (more) load_tile(kt + 1);
-
         const float* as = As + cur * BM * GEMM_LD + a_rd;
         const float* bs = Bs + cur * BN * GEMM_LD + b_rd;
 #pragma unroll
@@ -162,83 +318,91 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+    // epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const bool has_res = g.R != nullptr;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int64_t m0 = (int64_t)bm * BM + wm * WM + i * 32;
         if (m0 >= g.M) continue;
-        const bool rows_full = m0 + 32 <= g.M;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int n0 = bn * BN + wn * WN + j * 32;
-            if (n0 >= g.N) continue;
-            const int n = n0 + l31;
-            if (EPI != EPI_GENERIC && rows_full && n0 + 32 <= g.N) {
-                // fast path: whole 32x32 tile in range, plain row-major C (and R)
-                const float bv = g.bias ? g.bias[n] : 0.f;
-                float* crow = g.C + (m0 + 4 * hi) * g.cm.ld + n;
-                const float* rrow = EPI == EPI_RES ? g.R + (m0 + 4 * hi) * g.rm.ld + n : nullptr;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ro = (r & 3) + 8 * (r >> 2);
-                    float v = acc[i][j][r] + bv;
-                    if (EPI == EPI_GELU) v = gelu_erf(v);
-                    if (EPI == EPI_RES) v += rrow[ro * g.rm.ld];
-                    crow[ro * g.cm.ld] = v;
-                }
-            } else {
-                const bool n_ok = n < g.N;
-                const float bv = (g.bias != nullptr && n_ok) ? g.bias[n] : 0.f;
-                const int act = EPI == EPI_GENERIC ? g.act : (EPI == EPI_GELU ? AVD_ACT_GELU : AVD_ACT_NONE);
-                const bool has_res = EPI == EPI_GENERIC ? (g.R != nullptr) : (EPI == EPI_RES);
+            const int n = bn * BN + wn * WN + j * 32 + l31;
+            const bool n_ok = n < g.N;
+            const float bv = (g.bias != nullptr && n_ok) ? g.bias[n] : 0.f;
 #pragma unroll 1
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t m = m0 + mfma32_row(r, hi);
-                    if (m < g.M && n_ok) {
-                        float v = acc[i][j][r] + bv;
-                        if (act == AVD_ACT_GELU) v = gelu_erf(v);
-                        else if (act == AVD_ACT_SILU) v = silu(v);
-                        if (has_res) v += g.R[g.rm.off(m) + n];
-                        g.C[g.cm.off(m) + n] = v;
-                    }
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + mfma32_row(r, hi);
+                if (m < g.M && n_ok) {
+                    float v = acc[i][j][r] + bv;
+                    if (g.act == AVD_ACT_GELU) v = gelu_erf(v);
+                    else if (g.act == AVD_ACT_SILU) v = silu(v);
+                    if (has_res) v += g.R[g.rm.off(m) + n];
+                    g.C[g.cm.off(m) + n] = v;
                 }
             }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, bool KTAIL>
-static int launch_gemm_epi(const GemmArgs& a, hipStream_t st) {
-    constexpr int lds = 2 * (BM + BN) * GEMM_LD * (int)sizeof(float);
-    static bool attr_set = false;
-    auto kern = gemm_f32_kernel<BM, BN, WM, WN, EPI, KTAIL>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+// =====================================================================================================
+// host side
+// =====================================================================================================
+template <typename Kern>
+static int set_lds(Kern kern, int lds, bool& done) {
+    if (!done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return set_error(AVD_ELAUNCH, "gemm attr: %s", hipGetErrorString(e));
-        attr_set = true;
+        done = true;
     }
+    return AVD_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int WPS>
+static int launch_dma(const GemmArgs& a, hipStream_t st) {
+    constexpr int stage_lds = 2 * (BM + BN) * GEMM_BK * 4, epi_lds = 4 * WM * (WN + 4) * 4;
+    constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
+    static bool attr = false;
+    auto kern = gemm_f32_dma_kernel<BM, BN, WM, WN, EPI, WPS>;
+    if (int rc = set_lds(kern, lds, attr)) return rc;
     GemmArgs g = a;
-    const int64_t nbm = (a.M + BM - 1) / BM;
     g.nbn = (a.N + BN - 1) / BN;
-    const int64_t nwg = nbm * g.nbn;
+    const int64_t nwg = ((a.M + BM - 1) / BM) * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm grid too large");
-    constexpr int tag = (BM == 128 && BN == 128) ? AVD_PROF_GEMM_128x128 : (BM == 128 && BN == 64) ? AVD_PROF_GEMM_128x64
-                        : (BM == 64) ? AVD_PROF_GEMM_64x64 : AVD_PROF_GEMM_128x32;
+    static const int tag = prof_tag_id("gemm_f32_dma_kernel<%d,%d,%d,%d,%s>", BM, BN, WM, WN,
+                                       EPI == EPI_BIAS ? "bias" : EPI == EPI_GELU ? "gelu" : "res");
     ProfScope prof(tag, 2.0 * (double)a.M * a.N * a.K, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, g);
-    AVD_CHECK_LAUNCH("gemm_f32");
+    AVD_CHECK_LAUNCH("gemm_f32_dma");
+    return AVD_OK;
+}
+
+template <int BM, int BN, int WM, int WN, int WPS>
+static int launch_dma_epi(const GemmArgs& a, hipStream_t st) {
+    if (a.R != nullptr) return launch_dma<BM, BN, WM, WN, EPI_RES, WPS>(a, st);
+    if (a.act == AVD_ACT_GELU) return launch_dma<BM, BN, WM, WN, EPI_GELU, WPS>(a, st);
+    return launch_dma<BM, BN, WM, WN, EPI_BIAS, WPS>(a, st);
+}
+
+template <int BM, int BN, int WM, int WN, bool KTAIL>
+static int launch_reg(const GemmArgs& a, hipStream_t st) {
+    constexpr int lds = 2 * (BM + BN) * GEMM_LD * 4;
+    static bool attr = false;
+    auto kern = gemm_f32_reg_kernel<BM, BN, WM, WN, KTAIL>;
+    if (int rc = set_lds(kern, lds, attr)) return rc;
+    GemmArgs g = a;
+    g.nbn = (a.N + BN - 1) / BN;
+    const int64_t nwg = ((a.M + BM - 1) / BM) * g.nbn;
+    AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm grid too large");
+    static const int tag = prof_tag_id("gemm_f32_reg_kernel<%d,%d,%d,%d,%s>", BM, BN, WM, WN, KTAIL ? "ktail" : "k32");
+    ProfScope prof(tag, 2.0 * (double)a.M * a.N * a.K, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, g);
+    AVD_CHECK_LAUNCH("gemm_f32_reg");
     return AVD_OK;
 }
 
 template <int BM, int BN, int WM, int WN>
-static int launch_gemm(const GemmArgs& a, hipStream_t st) {
-    if (a.K % GEMM_BK) return launch_gemm_epi<BM, BN, WM, WN, EPI_GENERIC, true>(a, st);
-    const bool plain = a.am.seg <= 0 && a.cm.seg <= 0 && (a.R == nullptr || a.rm.seg <= 0);
-    if (plain && a.act == AVD_ACT_NONE && a.R == nullptr) return launch_gemm_epi<BM, BN, WM, WN, EPI_BIAS, false>(a, st);
-    if (plain && a.act == AVD_ACT_GELU && a.R == nullptr) return launch_gemm_epi<BM, BN, WM, WN, EPI_GELU, false>(a, st);
-    if (plain && a.act == AVD_ACT_NONE && a.R != nullptr) return launch_gemm_epi<BM, BN, WM, WN, EPI_RES, false>(a, st);
-    return launch_gemm_epi<BM, BN, WM, WN, EPI_GENERIC, false>(a, st);
+static int launch_reg_k(const GemmArgs& a, hipStream_t st) {
+    return (a.K % GEMM_BK) ? launch_reg<BM, BN, WM, WN, true>(a, st) : launch_reg<BM, BN, WM, WN, false>(a, st);
 }
 
 int gemm_f32(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm,
@@ -252,17 +416,25 @@ int gemm_f32(const float* A, RowMap am, const float* W, const float* bias, const
     AVD_REQUIRE(act == AVD_ACT_NONE || act == AVD_ACT_GELU || act == AVD_ACT_SILU, AVD_EINVAL, "gemm: bad act %d", act);
     if (M == 0) return AVD_OK;
     GemmArgs g{A, am, W, bias, R, rm, C, cm, M, N, K, act, 0};
-    // tile choice: big square tiles when there is enough work to fill 256 CUs x 2 blocks, finer ones otherwise
+
     static const int force = getenv("AVD_GEMM_TILE") ? atoi(getenv("AVD_GEMM_TILE")) : -1;   // tuning/debug only
-    if (force == 0) return launch_gemm<128, 128, 64, 64>(g, st);
-    if (force == 1) return launch_gemm<128, 64, 64, 32>(g, st);
-    if (force == 2) return launch_gemm<64, 64, 32, 32>(g, st);
-    if (force == 3) return launch_gemm<128, 32, 32, 32>(g, st);
-    const int64_t big = ((M + 127) / 128) * ((N + 127) / 128);
-    if (N >= 128 && big >= 512) return launch_gemm<128, 128, 64, 64>(g, st);
-    if (N >= 64 && ((M + 127) / 128) * ((N + 63) / 64) >= 384) return launch_gemm<128, 64, 64, 32>(g, st);
-    if (N > 32) return launch_gemm<64, 64, 32, 32>(g, st);
-    return launch_gemm<128, 32, 32, 32>(g, st);
+    const bool dma_ok = K % GEMM_BK == 0 && N % 4 == 0 && N > 32 && cm.seg <= 0 && cm.ld % 4 == 0 && aligned16(C) &&
+                        (R == nullptr || (rm.seg <= 0 && rm.ld % 4 == 0 && aligned16(R))) &&
+                        (bias == nullptr || aligned16(bias)) && (act == AVD_ACT_NONE || act == AVD_ACT_GELU) &&
+                        !(R != nullptr && act != AVD_ACT_NONE) && force < 10;
+    const int64_t mb128 = (M + 127) / 128;
+    if (dma_ok) {
+        // 128x128 when it still gives >= 3 full rounds of 512 resident blocks; 128x64 (3 blocks/CU) for the
+        // N = 512 projections so the last round is not half empty; 64x64 for small problems
+        int tile = (N >= 128 && mb128 * ((N + 127) / 128) >= 1536) ? 0 : (mb128 * ((N + 63) / 64) >= 512) ? 1 : 2;
+        if (force >= 0 && force <= 2) tile = force;
+        if (tile == 0) return launch_dma_epi<128, 128, 64, 64, 2>(g, st);
+        if (tile == 1) return launch_dma_epi<128, 64, 64, 32, 2>(g, st);
+        return launch_dma_epi<64, 64, 32, 32, 4>(g, st);
+    }
+    if (N <= 32) return launch_reg_k<128, 32, 32, 32>(g, st);
+    if (N >= 128 && mb128 * ((N + 127) / 128) >= 512) return launch_reg_k<128, 128, 64, 64>(g, st);
+    return launch_reg_k<64, 64, 32, 32>(g, st);
 }
 
 }  // namespace avd

@@ -108,7 +108,8 @@ int rmsnorm_f32(const float* x, RowMap xm, const float* scale, float* y, RowMap 
     AVD_REQUIRE(xm.ld % 4 == 0 && ym.ld % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(scale), AVD_EUNSUPPORTED,
                 "rmsnorm: rows must be 16-byte aligned");
     if (rows == 0) return AVD_OK;
-    ProfScope prof(AVD_PROF_RMSNORM, 8.0 * (double)rows * d, st);
+    static const int tag = prof_tag_id("rmsnorm_kernel");
+    ProfScope prof(tag, 8.0 * (double)rows * d, st);
     const unsigned grid = (unsigned)((rows + 3) / 4);
     const float isd = (float)sqrt((double)d);   // the reference divides by math.sqrt(d) rounded to fp32
     switch (nv_for(d)) {
@@ -129,7 +130,8 @@ int layernorm_act_f32(const float* x, const float* gamma, const float* beta, flo
     AVD_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), AVD_EUNSUPPORTED,
                 "layernorm: pointers must be 16-byte aligned");
     if (rows == 0) return AVD_OK;
-    ProfScope prof(AVD_PROF_LAYERNORM, 8.0 * (double)rows * d, st);
+    static const int tag = prof_tag_id("layernorm_act_kernel");
+    ProfScope prof(tag, 8.0 * (double)rows * d, st);
     const unsigned grid = (unsigned)((rows + 3) / 4);
     switch (nv_for(d)) {
 #define AVD_CASE(NV) case NV: hipLaunchKernelGGL(layernorm_act_kernel<NV>, dim3(grid), dim3(256), 0, st, x, gamma, beta, y, rows, d, eps, act); break;

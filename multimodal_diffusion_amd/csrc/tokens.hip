@@ -90,7 +90,8 @@ int tube_patch_f32(const float* z, float* tok, int B, int C, int T, int H, int W
     Tube g;
     if (int rc = make_tube(g, C, T, H, W, t, h, w)) return rc;
     const int64_t total4 = (int64_t)B * (g.per >> 2);
-    ProfScope prof(AVD_PROF_TOKENS, 8.0 * (double)B * g.per, st);
+    static const int tag = prof_tag_id("tube_kernel<true>");
+    ProfScope prof(tag, 8.0 * (double)B * g.per, st);
     hipLaunchKernelGGL(tube_kernel<true>, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, z, tok, g, total4);
     AVD_CHECK_LAUNCH("tube_patch");
     return AVD_OK;
@@ -266,7 +267,8 @@ int cfg_unpatch_ddim_f32(const float* eps2, const float* z, const int64_t* t_now
     Tube g;
     if (int rc = make_tube(g, C, T, H, W, t, h, w)) return rc;
     const int64_t total4 = (int64_t)B * (g.per >> 2);
-    ProfScope prof(AVD_PROF_CFG_DDIM, 16.0 * (double)B * g.per, st);
+    static const int tag = prof_tag_id("cfg_unpatch_ddim_kernel");
+    ProfScope prof(tag, 16.0 * (double)B * g.per, st);
     hipLaunchKernelGGL(cfg_unpatch_ddim_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, eps2, z, t_now,
                        t_prev, abar, T_train, guidance, eta, noise, z_out, g, B, total4);
     AVD_CHECK_LAUNCH("cfg_unpatch_ddim");
@@ -358,7 +360,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(float* __restrict__ X2, c
 int assemble_f32(float* X2, const float* temb, const float* Xp, int B, int N, int d, int tdim, int Nt, int Np,
                  int target_first, hipStream_t st) {
     const int64_t total4 = (int64_t)2 * B * N * (d >> 2);
-    ProfScope prof(AVD_PROF_TOKENS, 4.0 * (2.0 * B * N * d + (double)B * Nt * (d - tdim) + (double)B * Np * d), st);
+    static const int tag = prof_tag_id("assemble_kernel");
+    ProfScope prof(tag, 4.0 * (2.0 * B * N * d + (double)B * Nt * (d - tdim) + (double)B * Np * d), st);
     hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, X2, temb, Xp, B, N, d,
                        tdim, Nt, Np, target_first, total4);
     AVD_CHECK_LAUNCH("assemble");

@@ -111,6 +111,171 @@ void run(const char* name, const float* A, const float* W, float* C, int M, int 
 }
 
 #include "../../include/avdiff_hip.h"
+#include <math.h>
+
+// ---------------------------------------------------------------------------------------------------------
+// kd: LDS-DMA (global_load_lds_dwordx4) staged main loop, XOR-swizzled unpadded LDS image, optional
+// LDS-staged float4 epilogue.  EPI: 0 = scalar stores (as k), 1 = via LDS, float4 stores + bias
+// ---------------------------------------------------------------------------------------------------------
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+template <int BM, int BN, int WM, int WN, int EPI, int WPS>
+__global__ __launch_bounds__(256, WPS) void kd(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
+                                              float* __restrict__ C, int M, int N, int K, int nbn) {
+    constexpr int BK = 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_PIECES = BM / 8 / 4, B_PIECES = BN / 8 / 4;     // 1-KiB pieces (8 rows) per wave
+    constexpr int STAGE = (BM + BN) * BK;                            // floats per stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nwg = gridDim.x;
+    int wg;
+    { const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7; wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3); }
+    const int bm = wg / nbn, bn = wg % nbn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    // staging: piece p covers tile rows 8p..8p+7; lane -> row 8p + lane/8, PHYSICAL chunk lane%8, logical chunk = phys ^ ((row>>1)&7)
+    const int r8 = lane >> 3, pc = lane & 7;
+    const float* a_src[A_PIECES]; const float* b_src[B_PIECES];
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+        const int trow = (wave + 4 * i) * 8 + r8;
+        int row = bm * BM + trow; row = row < M ? row : M - 1;
+        a_src[i] = A + (size_t)row * K + ((pc ^ ((trow >> 1) & 7)) << 2);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) {
+        const int trow = (wave + 4 * i) * 8 + r8;
+        int n = bn * BN + trow; n = n < N ? n : N - 1;
+        b_src[i] = W + (size_t)n * K + ((pc ^ ((trow >> 1) & 7)) << 2);
+    }
+    auto stage = [&](int kt, int buf) {
+        float* as = smem + buf * STAGE;
+        float* bs = as + BM * BK;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[i] + k0), LDS_PTR(as + (wave + 4 * i) * 8 * BK), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[i] + k0), LDS_PTR(bs + (wave + 4 * i) * 8 * BK), 16, 0, 0);
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = K / BK;
+    stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+    __syncthreads();
+    // fragment read offsets (floats): row*32 + ((2kk+hi) ^ ((row>>1)&7))*4
+    int a_row[TM], a_sw[TM], b_row[TN], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { const int r = wm * WM + i * 32 + l31; a_row[i] = r * BK; a_sw[i] = (r >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { const int r = wn * WN + j * 32 + l31; b_row[j] = r * BK; b_sw[j] = (r >> 1) & 7; }
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const float* as = smem + cur * STAGE;
+        const float* bs = as + BM * BK;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + a_row[i] + (((2 * kk + hi) ^ a_sw[i]) << 2));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + b_row[j] + (((2 * kk + hi) ^ b_sw[j]) << 2));
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): next stage landed
+        __syncthreads();
+    }
+    if (EPI == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = bn * BN + wn * WN + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = bm * BM + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (m < M && n < N) C[(size_t)m * N + n] = acc[i][j][r];
+                }
+            }
+    } else {
+        // each wave parks its WM x WN tile in its own LDS slab [WM][WN+4], then streams it out as float4 rows
+        constexpr int CLD = WN + 4;
+        float* slab = smem + wave * WM * CLD;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    slab[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * CLD + j * 32 + l31] = acc[i][j][r];
+        __syncthreads();
+        constexpr int LPR = WN / 4;              // lanes per row
+        constexpr int RPI = 64 / LPR;            // rows per wave-instruction
+        const int cr = lane / LPR, cc = (lane % LPR) * 4;
+        const int n = bn * BN + wn * WN + cc;
+        const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + n);
+        const int mbase = bm * BM + wm * WM + cr;
+#pragma unroll
+        for (int it = 0; it < WM / RPI; ++it) {
+            const int m = mbase + it * RPI;
+            f32x4 v = *reinterpret_cast<const f32x4*>(slab + (cr + it * RPI) * CLD + cc);
+            v += bv;
+            if (m < M) *reinterpret_cast<f32x4*>(C + (size_t)m * N + n) = v;
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int WPS>
+void rund(const char* name, const float* A, const float* W, float* C, int M, int N, int K) {
+    int lds = 2 * (BM + BN) * 32 * 4;
+    const int epi_lds = 4 * WM * (WN + 4) * 4;
+    if (EPI && epi_lds > lds) lds = epi_lds;
+    auto kern = kd<BM, BN, WM, WN, EPI, WPS>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) kern<<<nbm * nbn, 256, lds>>>(A, W, W, C, M, N, K, nbn);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    const int it = 20;
+    for (int i = 0; i < it; ++i) kern<<<nbm * nbn, 256, lds>>>(A, W, W, C, M, N, K, nbn);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
+    printf("%-36s M=%d N=%d K=%d lds=%d: %8.1f us %7.1f TF\n", name, M, N, K, lds, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
+}
+
+// correctness of kd against the library GEMM (bias = W's first row values)
+static void check(const float* A, const float* W, float* C, float* C2, int M, int N, int K) {
+    auto kern = kd<128, 128, 64, 64, 1, 2>;
+    const int lds = 4 * 64 * 68 * 4;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int nbm = (M + 127) / 128, nbn = (N + 127) / 128;
+    kern<<<nbm * nbn, 256, lds>>>(A, W, W, C, M, N, K, nbn);
+    if (avd_gemm_bias_act_f32(A, K, W, W, nullptr, N, C2, N, M, N, K, 0, nullptr)) { printf("lib err\n"); exit(1); }
+    CK(hipDeviceSynchronize());
+    std::vector<float> a((size_t)M * N), b((size_t)M * N);
+    CK(hipMemcpy(a.data(), C, a.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(b.data(), C2, b.size() * 4, hipMemcpyDeviceToHost));
+    double md = 0; size_t bad = 0;
+    for (size_t i = 0; i < a.size(); ++i) { double d = fabs((double)a[i] - b[i]); if (d > md) md = d; if (d > 1e-3) ++bad; }
+    printf("kd(glds, lds-epilogue) vs library: max|diff| = %.3g, mismatches = %zu of %zu\n", md, bad, a.size());
+}
+
 static void run_lib(const char* name, const float* A, const float* W, const float* bias, const float* R, float* C, int M, int N, int K, int act) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int i = 0; i < 5; ++i) if (avd_gemm_bias_act_f32(A, K, W, bias, R, N, C, N, M, N, K, act, nullptr)) { printf("lib error %s\n", avd_last_error()); exit(1); }
@@ -126,12 +291,13 @@ static void run_lib(const char* name, const float* A, const float* W, const floa
 int main(int argc, char** argv) {
     const int M = 26944;
     const size_t maxe = (size_t)M * 2048;
-    float *A, *W, *C;
-    CK(hipMalloc(&A, maxe * 4)); CK(hipMalloc(&W, 2048 * 2048 * 4)); CK(hipMalloc(&C, maxe * 4));
+    float *A, *W, *C, *C2;
+    CK(hipMalloc(&A, maxe * 4)); CK(hipMalloc(&W, 2048 * 2048 * 4)); CK(hipMalloc(&C, maxe * 4)); CK(hipMalloc(&C2, maxe * 4));
     std::vector<float> h(maxe);
     for (size_t i = 0; i < maxe; ++i) h[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
     CK(hipMemcpy(A, h.data(), maxe * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(W, h.data(), 2048 * 2048 * 4, hipMemcpyHostToDevice));
+    check(A, W, C, C2, 26944 - 57, 1536, 512);
     // clock ramp: ~0.5 s of sustained MFMA work before anything is timed (first-run kernels read 15-20 % low)
     for (int i = 0; i < 1000; ++i) avd_gemm_bias_act_f32(A, 512, W, W, nullptr, 1536, C, 1536, M, 1536, 512, 0, nullptr);
     CK(hipDeviceSynchronize());
@@ -142,6 +308,10 @@ int main(int argc, char** argv) {
         run_lib("LIB bias+res (R=A)", A, W, W, A, C, M, N, K, 0);
         run_lib("LIB bias+res in-place", A, W, W, C, C, M, N, K, 0);
         run<128, 128, 64, 64, 32, 0, 2>("128x128 bk32 v0 prod", A, W, C, M, N, K);
+        rund<128, 128, 64, 64, 0, 2>("GLDS 128x128 scalar-epi", A, W, C, M, N, K);
+        rund<128, 128, 64, 64, 1, 2>("GLDS 128x128 lds-epi+bias", A, W, C, M, N, K);
+        rund<128, 64, 64, 32, 1, 2>("GLDS 128x64 lds-epi+bias", A, W, C, M, N, K);
+        rund<64, 64, 32, 32, 1, 4>("GLDS 64x64 lds-epi+bias", A, W, C, M, N, K);
         run<128, 128, 64, 64, 32, 1, 2>("128x128 bk32 v1 no-gload", A, W, C, M, N, K);
         run<128, 128, 64, 64, 32, 2, 2>("128x128 bk32 v2 no-gload,no-lds-wr", A, W, C, M, N, K);
         run<128, 128, 64, 64, 32, 3, 2>("128x128 bk32 v3 mfma+ldsrd only", A, W, C, M, N, K);
