@@ -1,0 +1,52 @@
+"""World-size-2 gloo run (CPU) of the multi-GPU plumbing: one broadcast of the conditioning latents from rank 0,
+contiguous batch shards, max-over-ranks timing.  The per-rank compute itself is covered by the GPU tests; here the
+'step' is a stand-in so the test exercises exactly the collective layout bench.py uses."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from multimodal_diffusion_amd import dist as D
+    r, w, _ = D.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    B = 3                                                    # per-rank batch
+    gshape = (B * world, 8, 150)
+    cond = torch.randn(gshape, generator=torch.Generator().manual_seed(2)) if rank == 0 else None
+    full = D.broadcast_conditioning(cond, gshape, torch.device("cpu"))
+    mine = D.local_conditioning(full, rank, world)
+    expect = torch.randn(gshape, generator=torch.Generator().manual_seed(2))
+    lo, hi = D.shard_range(B * world, rank, world)
+    ok = torch.equal(full, expect) and torch.equal(mine, expect[lo:hi]) and mine.shape[0] == B
+    slow = D.max_over_ranks(1.0 + rank, torch.device("cpu"))
+    D.barrier()
+    out.put((rank, bool(ok), slow))
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_shard_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True, 2.0), (1, True, 2.0)]
