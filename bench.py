@@ -95,6 +95,7 @@ def main():
     ap.add_argument("--sampler-steps", type=int, default=50)
     ap.add_argument("--guidance", type=float, default=3.5)
     ap.add_argument("--graph", action="store_true", help="replay a captured 2-step HIP graph instead of eager launches")
+    ap.add_argument("--split-streams", type=int, default=0, help="run the cond/null halves on two HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -126,7 +127,8 @@ def main():
     z0 = torch.randn(lat, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
 
     eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=tdim, target="video",
-                          latent_shape=lat, prompt_tokens=na, alpha_bar=abar, guidance=args.guidance)
+                          latent_shape=lat, prompt_tokens=na, alpha_bar=abar, guidance=args.guidance,
+                          split_streams=bool(args.split_streams))
     eng.set_prompt(z_a0)
     eng.begin(sched)
     za, zb = z0.clone(), torch.empty_like(z0)

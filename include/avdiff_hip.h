@@ -201,6 +201,8 @@ typedef struct {                       /* one whole CFG denoising step (sample_c
     const float* adapt_w; const float* adapt_b;   /* target adapter */
     const float* alpha_bar; int T_train;
     float guidance, eta;
+    int split_streams;   /* !=0: run the cond and null CFG halves as two kernel chains on two streams (fork/join by events;
+                            graph-capturable); results are bit-identical to the single-stream order */
 } avd_step_desc;
 int64_t avd_step_workspace_bytes(const avd_step_desc* s);
 /* z_out = DDIM(z, eps_cfg(z, Xp, t_now), t_now -> t_prev).  z_out must not alias z. */

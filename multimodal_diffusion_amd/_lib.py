@@ -54,7 +54,7 @@ class HeadWeights(C.Structure):
 class StepDesc(C.Structure):
     _fields_ = [("embed", EmbedDesc), ("core", C.POINTER(CoreWeights)), ("head", C.POINTER(HeadWeights)),
                 ("adapt_w", C.c_void_p), ("adapt_b", C.c_void_p), ("alpha_bar", C.c_void_p), ("T_train", C.c_int),
-                ("guidance", C.c_float), ("eta", C.c_float)]
+                ("guidance", C.c_float), ("eta", C.c_float), ("split_streams", C.c_int)]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float

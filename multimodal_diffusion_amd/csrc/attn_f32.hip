@@ -12,33 +12,36 @@
 //    kappa(s,half)) is used directly as the B operand of step s of O^T = V^T·P^T — P never moves between
 //    lanes or through LDS; V is read from LDS row kappa(s,half), 32 consecutive floats per half-wave
 //    (conflict-free ds_read_b32).
-//  * K fragments are ds_read_b128 from [key][64+4]-padded rows (conflict-free), four MFMA steps per read.
-//  * K/V tiles are register-prefetched (global loads issued before the tile's MFMAs) into a single LDS
-//    buffer; 2 waves/SIMD co-reside so one wave's softmax VALU work hides under its partner's MFMAs.
+//  * K/V tiles go global -> LDS directly (global_load_lds_dwordx4: 4 rows x 256 B per wave instruction, no VGPR
+//    staging).  K is stored unpadded with its 16-byte chunks XOR-swizzled by (key & 15) — applied on the per-lane
+//    source address and again on the ds_read_b128 fragment read — so 16 distinct key rows hit 16 distinct slots.
+//  * one LDS buffer per operand, but the loads overlap compute by phase: the S phase reads only K, so V's next
+//    tile flies under it; the softmax + PV phase reads only V, so K's next tile flies under that.
+//    Two barriers per tile, each preceded by a vmcnt(0) for DMA issued a whole phase earlier.
 #include "avd_common.h"
 
 namespace avd {
 
 constexpr int ATT_DH = 64;
 constexpr int ATT_KT = 64;            // keys per tile
-constexpr int ATT_KLD = ATT_DH + 4;   // padded K row
-constexpr int ATT_VLD = ATT_DH;
 constexpr float ATT_NEG = -1.0e30f;
 constexpr float LOG2E = 1.4426950408889634f;
+
+#define AVD_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define AVD_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                               int N, int H, float scale, int n_query) {
-    constexpr int NT = NW * 64;
-    constexpr int CH = ATT_KT * (ATT_DH / 4) / NT;   // float4 chunks per thread per matrix
-    __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * ATT_KLD];
-    __shared__ __attribute__((aligned(16))) float Vs[ATT_KT * ATT_VLD];
+    constexpr int PPW = 16 / NW;       // 1-KiB DMA pieces (4 key rows) per wave per operand per tile
+    __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * ATT_DH];
+    __shared__ __attribute__((aligned(16))) float Vs[ATT_KT * ATT_DH];
 
     const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int d = H * ATT_DH;
-    const int64_t rs = 3 * (int64_t)d;
+    const int rs = 3 * d;
     const float* base = qkv + (int64_t)b * N * rs + h * ATT_DH;
     const float* kp = base + d;
     const float* vp = base + 2 * d;
@@ -59,29 +62,27 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_f32_kernel(const float* __res
         }
     }
 
-    f32x4 rk[CH], rv[CH];
-    auto load_tile = [&](int kt) {
+    // ---- DMA: piece p = key rows 4p..4p+3 of the tile; lane -> row 4p + lane/16, PHYSICAL 16-byte chunk lane%16 ----
+    const int r4 = lane >> 4, pc = lane & 15;
+    auto dma_k = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int c = tid + i * NT;
-            const int key = kt * ATT_KT + (c >> 4);
-            const int col = (c & 15) * 4;
-            if (key < N) {
-                rk[i] = *reinterpret_cast<const f32x4*>(kp + (int64_t)key * rs + col);
-                rv[i] = *reinterpret_cast<const f32x4*>(vp + (int64_t)key * rs + col);
-            } else {
-                rk[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                rv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + NW * i;
+            const int kl = p * 4 + r4;
+            int key = kt * ATT_KT + kl;
+            key = key < N ? key : N - 1;                       // ragged tail: finite filler, masked below
+            const float* src = kp + key * rs + ((pc ^ (kl & 15)) << 2);
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(src), AVD_LDS_PTR(Ks + p * 4 * ATT_DH), 16, 0, 0);
         }
     };
-    auto store_tile = [&]() {
+    auto dma_v = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const int c = tid + i * NT;
-            const int kl = c >> 4, col = (c & 15) * 4;
-            *reinterpret_cast<f32x4*>(&Ks[kl * ATT_KLD + col]) = rk[i];
-            *reinterpret_cast<f32x4*>(&Vs[kl * ATT_VLD + col]) = rv[i];
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + NW * i;
+            int key = kt * ATT_KT + p * 4 + r4;
+            key = key < N ? key : N - 1;
+            const float* src = vp + key * rs + (pc << 2);
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(src), AVD_LDS_PTR(Vs + p * 4 * ATT_DH), 16, 0, 0);
         }
     };
 
@@ -91,29 +92,36 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_f32_kernel(const float* __res
     float m_run = ATT_NEG, l_run = 0.f;
 
     const int nkt = (N + ATT_KT - 1) / ATT_KT;
-    load_tile(0);
-    store_tile();
+    dma_k(0);
+    dma_v(0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
     __syncthreads();
 
-    const int k_rd = l31 * ATT_KLD + 32 * hi;
+    const int ksw = l31 & 15;
+    const int k_rd0 = l31 * ATT_DH, k_rd1 = (32 + l31) * ATT_DH;
     for (int kt = 0; kt < nkt; ++kt) {
         const bool more = (kt + 1) < nkt;
-        if (more) load_tile(kt + 1);
 
-        // ---- S^T = K·Q^T for keys [0,32) and [32,64) of the tile ----
+        // ---- S^T = K·Q^T for keys [0,32) and [32,64) of the tile (reads Ks only) ----
         f32x16 s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const f32x4 ka = *reinterpret_cast<const f32x4*>(&Ks[k_rd + 4 * c]);
-            const f32x4 kb = *reinterpret_cast<const f32x4*>(&Ks[k_rd + 32 * ATT_KLD + 4 * c]);
+            const int ph = ((8 * hi + c) ^ ksw) << 2;
+            const f32x4 ka = *reinterpret_cast<const f32x4*>(&Ks[k_rd0 + ph]);
+            const f32x4 kb = *reinterpret_cast<const f32x4*>(&Ks[k_rd1 + ph]);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[j], qf[4 * c + j], s0, 0, 0, 0);
                 s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[j], qf[4 * c + j], s1, 0, 0, 0);
             }
         }
+        // K is free once every wave is here; V(kt) (issued a phase ago) has landed after the wait
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        if (more) dma_k(kt + 1);
+
         if (!more && (N & (ATT_KT - 1))) {   // ragged last tile: keys >= N contribute nothing
             const int kbase = kt * ATT_KT;
 #pragma unroll
@@ -145,25 +153,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_f32_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
 
-        // ---- O^T += V^T · P^T ; step s consumes key row kappa(s,hi) of each 32-key half ----
+        // ---- O^T += V^T · P^T ; step s consumes key row kappa(s,hi) of each 32-key half (reads Vs only) ----
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int kr = mfma32_row(s, hi);
-            const float va0 = Vs[kr * ATT_VLD + l31];
-            const float va1 = Vs[kr * ATT_VLD + 32 + l31];
-            const float vb0 = Vs[(32 + kr) * ATT_VLD + l31];
-            const float vb1 = Vs[(32 + kr) * ATT_VLD + 32 + l31];
+            const float va0 = Vs[kr * ATT_DH + l31];
+            const float va1 = Vs[kr * ATT_DH + 32 + l31];
+            const float vb0 = Vs[(32 + kr) * ATT_DH + l31];
+            const float vb1 = Vs[(32 + kr) * ATT_DH + 32 + l31];
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, s0[s], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, s0[s], o1, 0, 0, 0);
             o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb0, s1[s], o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb1, s1[s], o1, 0, 0, 0);
         }
-
+        // V is free once every wave is here; K(kt+1) has landed after the wait
+        __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
-        if (more) {
-            store_tile();
-            __syncthreads();
-        }
+        if (more) dma_v(kt + 1);
     }
 
     // ---- normalise and store: lane (q, hi) holds O[q][8*g + 4*hi + (0..3)] in regs 4g..4g+3 ----
@@ -188,6 +194,7 @@ int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float sc
     AVD_REQUIRE(n_query >= 0 && n_query <= N, AVD_EINVAL, "attn: n_query=%d outside [0,%d]", n_query, N);
     AVD_REQUIRE(aligned16(qkv) && aligned16(out), AVD_EUNSUPPORTED, "attn: pointers must be 16-byte aligned");
     AVD_REQUIRE(H <= 65535 && B <= 65535, AVD_EUNSUPPORTED, "attn: grid too large");
+    AVD_REQUIRE((int64_t)N * 3 * H * Dh < (1ll << 31), AVD_EUNSUPPORTED, "attn: one sample's qkv exceeds 2^31 elements");
     if (n_query == 0) return AVD_OK;
     // 2-wave blocks (64 query rows) waste the fewest padded rows on the ragged N of this model
     // (421 -> 448); 4-wave blocks halve K/V re-reads when N is a comfortable multiple of 128.

@@ -193,6 +193,22 @@ static int embed_cfg_pair(const avd_embed_desc* e, const float* z, const float* 
 }
 
 // ---------------------------------------------------------------- one CFG denoising step
+#define AVD_HIP(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess) return set_error(AVD_ELAUNCH, "%s: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+static hipStream_t g_aux = nullptr;
+static hipEvent_t g_fork = nullptr, g_join = nullptr;
+static int ensure_aux() {
+    if (g_aux) return AVD_OK;
+    AVD_HIP(hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking));
+    AVD_HIP(hipEventCreateWithFlags(&g_fork, hipEventDisableTiming));
+    AVD_HIP(hipEventCreateWithFlags(&g_join, hipEventDisableTiming));
+    return AVD_OK;
+}
+
 struct StepPlan {
     int64_t x2, tok, core, head, eps, total;
     int N, D;
@@ -210,8 +226,8 @@ static int plan_step(const avd_step_desc* s, StepPlan& p) {
     p.rows = (int64_t)2 * e.B * e.Nt;
     p.x2 = align_up((int64_t)2 * e.B * p.N * e.d * 4);
     p.tok = align_up(embed_ws_floats(&e) * 4);
-    p.core = core_ws_bytes(s->core, (int64_t)2 * e.B * p.N);
-    p.head = head_ws_bytes(s->head, p.rows);
+    p.core = 2 * core_ws_bytes(s->core, (int64_t)e.B * p.N);     // one slice per CFG half (they may run on two streams)
+    p.head = 2 * head_ws_bytes(s->head, p.rows / 2);
     p.eps = align_up(p.rows * p.D * 4);
     p.total = p.x2 + p.tok + p.core + p.head + p.eps;
     return AVD_OK;
@@ -290,10 +306,29 @@ extern "C" int avd_denoise_step_f32(const avd_step_desc* s, const float* z, cons
 
     if (int rc = embed_cfg_pair(&e, z, s->adapt_w, s->adapt_b, t_now, Xp, tok, X2, st)) return rc;
     const int row0 = e.target_first ? 0 : e.Np;
-    if (int rc = core_forward(s->core, X2, X2, 2 * e.B, p.N, row0, e.Nt, core_ws, p.core, st)) return rc;
     // head over the target rows only (per-token independent, so skipping prompt rows is exact)
     const RowMap hm{e.d, e.Nt, (int64_t)p.N * e.d};
-    if (int rc = head_forward(s->head, X2 + (int64_t)row0 * e.d, hm, p.rows, eps2, head_ws, p.head, st)) return rc;
+    if (!s->split_streams) {
+        if (int rc = core_forward(s->core, X2, X2, 2 * e.B, p.N, row0, e.Nt, core_ws, p.core, st)) return rc;
+        if (int rc = head_forward(s->head, X2 + (int64_t)row0 * e.d, hm, p.rows, eps2, head_ws, p.head, st)) return rc;
+    } else {
+        // the cond and null halves are independent until the CFG combine: run them as two kernel chains on two
+        // streams so one chain's partially-filled last rounds overlap the other chain's kernels
+        if (int rc = ensure_aux()) return rc;
+        const int64_t half_rows = (int64_t)e.B * p.N * e.d;
+        const int64_t hc = p.core / 2, hh = p.head / 2;
+        AVD_HIP(hipEventRecord(g_fork, st));
+        AVD_HIP(hipStreamWaitEvent(g_aux, g_fork, 0));
+        for (int half = 0; half < 2; ++half) {
+            hipStream_t hs = half ? g_aux : st;
+            float* xh = X2 + half * half_rows;
+            if (int rc = core_forward(s->core, xh, xh, e.B, p.N, row0, e.Nt, static_cast<char*>(core_ws) + half * hc, hc, hs)) return rc;
+            if (int rc = head_forward(s->head, xh + (int64_t)row0 * e.d, hm, p.rows / 2, eps2 + half * (p.rows / 2) * p.D,
+                                      static_cast<char*>(head_ws) + half * hh, hh, hs)) return rc;
+        }
+        AVD_HIP(hipEventRecord(g_join, g_aux));
+        AVD_HIP(hipStreamWaitEvent(st, g_join, 0));
+    }
     if (e.target_kind == 0)
         return cfg_unpatch_ddim_f32(eps2, z, t_now, t_prev, s->alpha_bar, s->T_train, s->guidance, s->eta, noise, z_out,
                                     e.B, e.C, e.T, e.H, e.W, e.p0, e.p1, e.p2, st);

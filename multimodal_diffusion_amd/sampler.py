@@ -96,7 +96,7 @@ class DenoiseEngine:
 
     def __init__(self, *, adapt_v: LinearAdapter, adapt_a: LinearAdapter, core: MMDiT, head: MultiModalNoiseHead,
                  tstep_dim: int, target: str, latent_shape: Tuple[int, ...], prompt_tokens: int, alpha_bar: torch.Tensor,
-                 guidance: float, eta: float = 0.0, tube=(2, 4, 4), chunk=(4, 4)):
+                 guidance: float, eta: float = 0.0, tube=(2, 4, 4), chunk=(4, 4), split_streams: bool = False):
         if target not in ("video", "audio"):
             raise ValueError("target must be 'video' or 'audio'")
         if eta < 0:
@@ -149,6 +149,7 @@ class DenoiseEngine:
         s.adapt_w, s.adapt_b = self._aw.data_ptr(), self._ab.data_ptr()
         s.alpha_bar, s.T_train = self.alpha_bar.data_ptr(), self.alpha_bar.numel()
         s.guidance, s.eta = self.guidance, self.eta
+        s.split_streams = 1 if split_streams else 0
         self.desc = s
         need = L.lib().avd_step_workspace_bytes(C.byref(s))
         if need < 0:

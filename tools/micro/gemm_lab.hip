@@ -120,7 +120,7 @@ void run(const char* name, const float* A, const float* W, float* C, int M, int 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-template <int BM, int BN, int WM, int WN, int EPI, int WPS>
+template <int BM, int BN, int WM, int WN, int EPI, int WPS, int ILV = 0>
 __global__ __launch_bounds__(256, WPS) void kd(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
                                               float* __restrict__ C, int M, int N, int K, int nbn) {
     constexpr int BK = 32;
@@ -180,9 +180,13 @@ __global__ __launch_bounds__(256, WPS) void kd(const float* __restrict__ A, cons
     for (int j = 0; j < TN; ++j) { const int r = wn * WN + j * 32 + l31; b_row[j] = r * BK; b_sw[j] = (r >> 1) & 7; }
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const bool more = kt + 1 < nk;
+        if (ILV == 0 && more) stage(kt + 1, cur ^ 1);
         const float* as = smem + cur * STAGE;
         const float* bs = as + BM * BK;
+        float* nas = smem + (cur ^ 1) * STAGE;
+        float* nbs = nas + BM * BK;
+        const int k1 = (kt + 1) * BK;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             f32x4 af[TM], bf[TN];
@@ -191,11 +195,20 @@ __global__ __launch_bounds__(256, WPS) void kd(const float* __restrict__ A, cons
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + b_row[j] + (((2 * kk + hi) ^ b_sw[j]) << 2));
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+                if (ILV == 1 && more) {
+                    // one DMA piece after each MFMA group of the first kk steps: its issue hides under the matrix pipe
+                    const int pi = kk * 4 + s;
+                    if (pi < A_PIECES)
+                        __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[pi] + k1), LDS_PTR(nas + (wave + 4 * pi) * 8 * BK), 16, 0, 0);
+                    else if (pi < A_PIECES + B_PIECES)
+                        __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[pi - A_PIECES] + k1), LDS_PTR(nbs + (wave + 4 * (pi - A_PIECES)) * 8 * BK), 16, 0, 0);
+                }
+            }
         }
         __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): next stage landed
         __syncthreads();
@@ -240,12 +253,12 @@ __global__ __launch_bounds__(256, WPS) void kd(const float* __restrict__ A, cons
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int WPS>
+template <int BM, int BN, int WM, int WN, int EPI, int WPS, int ILV = 0>
 void rund(const char* name, const float* A, const float* W, float* C, int M, int N, int K) {
     int lds = 2 * (BM + BN) * 32 * 4;
     const int epi_lds = 4 * WM * (WN + 4) * 4;
     if (EPI && epi_lds > lds) lds = epi_lds;
-    auto kern = kd<BM, BN, WM, WN, EPI, WPS>;
+    auto kern = kd<BM, BN, WM, WN, EPI, WPS, ILV>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -310,6 +323,8 @@ int main(int argc, char** argv) {
         run<128, 128, 64, 64, 32, 0, 2>("128x128 bk32 v0 prod", A, W, C, M, N, K);
         rund<128, 128, 64, 64, 0, 2>("GLDS 128x128 scalar-epi", A, W, C, M, N, K);
         rund<128, 128, 64, 64, 1, 2>("GLDS 128x128 lds-epi+bias", A, W, C, M, N, K);
+        rund<128, 128, 64, 64, 1, 2, 1>("GLDS 128x128 lds-epi ILV", A, W, C, M, N, K);
+        rund<128, 64, 64, 32, 1, 2, 1>("GLDS 128x64 lds-epi ILV", A, W, C, M, N, K);
         rund<128, 64, 64, 32, 1, 2>("GLDS 128x64 lds-epi+bias", A, W, C, M, N, K);
         rund<64, 64, 32, 32, 1, 4>("GLDS 64x64 lds-epi+bias", A, W, C, M, N, K);
         run<128, 128, 64, 64, 32, 1, 2>("128x128 bk32 v1 no-gload", A, W, C, M, N, K);
