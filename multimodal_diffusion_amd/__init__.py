@@ -4,7 +4,8 @@ Host-side mirrors of the reference's Python interface for this path; all compute
 gfx950 behind the C ABI in ``include/avdiff_hip.h`` (``multimodal_diffusion_amd/csrc`` → ``libavdiff_hip.so``).
 There is no CPU or eager-PyTorch fallback: CPU tensors or a missing library raise.
 """
-from . import ops, schedule_utils, schedules           # noqa: F401
+from . import adapters, ops, schedule_utils, schedules   # noqa: F401
+from .adapters import TimestepCfg, TimestepEmbedder      # noqa: F401
 from .mmdt import MMDiT, Block, MHA, MLP, RMSNorm      # noqa: F401
 from .noise_heads import MultiModalNoiseHead           # noqa: F401
 from .sampler import (DenoiseEngine, LinearAdapter, add_sinusoidal_timestep, build_components,   # noqa: F401

@@ -32,12 +32,21 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 2) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                              int N, int H, float scale, int n_query) {
+                                                              int N, int H, float scale, int n_query, int nqb) {
     constexpr int PPW = 16 / NW;       // 1-KiB DMA pieces (4 key rows) per wave per operand per tile
     __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * ATT_DH];
     __shared__ __attribute__((aligned(16))) float Vs[ATT_KT * ATT_DH];
 
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // 1-D grid, XCD-aware: hardware deals consecutive block ids round-robin over the 8 XCDs; remap so each XCD gets a
+    // contiguous range of work ids, i.e. the q-blocks of one (batch, head) — which re-read the same K/V — share an L2.
+    int qb, h, b;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = id & 7;
+        const int w = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+        qb = w % nqb;
+        h = (w / nqb) % H;
+        b = w / (nqb * H);
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int d = H * ATT_DH;
@@ -64,6 +73,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_f32_kernel(const float* __res
 
     // ---- DMA: piece p = key rows 4p..4p+3 of the tile; lane -> row 4p + lane/16, PHYSICAL 16-byte chunk lane%16 ----
     const int r4 = lane >> 4, pc = lane & 15;
+    // (keep these unrolled: a rolled loop serialises the DMA issue and measured 25 % slower)
     auto dma_k = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
@@ -193,7 +203,7 @@ int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float sc
     AVD_REQUIRE(Dh == ATT_DH, AVD_EUNSUPPORTED, "attn: head_dim %d unsupported (kernel is built for 64)", Dh);
     AVD_REQUIRE(n_query >= 0 && n_query <= N, AVD_EINVAL, "attn: n_query=%d outside [0,%d]", n_query, N);
     AVD_REQUIRE(aligned16(qkv) && aligned16(out), AVD_EUNSUPPORTED, "attn: pointers must be 16-byte aligned");
-    AVD_REQUIRE(H <= 65535 && B <= 65535, AVD_EUNSUPPORTED, "attn: grid too large");
+    AVD_REQUIRE((int64_t)B * H * ((N + 63) / 64) < (1ll << 31), AVD_EUNSUPPORTED, "attn: grid too large");
     AVD_REQUIRE((int64_t)N * 3 * H * Dh < (1ll << 31), AVD_EUNSUPPORTED, "attn: one sample's qkv exceeds 2^31 elements");
     if (n_query == 0) return AVD_OK;
     // 2-wave blocks (64 query rows) waste the fewest padded rows on the ragged N of this model
@@ -202,9 +212,9 @@ int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float sc
     static const int tag4 = prof_tag_id("attn_f32_kernel<4>"), tag2 = prof_tag_id("attn_f32_kernel<2>");
     ProfScope prof(pad4 == pad2 ? tag4 : tag2, 4.0 * (double)B * H * (double)n_query * N * ATT_DH, st);
     if (pad4 == pad2) {
-        hipLaunchKernelGGL(attn_f32_kernel<4>, dim3(pad4 / 128, H, B), dim3(256), 0, st, qkv, out, N, H, scale, n_query);
+        hipLaunchKernelGGL(attn_f32_kernel<4>, dim3((pad4 / 128) * H * B), dim3(256), 0, st, qkv, out, N, H, scale, n_query, pad4 / 128);
     } else {
-        hipLaunchKernelGGL(attn_f32_kernel<2>, dim3(pad2 / 64, H, B), dim3(128), 0, st, qkv, out, N, H, scale, n_query);
+        hipLaunchKernelGGL(attn_f32_kernel<2>, dim3((pad2 / 64) * H * B), dim3(128), 0, st, qkv, out, N, H, scale, n_query, pad2 / 64);
     }
     AVD_CHECK_LAUNCH("attn_f32");
     return AVD_OK;

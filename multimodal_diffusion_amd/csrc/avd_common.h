@@ -50,7 +50,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
     const float er = copysignf(1.0f - p * e, z);
     return 0.5f * x * (1.0f + er);
 }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
 
 template <int ACT>
 __device__ __forceinline__ float apply_act(float x) {

@@ -400,6 +400,19 @@ def test_bench_size_properties(dev, full):
     assert rel_err(su.ddim_step(z, tn, tp, lat, abar).cpu(), c.cpu()) < 1e-5
 
 
+def test_timestep_mlp_golden(dev):
+    """TimestepEmbedder(mode='mlp') — sinusoid -> Linear -> SiLU -> Linear, reference state_dict keys."""
+    import multimodal_diffusion_amd as A
+    g = load_golden("g10_tmlp.npz")
+    te = A.TimestepEmbedder(A.TimestepCfg(dim=64, mode="mlp"))
+    te.load_state_dict(split_weights(g)["w"], strict=True)
+    y = te.to(dev)(G(g["t"], dev)).cpu()
+    assert rel_err(y, g["y"]) < 1e-4
+    assert rel_err(y, R.timestep_mlp(T(g["t"]), R.cast_weights({"w": split_weights(g)["w"]}, torch.float64)["w"], 64)) < 1e-4
+    sin = A.TimestepEmbedder(A.TimestepCfg(dim=64, mode="sin")).to(dev)
+    assert torch.equal(sin(G(g["t"], dev)), A.schedule_utils.timestep_embedding(G(g["t"], dev), 64))
+
+
 def test_errors_are_loud(dev):
     import multimodal_diffusion_amd as A
     from multimodal_diffusion_amd import functional as Fn, _lib as L
