@@ -46,6 +46,22 @@ PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f3
 PEAK_HBM_GBS = 8000.0
 
 
+def pmc_traffic(kernel_tag: str):
+    """HBM-side bytes per launch of `kernel_tag` from the newest committed PMC pass (tools/pmc_traffic.py), or None.
+    The PMC passes cannot run inside this process (rocprofv3 wraps the command), so the figure is read back."""
+    files = sorted((ROOT / "profiles").glob("r*_traffic.json"))
+    if not files:
+        return None
+    try:
+        ks = json.loads(files[-1].read_text())["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    for name, v in ks.items():
+        if kernel_tag in name:
+            return v["traffic_bytes_per_launch"]
+    return None
+
+
 def step_flops_per_sample(nv: int, na: int, d: int = 512, L: int = 8, hid: int = 2048, tok: int = 256,
                           head_hidden: int = 512, tdim: int = 256) -> float:
     """Algorithmic FLOPs of one CFG step for one sample (head on target rows only)."""
@@ -209,7 +225,7 @@ def main():
         n, ms, work = rep[dom]
         achieved = work / (ms * 1e-3) / 1e12
         out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": PEAK_F32_MATRIX_TFLOPS,
-                           "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": None,
+                           "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MATRIX_TFLOPS, "traffic": pmc_traffic(dom),
                            "launches": n, "avg_launch_us": 1e3 * ms / max(n, 1),
                            "flops_per_launch": work / max(n, 1)}
         tot_ms = sum(v[1] for v in rep.values())

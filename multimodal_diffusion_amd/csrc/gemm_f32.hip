@@ -368,8 +368,8 @@ static int launch_dma(const GemmArgs& a, hipStream_t st) {
     g.nbn = (a.N + BN - 1) / BN;
     const int64_t nwg = ((a.M + BM - 1) / BM) * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm grid too large");
-    static const int tag = prof_tag_id("gemm_f32_dma_kernel<%d,%d,%d,%d,%s>", BM, BN, WM, WN,
-                                       EPI == EPI_BIAS ? "bias" : EPI == EPI_GELU ? "gelu" : "res");
+    // tag = the kernel name exactly as rocprofv3 prints its template arguments (EPI: 0 bias, 1 gelu, 2 residual)
+    static const int tag = prof_tag_id("gemm_f32_dma_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, EPI, WPS);
     ProfScope prof(tag, 2.0 * (double)a.M * a.N * a.K, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, g);
     AVD_CHECK_LAUNCH("gemm_f32_dma");
@@ -393,7 +393,7 @@ static int launch_reg(const GemmArgs& a, hipStream_t st) {
     g.nbn = (a.N + BN - 1) / BN;
     const int64_t nwg = ((a.M + BM - 1) / BM) * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm grid too large");
-    static const int tag = prof_tag_id("gemm_f32_reg_kernel<%d,%d,%d,%d,%s>", BM, BN, WM, WN, KTAIL ? "ktail" : "k32");
+    static const int tag = prof_tag_id("gemm_f32_reg_kernel<%d, %d, %d, %d, %s>", BM, BN, WM, WN, KTAIL ? "true" : "false");
     ProfScope prof(tag, 2.0 * (double)a.M * a.N * a.K, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, g);
     AVD_CHECK_LAUNCH("gemm_f32_reg");

@@ -108,7 +108,7 @@ int rmsnorm_f32(const float* x, RowMap xm, const float* scale, float* y, RowMap 
     AVD_REQUIRE(xm.ld % 4 == 0 && ym.ld % 4 == 0 && aligned16(x) && aligned16(y) && aligned16(scale), AVD_EUNSUPPORTED,
                 "rmsnorm: rows must be 16-byte aligned");
     if (rows == 0) return AVD_OK;
-    static const int tag = prof_tag_id("rmsnorm_kernel");
+    const int tag = prof_tag_id("rmsnorm_kernel<%d>", nv_for(d));
     ProfScope prof(tag, 8.0 * (double)rows * d, st);
     const unsigned grid = (unsigned)((rows + 3) / 4);
     const float isd = (float)sqrt((double)d);   // the reference divides by math.sqrt(d) rounded to fp32
@@ -130,7 +130,7 @@ int layernorm_act_f32(const float* x, const float* gamma, const float* beta, flo
     AVD_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), AVD_EUNSUPPORTED,
                 "layernorm: pointers must be 16-byte aligned");
     if (rows == 0) return AVD_OK;
-    static const int tag = prof_tag_id("layernorm_act_kernel");
+    const int tag = prof_tag_id("layernorm_act_kernel<%d>", nv_for(d));
     ProfScope prof(tag, 8.0 * (double)rows * d, st);
     const unsigned grid = (unsigned)((rows + 3) / 4);
     switch (nv_for(d)) {
