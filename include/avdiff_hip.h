@@ -210,6 +210,31 @@ int avd_denoise_step_f32(const avd_step_desc* s, const float* z, const float* Xp
                          const int64_t* t_prev, const float* noise, float* z_out,
                          void* workspace, int64_t workspace_bytes, avd_stream_t stream);
 
+/* ---- a9 / next-1: VideoVAE.decode — avdiff/models/encoders/vae_video3d.py:195-214 (decode), :79-84
+ * (_conv_block_3d: Conv3d 3x3x3 pad 1 -> GELU(erf) -> GroupNorm(min(8,C), eps 1e-5, affine)), :108-119.
+ * z [B,Cv,Tp,Hp,Wp] NCDHW -> from_lat (1x1x1) -> trilinear upsample (align_corners=False) to (T,H,W) ->
+ * n_blocks x [conv3x3x3 + GELU + GroupNorm] -> to_img (1x1x1) -> sigmoid | tanh -> out [B,out_ch,T,H,W] NCDHW.
+ * Inside, activations are NDHWC in a zero-haloed buffer and the convolution is the fp32 MFMA GEMM with a
+ * per-tap address shift (no im2col).  Decoder width must be 64 (the reference default). */
+typedef struct {
+    int B, Cv, Tp, Hp, Wp;             /* latent dims */
+    int T, H, W;                       /* output size (reference default: Tp*t_down, Hp*s_down, Wp*s_down) */
+    int base, n_blocks, out_ch;        /* dec_base (64), dec_blocks, in_ch of the VAE (3) */
+    int out_tanh;                      /* 0 = sigmoid, 1 = tanh (cfg.out_activation) */
+    float gn_eps;                      /* 1e-5 */
+    const float* from_lat_w;           /* from_lat.weight  [base,Cv]   (1x1x1 kernel squeezed) */
+    const float* from_lat_b;           /* from_lat.bias    [base] */
+    const float* const* conv_w;        /* HOST array [n_blocks]: dec_net.{i}.0.weight re-laid as [out][kt][kh][kw][in] */
+    const float* const* conv_b;        /* dec_net.{i}.0.bias [base] */
+    const float* const* gn_w;          /* dec_net.{i}.2.weight [base] */
+    const float* const* gn_b;          /* dec_net.{i}.2.bias   [base] */
+    const float* to_img_w;             /* to_img.weight [out_ch,base] */
+    const float* to_img_b;             /* to_img.bias   [out_ch] */
+} avd_vae_decode_desc;
+int64_t avd_vae_decode_workspace_bytes(const avd_vae_decode_desc* d);
+int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, float* out, void* workspace,
+                       int64_t workspace_bytes, avd_stream_t stream);
+
 /* device-side sampling-schedule cursor so a captured step can be replayed without host writes:
  * t_now[b] = sched[*cursor], t_prev[b] = sched[*cursor+1] for all b, then (*cursor)++ . */
 int avd_sched_advance(const int64_t* sched, int n_sched, int32_t* cursor, int64_t* t_now, int64_t* t_prev,

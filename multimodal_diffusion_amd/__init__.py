@@ -12,5 +12,6 @@ from .sampler import (DenoiseEngine, LinearAdapter, add_sinusoidal_timestep, bui
                       latents_to_tokens_audio, latents_to_tokens_video, sample_one_direction,
                       tokens_to_latents_audio)
 from .schedules import ModalitySchedule, build_schedules_from_config   # noqa: F401
+from .vae_video3d import VideoVAE, VideoVAEConfig                      # noqa: F401
 
 __version__ = "0.1.0"

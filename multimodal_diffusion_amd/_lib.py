@@ -57,6 +57,17 @@ class StepDesc(C.Structure):
                 ("guidance", C.c_float), ("eta", C.c_float), ("split_streams", C.c_int)]
 
 
+class VaeDecodeDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("Cv", C.c_int), ("Tp", C.c_int), ("Hp", C.c_int), ("Wp", C.c_int),
+                ("T", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("base", C.c_int), ("n_blocks", C.c_int), ("out_ch", C.c_int), ("out_tanh", C.c_int),
+                ("gn_eps", C.c_float),
+                ("from_lat_w", C.c_void_p), ("from_lat_b", C.c_void_p),
+                ("conv_w", C.POINTER(C.c_void_p)), ("conv_b", C.POINTER(C.c_void_p)),
+                ("gn_w", C.POINTER(C.c_void_p)), ("gn_b", C.POINTER(C.c_void_p)),
+                ("to_img_w", C.c_void_p), ("to_img_b", C.c_void_p)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); must list every symbol include/avdiff_hip.h declares
@@ -85,6 +96,8 @@ SIGNATURES = {
     "avd_step_workspace_bytes": (_L, [C.POINTER(StepDesc)]),
     "avd_denoise_step_f32": (_I, [C.POINTER(StepDesc), _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "avd_sched_advance": (_I, [_P, _I, _P, _P, _P, _I, _P]),
+    "avd_vae_decode_workspace_bytes": (_L, [C.POINTER(VaeDecodeDesc)]),
+    "avd_vae_decode_f32": (_I, [C.POINTER(VaeDecodeDesc), _P, _P, _P, _L, _P]),
     "avd_prof_enable": (_I, [_I]),
     "avd_prof_num_tags": (_I, []),
     "avd_prof_tag_name": (C.c_char_p, [_I]),

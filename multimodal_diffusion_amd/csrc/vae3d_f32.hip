@@ -1,0 +1,426 @@
+// VideoVAE.decode on MI355X — the loop boundary right after the sampler:
+//   avdiff/models/encoders/vae_video3d.py:195-214 (decode), :79-84 (_conv_block_3d = Conv3d 3x3x3 -> GELU -> GroupNorm(8)),
+//   :108-119 (from_lat 1x1x1, dec_net, to_img 1x1x1), trilinear upsample align_corners=False, sigmoid/tanh output.
+//
+// Layout: activations are NDHWC (64 channels = 256 contiguous bytes per voxel) in a buffer padded by one zero voxel
+// on every side of T, H, W.  In that layout a 3x3x3 tap is a CONSTANT address shift for every voxel of a tile, so
+// the convolution is the fp32 MFMA GEMM of gemm_f32.hip with a per-K-tile scalar offset on the A operand:
+//   M = voxels (128 per block), N = 64 output channels, K = 27 taps x 64 input channels = 54 K-tiles of 32,
+//   A tiles by LDS-DMA straight from the padded activation (no im2col buffer, no boundary branches),
+//   weights pre-arranged [out][tap][in].  Same XOR-swizzled unpadded LDS image and permuted-k fragment reads.
+// Epilogue: bias + exact-erf GELU on float4 row segments, store NDHWC, and per-(sample, group) partial sums /
+// sums of squares reduced with wavefront shuffles into a partials buffer (deterministic two-level reduction, no
+// atomics).  GroupNorm is finished by a tiny fp64 reduction kernel and applied by an HBM-bound pass that writes the
+// next conv's padded input — or, after the last block, fuses normalise + to_img (64->3) + sigmoid and writes NCDHW.
+#include "avd_common.h"
+
+namespace avd {
+
+constexpr int VC = 64;          // channels of the decoder trunk (reference default dec_base = 64)
+constexpr int VG = 8;           // GroupNorm groups = min(8, C)
+constexpr int VBM = 128;        // voxels per block
+constexpr int VBK = 32;
+
+#define AVD_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define AVD_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+struct ConvArgs {
+    const float* X;      // padded NDHWC [B, T+2, H+2, W+2, 64]
+    const float* Wt;     // [64][27][64]
+    const float* bias;   // [64]
+    float* Y;            // NDHWC [B, T, H, W, 64]
+    float* part;         // [B*tiles][2][8][2]
+    int T, H, W, tiles;  // tiles = ceil(T*H*W / 128) per sample
+};
+
+__global__ __launch_bounds__(256, 2) void conv3d_k3_c64_gelu_stats_kernel(ConvArgs g) {
+    constexpr int BM = VBM, BN = VC, WM = 64, WN = 32, BK = VBK;
+    constexpr int TM = 2, TN = 1;
+    constexpr int A_PIECES = BM / 32, B_PIECES = BN / 32;
+    constexpr int STAGE = (BM + BN) * BK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int nwg = gridDim.x;
+    int wg;
+    {
+        const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    const int smp = wg / g.tiles, tile = wg % g.tiles;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int THW = g.T * g.H * g.W;
+    const int Hp = g.H + 2, Wp = g.W + 2;
+
+    const int r8 = lane >> 3, pc = lane & 7;
+    const float* a_src[A_PIECES];
+    const float* b_src[B_PIECES];
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+        const int trow = (wave + 4 * i) * 8 + r8;
+        int v = tile * BM + trow;
+        v = v < THW ? v : THW - 1;
+        const int w = v % g.W, h = (v / g.W) % g.H, t = v / (g.W * g.H);
+        const int64_t pv = (((int64_t)smp * (g.T + 2) + t) * Hp + h) * Wp + w;      // tap (0,0,0) of this voxel
+        a_src[i] = g.X + pv * VC + ((pc ^ ((trow >> 1) & 7)) << 2);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) {
+        const int trow = (wave + 4 * i) * 8 + r8;
+        b_src[i] = g.Wt + (int64_t)trow * (27 * VC) + ((pc ^ ((trow >> 1) & 7)) << 2);
+    }
+    auto stage = [&](int kt, int buf) {
+        float* as = smem + buf * STAGE;
+        float* bs = as + BM * BK;
+        const int tap = kt >> 1, half = kt & 1;
+        const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+        const int offA = ((dt * Hp + dh) * Wp + dw) * VC + half * BK;       // same shift for every voxel of the tile
+        const int offB = kt * BK;
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(a_src[i] + offA), AVD_LDS_PTR(as + (wave + 4 * i) * 8 * BK), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(b_src[i] + offB), AVD_LDS_PTR(bs + (wave + 4 * i) * 8 * BK), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
+
+    constexpr int nk = 27 * VC / BK;   // 54
+    stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+
+    int a_row[TM], a_sw[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * WM + i * 32 + l31;
+        a_row[i] = r * BK;
+        a_sw[i] = (r >> 1) & 7;
+    }
+    const int br = wn * WN + l31;
+    const int b_row = br * BK, b_sw = (br >> 1) & 7;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const float* as = smem + cur * STAGE;
+        const float* bs = as + BM * BK;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 af[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(as + a_row[i] + (((2 * kk + hi) ^ a_sw[i]) << 2));
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(bs + b_row + (((2 * kk + hi) ^ b_sw) << 2));
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[s], acc[i][0], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+    }
+
+    // ---- epilogue: slab -> bias + GELU -> NDHWC store + GroupNorm partial statistics ----
+    constexpr int CLD = WN + 4;
+    float* slab = smem + wave * WM * CLD;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[(i * 32 + mfma32_row(r, hi)) * CLD + l31] = acc[i][0][r];
+    __syncthreads();
+
+    constexpr int LPR = WN / 4, RPI = 64 / LPR, NIT = WM / RPI;     // 8 lanes per row, 8 rows per pass, 8 passes
+    const int cr = lane / LPR, cc = (lane % LPR) * 4;
+    const int n = wn * WN + cc;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int v = tile * BM + wm * WM + cr + it * RPI;
+        f32x4 y = *reinterpret_cast<const f32x4*>(slab + (cr + it * RPI) * CLD + cc);
+        y += bv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = gelu_erf(y[e]);
+        if (v < THW) {
+            *reinterpret_cast<f32x4*>(g.Y + ((int64_t)smp * THW + v) * VC + n) = y;
+            s1 += (y[0] + y[1]) + (y[2] + y[3]);
+            s2 += (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+        }
+    }
+    // lanes sharing a group: the two 4-channel chunks (lane bit 0) x the 8 rows of a pass (lane bits 3..5)
+    s1 += __shfl_xor(s1, 1, 64);  s2 += __shfl_xor(s2, 1, 64);
+    s1 += __shfl_xor(s1, 8, 64);  s2 += __shfl_xor(s2, 8, 64);
+    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    if ((lane & 0x39) == 0) {            // lanes 0,2,4,6: group wn*4 + lane/2
+        float* p = g.part + ((((int64_t)smp * g.tiles + tile) * 2 + wm) * VG + wn * 4 + (lane >> 1)) * 2;
+        p[0] = s1;
+        p[1] = s2;
+    }
+}
+
+// mean / rstd per (sample, group): fp64 reduction of the per-block partials in a fixed order
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                          int tiles, double count, float eps) {
+    __shared__ double sh1[256], sh2[256];
+    const int smp = blockIdx.x / VG, grp = blockIdx.x % VG;
+    double a = 0.0, b = 0.0;
+    for (int i = threadIdx.x; i < tiles * 2; i += 256) {
+        const float* p = part + (((int64_t)smp * tiles * 2 + i) * VG + grp) * 2;
+        a += p[0];
+        b += p[1];
+    }
+    sh1[threadIdx.x] = a;
+    sh2[threadIdx.x] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            sh1[threadIdx.x] += sh1[threadIdx.x + o];
+            sh2[threadIdx.x] += sh2[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = sh1[0] / count;
+        double var = sh2[0] / count - mean * mean;     // biased, as torch.nn.GroupNorm
+        if (var < 0.0) var = 0.0;
+        stats[blockIdx.x * 2 + 0] = (float)mean;
+        stats[blockIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// GroupNorm apply: Y (NDHWC) -> interior of the padded NDHWC buffer feeding the next conv
+__global__ __launch_bounds__(256) void gn_apply_pad_kernel(const float* __restrict__ Y, const float* __restrict__ stats,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ Xp, int T, int H, int W, int64_t total4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int c = (int)(i % (VC / 4)) * 4;
+    const int64_t vox = i / (VC / 4);
+    const int THW = T * H * W;
+    const int smp = (int)(vox / THW), v = (int)(vox % THW);
+    const int w = v % W, h = (v / W) % H, t = v / (W * H);
+    const float mean = stats[(smp * VG + c / 8) * 2], rstd = stats[(smp * VG + c / 8) * 2 + 1];
+    const f32x4 y = *reinterpret_cast<const f32x4*>(Y + vox * VC + c);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (y[e] - mean) * rstd * gm[e] + bt[e];
+    const int64_t pv = (((int64_t)smp * (T + 2) + t + 1) * (H + 2) + h + 1) * (W + 2) + w + 1;
+    *reinterpret_cast<f32x4*>(Xp + pv * VC + c) = o;
+}
+
+// last block: GroupNorm apply + to_img (1x1x1, 64 -> Cout<=4) + sigmoid/tanh, NDHWC -> NCDHW
+__global__ __launch_bounds__(256) void gn_apply_toimg_kernel(const float* __restrict__ Y, const float* __restrict__ stats,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const float* __restrict__ Wimg, const float* __restrict__ bimg,
+                                                             float* __restrict__ out, int THW, int Cout, int use_tanh,
+                                                             int64_t nvox) {
+    // 16 lanes per voxel (one float4 of channels each): coalesced 1 KiB per wave instruction
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t vox = gid >> 4;
+    const int c = (int)(gid & 15) * 4;
+    const bool ok = vox < nvox;
+    const int64_t vx = ok ? vox : nvox - 1;
+    const int smp = (int)(vx / THW);
+    const float mean = stats[(smp * VG + c / 8) * 2], rstd = stats[(smp * VG + c / 8) * 2 + 1];
+    const f32x4 y = *reinterpret_cast<const f32x4*>(Y + vx * VC + c);
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+    float xn[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xn[e] = (y[e] - mean) * rstd * gm[e] + bt[e];
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {          // static indices keep acc[] in registers
+        if (o < Cout) {
+            const f32x4 w = *reinterpret_cast<const f32x4*>(Wimg + o * VC + c);
+            float a = xn[0] * w[0] + xn[1] * w[1] + xn[2] * w[2] + xn[3] * w[3];
+            a += __shfl_xor(a, 1, 64);
+            a += __shfl_xor(a, 2, 64);
+            a += __shfl_xor(a, 4, 64);
+            a += __shfl_xor(a, 8, 64);
+            acc[o] = a;
+        }
+    }
+    const int o = (int)(gid & 15);
+    if (ok && o < Cout) {
+        float v = acc[0];
+        if (o == 1) v = acc[1];
+        if (o == 2) v = acc[2];
+        if (o == 3) v = acc[3];
+        v += bimg[o];
+        v = use_tanh ? tanhf(v) : 1.0f / (1.0f + expf(-v));
+        out[((int64_t)smp * Cout + o) * THW + (vx % THW)] = v;
+    }
+}
+
+// from_lat: 1x1x1 conv Cv -> 64 on the latent grid, NCDHW in -> NDHWC out
+__global__ __launch_bounds__(256) void fromlat_kernel(const float* __restrict__ z, const float* __restrict__ Wf,
+                                                      const float* __restrict__ bf, float* __restrict__ hlow, int Cv,
+                                                      int vol, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int o = (int)(i % VC);
+    const int64_t vox = i / VC;
+    const int smp = (int)(vox / vol), v = (int)(vox % vol);
+    float a = 0.f;
+    for (int c = 0; c < Cv; ++c) a += z[((int64_t)smp * Cv + c) * vol + v] * Wf[o * Cv + c];
+    hlow[i] = a + bf[o];
+}
+
+// PyTorch upsample index rule for align_corners=False (area_pixel_compute_source_index)
+__device__ __forceinline__ void tri_src(int dst, float scale, int in_size, int& i0, int& i1, float& l0, float& l1) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+    l0 = 1.0f - l1;
+}
+
+// trilinear upsample of the NDHWC latent-grid features into the interior of the padded NDHWC conv input
+__global__ __launch_bounds__(256) void upsample_pad_kernel(const float* __restrict__ hlow, float* __restrict__ Xp,
+                                                           int Tp, int Hp_, int Wp_, int T, int H, int W, float st,
+                                                           float sh, float sw, int64_t total4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total4) return;
+    const int c = (int)(i % (VC / 4)) * 4;
+    const int64_t vox = i / (VC / 4);
+    const int THW = T * H * W;
+    const int smp = (int)(vox / THW), v = (int)(vox % THW);
+    const int w = v % W, h = (v / W) % H, t = v / (W * H);
+    int t0, t1, h0, h1, w0, w1;
+    float tl0, tl1, hl0, hl1, wl0, wl1;
+    tri_src(t, st, Tp, t0, t1, tl0, tl1);
+    tri_src(h, sh, Hp_, h0, h1, hl0, hl1);
+    tri_src(w, sw, Wp_, w0, w1, wl0, wl1);
+    const float* base = hlow + (int64_t)smp * Tp * Hp_ * Wp_ * VC + c;
+    auto at = [&](int tt, int hh, int ww) {
+        return *reinterpret_cast<const f32x4*>(base + ((int64_t)(tt * Hp_ + hh) * Wp_ + ww) * VC);
+    };
+    // same association as torch's CPU kernel: t0l*(h0l*(w0l*a+w1l*b) + h1l*(w0l*c+w1l*d)) + t1l*(...)
+    const f32x4 r = tl0 * (hl0 * (wl0 * at(t0, h0, w0) + wl1 * at(t0, h0, w1)) + hl1 * (wl0 * at(t0, h1, w0) + wl1 * at(t0, h1, w1))) +
+                    tl1 * (hl0 * (wl0 * at(t1, h0, w0) + wl1 * at(t1, h0, w1)) + hl1 * (wl0 * at(t1, h1, w0) + wl1 * at(t1, h1, w1)));
+    const int64_t pv = (((int64_t)smp * (T + 2) + t + 1) * (H + 2) + h + 1) * (W + 2) + w + 1;
+    *reinterpret_cast<f32x4*>(Xp + pv * VC + c) = r;
+}
+
+static inline int64_t a256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+struct VaePlan {
+    int T, H, W, tiles;
+    int64_t THW, pad_b, y_b, hlow_b, part_b, stats_b, total;
+};
+
+static int vae_plan(const avd_vae_decode_desc* d, VaePlan& p) {
+    AVD_REQUIRE(d, AVD_EINVAL, "vae_decode: null descriptor");
+    AVD_REQUIRE(d->B > 0 && d->Cv > 0 && d->Tp > 0 && d->Hp > 0 && d->Wp > 0, AVD_EINVAL, "vae_decode: bad latent dims");
+    AVD_REQUIRE(d->base == VC, AVD_EUNSUPPORTED, "vae_decode: decoder width %d unsupported (kernels are built for 64)", d->base);
+    AVD_REQUIRE(d->n_blocks >= 1 && d->n_blocks <= 8, AVD_EUNSUPPORTED, "vae_decode: 1..8 conv blocks supported");
+    AVD_REQUIRE(d->out_ch >= 1 && d->out_ch <= 4, AVD_EUNSUPPORTED, "vae_decode: 1..4 output channels supported");
+    AVD_REQUIRE(d->T > 0 && d->H > 0 && d->W > 0, AVD_EINVAL, "vae_decode: bad output size");
+    p.T = d->T; p.H = d->H; p.W = d->W;
+    p.THW = (int64_t)d->T * d->H * d->W;
+    AVD_REQUIRE(p.THW * VC < (1ll << 31) && (int64_t)(d->T + 2) * (d->H + 2) * (d->W + 2) * VC < (1ll << 31), AVD_EUNSUPPORTED,
+                "vae_decode: one sample's activation exceeds 2^31 elements");
+    p.tiles = (int)((p.THW + VBM - 1) / VBM);
+    p.pad_b = a256((int64_t)d->B * (d->T + 2) * (d->H + 2) * (d->W + 2) * VC * 4);
+    p.y_b = a256((int64_t)d->B * p.THW * VC * 4);
+    p.hlow_b = a256((int64_t)d->B * d->Tp * d->Hp * d->Wp * VC * 4);
+    p.part_b = a256((int64_t)d->B * p.tiles * 2 * VG * 2 * 4);
+    p.stats_b = a256((int64_t)d->B * VG * 2 * 4);
+    p.total = p.pad_b + p.y_b + p.hlow_b + p.part_b + p.stats_b;
+    return AVD_OK;
+}
+
+}  // namespace avd
+
+using namespace avd;
+
+extern "C" int64_t avd_vae_decode_workspace_bytes(const avd_vae_decode_desc* d) {
+    VaePlan p;
+    if (vae_plan(d, p)) return -1;
+    return p.total;
+}
+
+extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, float* out, void* workspace,
+                                  int64_t workspace_bytes, avd_stream_t stream) {
+    VaePlan p;
+    if (int rc = vae_plan(d, p)) return rc;
+    AVD_REQUIRE(z && out && d->from_lat_w && d->from_lat_b && d->conv_w && d->conv_b && d->gn_w && d->gn_b && d->to_img_w &&
+                d->to_img_b, AVD_EINVAL, "vae_decode: null pointer");
+    AVD_REQUIRE(workspace && workspace_bytes >= p.total, AVD_EWORKSPACE, "vae_decode: workspace %lld < %lld bytes",
+                (long long)workspace_bytes, (long long)p.total);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* w = static_cast<char*>(workspace);
+    float* Xp = reinterpret_cast<float*>(w);
+    float* Y = reinterpret_cast<float*>(w + p.pad_b);
+    float* hlow = reinterpret_cast<float*>(w + p.pad_b + p.y_b);
+    float* part = reinterpret_cast<float*>(w + p.pad_b + p.y_b + p.hlow_b);
+    float* stats = reinterpret_cast<float*>(w + p.pad_b + p.y_b + p.hlow_b + p.part_b);
+    const int B = d->B;
+
+    // zero halo (whole padded buffer; interiors are overwritten below, the halo stays zero for every conv)
+    {
+        hipError_t e = hipMemsetAsync(Xp, 0, (size_t)B * (p.T + 2) * (p.H + 2) * (p.W + 2) * VC * 4, st);
+        if (e != hipSuccess) return set_error(AVD_ELAUNCH, "vae_decode memset: %s", hipGetErrorString(e));
+    }
+    {   // from_lat on the latent grid, then trilinear upsample into the padded conv input
+        const int vol = d->Tp * d->Hp * d->Wp;
+        const int64_t total = (int64_t)B * vol * VC;
+        static const int tag = prof_tag_id("fromlat_kernel");
+        ProfScope prof(tag, 4.0 * ((double)B * vol * d->Cv + (double)total), st);
+        hipLaunchKernelGGL(fromlat_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, d->from_lat_w,
+                           d->from_lat_b, hlow, d->Cv, vol, total);
+        AVD_CHECK_LAUNCH("fromlat");
+    }
+    {
+        const int64_t total4 = (int64_t)B * p.THW * (VC / 4);
+        static const int tag = prof_tag_id("upsample_pad_kernel");
+        ProfScope prof(tag, 4.0 * (double)B * p.THW * VC, st);
+        hipLaunchKernelGGL(upsample_pad_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, hlow, Xp, d->Tp,
+                           d->Hp, d->Wp, p.T, p.H, p.W, (float)d->Tp / (float)p.T, (float)d->Hp / (float)p.H,
+                           (float)d->Wp / (float)p.W, total4);
+        AVD_CHECK_LAUNCH("upsample_pad");
+    }
+    constexpr int stage_lds = 2 * (VBM + VC) * VBK * 4, epi_lds = 4 * 64 * 36 * 4;
+    constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
+    for (int blk = 0; blk < d->n_blocks; ++blk) {
+        ConvArgs a{Xp, d->conv_w[blk], d->conv_b[blk], Y, part, p.T, p.H, p.W, p.tiles};
+        {
+            static const int tag = prof_tag_id("conv3d_k3_c64_gelu_stats_kernel");
+            ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st);
+            hipLaunchKernelGGL(conv3d_k3_c64_gelu_stats_kernel, dim3((unsigned)(B * p.tiles)), dim3(256), lds, st, a);
+            AVD_CHECK_LAUNCH("conv3d");
+        }
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * VG), dim3(256), 0, st, part, stats, p.tiles,
+                           (double)p.THW * (VC / VG), d->gn_eps);
+        AVD_CHECK_LAUNCH("gn_finalize");
+        if (blk + 1 < d->n_blocks) {
+            const int64_t total4 = (int64_t)B * p.THW * (VC / 4);
+            static const int tag = prof_tag_id("gn_apply_pad_kernel");
+            ProfScope prof(tag, 8.0 * (double)B * p.THW * VC, st);
+            hipLaunchKernelGGL(gn_apply_pad_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, Y, stats,
+                               d->gn_w[blk], d->gn_b[blk], Xp, p.T, p.H, p.W, total4);
+            AVD_CHECK_LAUNCH("gn_apply_pad");
+        } else {
+            const int64_t nvox = (int64_t)B * p.THW;
+            static const int tag = prof_tag_id("gn_apply_toimg_kernel");
+            ProfScope prof(tag, 4.0 * ((double)nvox * VC + (double)nvox * d->out_ch), st);
+            hipLaunchKernelGGL(gn_apply_toimg_kernel, dim3((unsigned)((nvox * 16 + 255) / 256)), dim3(256), 0, st, Y, stats,
+                               d->gn_w[blk], d->gn_b[blk], d->to_img_w, d->to_img_b, out, (int)p.THW, d->out_ch,
+                               d->out_tanh, nvox);
+            AVD_CHECK_LAUNCH("gn_apply_toimg");
+        }
+    }
+    return AVD_OK;
+}

@@ -1,0 +1,141 @@
+"""VideoVAE — host-side mirror of ``avdiff/models/encoders/vae_video3d.py`` (loop boundary).
+
+Same config dataclass, constructor, ``from_config`` and ``state_dict`` keys (``enc_net.{i}.0/2``, ``to_lat``,
+``from_lat``, ``dec_net.{i}.0/2``, ``to_img``) as the reference, so its checkpoints load ``strict=True``.
+``decode`` (vae_video3d.py:195-214) runs as HIP kernels through ``avd_vae_decode_f32``: from_lat → trilinear upsample
+→ [Conv3d 3x3x3 → GELU → GroupNorm(8)] x dec_blocks → to_img → sigmoid/tanh.  ``encode`` (prompt side of the V→A
+direction, once per sample) is not ported yet and raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+
+@dataclass
+class VideoVAEConfig:
+    in_ch: int = 3
+    lat_ch: int = 8
+    t_down: int = 4
+    s_down: int = 8
+    enc_base: int = 64
+    enc_blocks: int = 2
+    dec_base: int = 64
+    dec_blocks: int = 2
+    variational: bool = False
+    out_activation: str = "sigmoid"
+
+    @staticmethod
+    def from_dict(d: Dict) -> "VideoVAEConfig":
+        lat, enc, dec = d.get("latent", {}), d.get("encoder", {}), d.get("decoder", {})
+        return VideoVAEConfig(in_ch=int(d.get("in_ch", 3)), lat_ch=int(lat.get("channels", 8)),
+                              t_down=int(lat.get("t_down", 4)), s_down=int(lat.get("s_down", 8)),
+                              enc_base=int(enc.get("base", 64)), enc_blocks=int(enc.get("blocks", 2)),
+                              dec_base=int(dec.get("base", 64)), dec_blocks=int(dec.get("blocks", 2)),
+                              variational=bool(d.get("variational", False)),
+                              out_activation=str(d.get("out_activation", "sigmoid")))
+
+
+def _conv_block_3d(c_in: int, c_out: int) -> nn.Sequential:
+    # parameter containers in the reference's slots: 0 = Conv3d, 1 = activation (no params), 2 = GroupNorm
+    return nn.Sequential(nn.Conv3d(c_in, c_out, (3, 3, 3), padding=(1, 1, 1)), nn.GELU(),
+                         nn.GroupNorm(num_groups=min(8, c_out), num_channels=c_out))
+
+
+class VideoVAE(nn.Module):
+    def __init__(self, cfg: VideoVAEConfig):
+        super().__init__()
+        self.cfg = cfg
+        if cfg.out_activation not in ("sigmoid", "tanh"):
+            raise ValueError("out_activation must be 'sigmoid' or 'tanh'")
+        Cc = cfg.enc_base
+        self.pool = nn.AvgPool3d(kernel_size=(cfg.t_down, cfg.s_down, cfg.s_down), stride=(cfg.t_down, cfg.s_down, cfg.s_down))
+        self.enc_net = nn.Sequential(*([_conv_block_3d(cfg.in_ch, Cc)] + [_conv_block_3d(Cc, Cc) for _ in range(cfg.enc_blocks - 1)]))
+        if cfg.variational:
+            self.to_mu = nn.Conv3d(Cc, cfg.lat_ch, kernel_size=1)
+            self.to_logv = nn.Conv3d(Cc, cfg.lat_ch, kernel_size=1)
+        else:
+            self.to_lat = nn.Conv3d(Cc, cfg.lat_ch, kernel_size=1)
+        D = cfg.dec_base
+        self.from_lat = nn.Conv3d(cfg.lat_ch, D, kernel_size=1)
+        self.dec_net = nn.Sequential(*[_conv_block_3d(D, D) for _ in range(cfg.dec_blocks)])
+        self.up_t, self.up_s = cfg.t_down, cfg.s_down
+        self.to_img = nn.Conv3d(D, cfg.in_ch, kernel_size=1)
+        self._ws: Optional[torch.Tensor] = None
+        self._relaid = {}
+
+    @classmethod
+    def from_config(cls, d: Dict) -> "VideoVAE":
+        return cls(VideoVAEConfig.from_dict(d))
+
+    def encode(self, x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError("VideoVAE.encode is not ported to HIP yet (prompt-side, once per sample)")
+
+    # conv weight [out,in,kt,kh,kw] -> [out][kt][kh][kw][in] (K = tap-major, channel-minor), cached per parameter version
+    def _tap_major(self, i: int) -> torch.Tensor:
+        w = self.dec_net[i][0].weight
+        key = (i, w.data_ptr(), w._version, str(w.device))
+        hit = self._relaid.get(i)
+        if hit is None or hit[0] != key:
+            self._relaid[i] = (key, w.detach().permute(0, 2, 3, 4, 1).contiguous())
+        return self._relaid[i][1]
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, out_size: Optional[Tuple[int, int, int]] = None,
+               max_workspace_bytes: int = 12 << 30) -> torch.Tensor:
+        """z [B,Cv,T',H',W'] -> x_hat [B,3,T,H,W] in [0,1] (sigmoid) or [-1,1] (tanh)."""
+        z = L.dev_f32(z, "z")
+        B, Cv, Tp, Hp, Wp = z.shape
+        if Cv != self.cfg.lat_ch:
+            raise RuntimeError(f"expected {self.cfg.lat_ch} latent channels, got {Cv}")
+        T, H, W = out_size if out_size is not None else (Tp * self.up_t, Hp * self.up_s, Wp * self.up_s)
+        nb = len(self.dec_net)
+        keep = [self._tap_major(i) for i in range(nb)]
+
+        def tab(ts):
+            arr = (C.c_void_p * nb)()
+            for i, t in enumerate(ts):
+                tt = L.dev_f32(t.detach(), "vae parameter")
+                keep.append(tt)
+                arr[i] = tt.data_ptr()
+            return arr
+
+        cw = tab(keep[:nb])
+        cb = tab([self.dec_net[i][0].bias for i in range(nb)])
+        gw = tab([self.dec_net[i][2].weight for i in range(nb)])
+        gb = tab([self.dec_net[i][2].bias for i in range(nb)])
+        flw = L.dev_f32(self.from_lat.weight.detach().reshape(self.cfg.dec_base, Cv), "from_lat.weight")
+        tiw = L.dev_f32(self.to_img.weight.detach().reshape(self.cfg.in_ch, self.cfg.dec_base), "to_img.weight")
+        d = L.VaeDecodeDesc()
+        d.Cv, d.Tp, d.Hp, d.Wp, d.T, d.H, d.W = Cv, Tp, Hp, Wp, T, H, W
+        d.base, d.n_blocks, d.out_ch = self.cfg.dec_base, nb, self.cfg.in_ch
+        d.out_tanh = 1 if self.cfg.out_activation == "tanh" else 0
+        d.gn_eps = self.dec_net[0][2].eps
+        d.from_lat_w, d.from_lat_b = flw.data_ptr(), L.dev_f32(self.from_lat.bias.detach()).data_ptr()
+        d.conv_w, d.conv_b = C.cast(cw, C.POINTER(C.c_void_p)), C.cast(cb, C.POINTER(C.c_void_p))
+        d.gn_w, d.gn_b = C.cast(gw, C.POINTER(C.c_void_p)), C.cast(gb, C.POINTER(C.c_void_p))
+        d.to_img_w, d.to_img_b = tiw.data_ptr(), L.dev_f32(self.to_img.bias.detach()).data_ptr()
+        # chunk the batch so the NDHWC activations (2 x 0.85 GB per 48x256x256 sample) stay inside the budget
+        d.B = 1
+        per = L.lib().avd_vae_decode_workspace_bytes(C.byref(d))
+        if per < 0:
+            raise L.AvdError(L.lib().avd_last_error().decode())
+        chunk = max(1, min(B, max_workspace_bytes // per))
+        d.B = chunk
+        need = L.lib().avd_vae_decode_workspace_bytes(C.byref(d))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != z.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=z.device)
+        out = torch.empty(B, self.cfg.in_ch, T, H, W, device=z.device, dtype=torch.float32)
+        for lo in range(0, B, chunk):
+            hi = min(B, lo + chunk)
+            d.B = hi - lo
+            L.check(L.lib().avd_vae_decode_f32(C.byref(d), z[lo:hi].data_ptr(), out[lo:hi].data_ptr(), self._ws.data_ptr(),
+                                               self._ws.numel(), L.stream_ptr(z.device)))
+        del keep
+        return out

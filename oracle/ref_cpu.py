@@ -374,3 +374,76 @@ def synth_weights(seed: int = 0, d: int = 512, n_layers: int = 8, mlp_ratio: flo
 
 def cast_weights(ws: Dict[str, Weights], dtype) -> Dict[str, Weights]:
     return {k: {n: t.to(dtype) for n, t in v.items()} for k, v in ws.items()}
+
+
+# --------------------------------------------------------------------------------------
+# VideoVAE.decode (vae_video3d.py:195-214; _conv_block_3d :79-84) — loop boundary, SURVEY a9 / next-1
+# --------------------------------------------------------------------------------------
+
+def _lin_src(out_size: int, in_size: int, dtype):
+    """torch's align_corners=False source index rule: src = max(scale*(dst+0.5)-0.5, 0), i1 = min(i0+1, in-1)."""
+    scale = in_size / out_size
+    src = (scale * (torch.arange(out_size, dtype=torch.float32) + 0.5) - 0.5).clamp(min=0.0)
+    i0 = src.floor().long().clamp(max=in_size - 1)
+    i1 = (i0 + 1).clamp(max=in_size - 1)
+    l1 = (src - i0.float()).to(dtype)
+    return i0, i1, 1.0 - l1, l1
+
+
+def trilinear_upsample(x: Tensor, size) -> Tensor:
+    """[B,C,t,h,w] -> [B,C,T,H,W], trilinear, align_corners=False (F.interpolate semantics)."""
+    T, H, W = size
+    t0, t1, tl0, tl1 = _lin_src(T, x.shape[2], x.dtype)
+    h0, h1, hl0, hl1 = _lin_src(H, x.shape[3], x.dtype)
+    w0, w1, wl0, wl1 = _lin_src(W, x.shape[4], x.dtype)
+
+    def at(ti, hi, wi):
+        return x[:, :, ti][:, :, :, hi][:, :, :, :, wi]
+
+    tl0, tl1 = tl0.view(1, 1, -1, 1, 1), tl1.view(1, 1, -1, 1, 1)
+    hl0, hl1 = hl0.view(1, 1, 1, -1, 1), hl1.view(1, 1, 1, -1, 1)
+    return (tl0 * (hl0 * (wl0 * at(t0, h0, w0) + wl1 * at(t0, h0, w1)) + hl1 * (wl0 * at(t0, h1, w0) + wl1 * at(t0, h1, w1))) +
+            tl1 * (hl0 * (wl0 * at(t1, h0, w0) + wl1 * at(t1, h0, w1)) + hl1 * (wl0 * at(t1, h1, w0) + wl1 * at(t1, h1, w1))))
+
+
+def group_norm(x: Tensor, groups: int, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
+    B, C = x.shape[:2]
+    g = x.reshape(B, groups, -1)
+    mu = g.mean(-1, keepdim=True)
+    var = (g - mu).pow(2).mean(-1, keepdim=True)
+    y = ((g - mu) / (var + eps).sqrt()).reshape(x.shape)
+    shp = [1, C] + [1] * (x.dim() - 2)
+    return y * w.view(shp) + b.view(shp)
+
+
+def vae_decode(z: Tensor, W: Weights, t_down: int = 4, s_down: int = 8, n_blocks: int = 2, out_act: str = "sigmoid",
+               out_size=None) -> Tensor:
+    conv3d = torch.nn.functional.conv3d
+    h = conv3d(z, W["from_lat.weight"], W["from_lat.bias"])
+    size = out_size or (z.shape[2] * t_down, z.shape[3] * s_down, z.shape[4] * s_down)
+    h = trilinear_upsample(h, size)
+    for i in range(n_blocks):
+        cw = W[f"dec_net.{i}.0.weight"]
+        h = conv3d(h, cw, W[f"dec_net.{i}.0.bias"], padding=1)
+        h = gelu_erf(h)
+        h = group_norm(h, min(8, cw.shape[0]), W[f"dec_net.{i}.2.weight"], W[f"dec_net.{i}.2.bias"])
+    x = conv3d(h, W["to_img.weight"], W["to_img.bias"])
+    return torch.sigmoid(x) if out_act == "sigmoid" else torch.tanh(x)
+
+
+def synth_vae_decoder(seed: int = 0, cv: int = 8, base: int = 64, n_blocks: int = 2, out_ch: int = 3) -> Weights:
+    g = torch.Generator().manual_seed(seed)
+
+    def u(*shape, fan_in):
+        a = 1.0 / math.sqrt(fan_in)
+        return (torch.rand(*shape, generator=g) * 2 - 1) * a
+
+    W: Weights = {"from_lat.weight": u(base, cv, 1, 1, 1, fan_in=cv), "from_lat.bias": u(base, fan_in=cv)}
+    for i in range(n_blocks):
+        W[f"dec_net.{i}.0.weight"] = u(base, base, 3, 3, 3, fan_in=27 * base)
+        W[f"dec_net.{i}.0.bias"] = u(base, fan_in=27 * base)
+        W[f"dec_net.{i}.2.weight"] = 1.0 + 0.1 * torch.randn(base, generator=g)
+        W[f"dec_net.{i}.2.bias"] = 0.1 * torch.randn(base, generator=g)
+    W["to_img.weight"] = u(out_ch, base, 1, 1, 1, fan_in=base)
+    W["to_img.bias"] = u(out_ch, fan_in=base)
+    return W

@@ -422,3 +422,41 @@ def test_errors_are_loud(dev):
         Fn.attention(torch.zeros(1, 4, 3 * 32, device=dev), 1)       # head_dim 32 unsupported
     with pytest.raises(ValueError):
         A.schedule_utils.make_beta_schedule(10, kind="nope")
+
+
+# ------------------------------------------------------------------------------------------------- VideoVAE.decode (next-1)
+def _vae_from(W, dev):
+    import multimodal_diffusion_amd as A
+    vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval()
+    missing, unexpected = vae.load_state_dict(W, strict=False)          # decoder-only weights
+    assert not unexpected and all(k.startswith(("enc_net", "to_lat")) for k in missing)
+    return vae.to(dev)
+
+
+def test_vae_decode_golden(dev):
+    """Reference VideoVAE.decode (vae_video3d.py:195-214) on a small latent, default and explicit out_size."""
+    g = load_golden("g11_vae_decode.npz")
+    W = split_weights(g)["w"]
+    vae = _vae_from(W, dev)
+    x = vae.decode(G(g["z"], dev)).cpu()
+    assert x.shape == (2, 3, 8, 32, 32)
+    assert rel_err(x, g["x"]) < TOL
+    x_odd = vae.decode(G(g["z"][:1], dev), out_size=(6, 24, 40)).cpu()     # ragged tiles: 5760 voxels = 45 tiles
+    assert rel_err(x_odd, g["x_odd"]) < TOL
+    # chunked batches give the same bits as one batch
+    one = vae.decode(G(g["z"], dev), max_workspace_bytes=1).cpu()
+    assert torch.equal(one, x)
+
+
+def test_vae_decode_vs_oracle_bigger(dev):
+    """128x128 output (T'=3 -> 12 frames): 196,608 voxels per sample, tanh head, 3 conv blocks, vs the fp64 oracle."""
+    import multimodal_diffusion_amd as A
+    W = R.synth_vae_decoder(seed=3, n_blocks=3)
+    vae = A.VideoVAE(A.VideoVAEConfig(dec_blocks=3, out_activation="tanh")).eval()
+    vae.load_state_dict(W, strict=False)
+    z = torch.randn(1, 8, 3, 16, 16, generator=torch.Generator().manual_seed(4))
+    ref = R.vae_decode(z.double(), {k: v.double() for k, v in W.items()}, n_blocks=3, out_act="tanh")
+    x = vae.to(dev).decode(z.to(dev)).cpu()
+    assert rel_err(x, ref) < TOL
+    with pytest.raises(NotImplementedError):
+        vae.encode(torch.zeros(1, 3, 4, 8, 8, device=dev))

@@ -142,3 +142,15 @@ def test_fp64_oracle_agrees_with_fp32(small_model):
     W64 = R.cast_weights(W, torch.float64)
     y64 = R.mmdit_forward(T(g["x"]).double(), W64["core"], meta["n_layers"], meta["n_heads"])
     assert rel_err(y64, g["y"]) < 1e-5
+
+
+def test_g11_vae_decode():
+    """Loop boundary (next-1): the oracle's VideoVAE.decode restatement vs the reference module's output."""
+    g = load_golden("g11_vae_decode.npz")
+    W = split_weights(g)["w"]
+    assert rel_err(R.vae_decode(T(g["z"]), W), g["x"]) < 1e-5
+    assert rel_err(R.vae_decode(T(g["z"][:1]), W, out_size=(6, 24, 40)), g["x_odd"]) < 1e-5
+    # hand-written trilinear == torch's F.interpolate rule on an awkward size
+    x = torch.randn(1, 2, 3, 5, 4, generator=torch.Generator().manual_seed(0))
+    ref = torch.nn.functional.interpolate(x, size=(7, 9, 10), mode="trilinear", align_corners=False)
+    assert rel_err(R.trilinear_upsample(x, (7, 9, 10)), ref) < 1e-6

@@ -10,7 +10,8 @@ exits with a message (tests then rely on the committed fixtures alone).
 
 Fixture list: G1 schedules, G2 timestep embedding, G3 token index maps,
 G4 RMSNorm, G5 Block/MMDiT, G6 MultiModalNoiseHead, G7 ddim_step, G8 one CFG step both directions,
-G9 chained A->V via the reference's own ``sample_one_direction``, G10 TimestepEmbedder(mlp).
+G9 chained A->V via the reference's own ``sample_one_direction``, G10 TimestepEmbedder(mlp),
+G11 VideoVAE.decode.
 """
 from __future__ import annotations
 
@@ -245,6 +246,19 @@ def main():
     te = TimestepEmbedder(TimestepCfg(dim=64, mode="mlp"))
     tt = torch.tensor([0, 3, 500, 999], dtype=torch.long)
     _save("g10_tmlp.npz", t=_np(tt), y=_np(te(tt)), **_flat("w", _sd(te)))
+
+    # ---- G11 VideoVAE.decode (loop boundary, next-1): reference module at its default decoder width ----------
+    from avdiff.models.encoders.vae_video3d import VideoVAE
+    torch.manual_seed(11)
+    vae = VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval()
+    g = torch.Generator().manual_seed(12)
+    for name, p_ in vae.named_parameters():          # exercise biases / GroupNorm affine (zeros / ones at init)
+        if name.startswith(("dec_net", "from_lat", "to_img")) and p_.dim() == 1:
+            p_.add_(0.1 * torch.randn(p_.shape, generator=g))
+    zz = torch.randn(2, 8, 2, 4, 4, generator=g)
+    dec_sd = {k: v for k, v in _sd(vae).items() if k.startswith(("from_lat", "dec_net", "to_img"))}
+    _save("g11_vae_decode.npz", z=_np(zz), x=_np(vae.decode(zz)), x_odd=_np(vae.decode(zz[:1], out_size=(6, 24, 40))),
+          **_flat("w", dec_sd))
 
     # ---- optional: full-size live comparison oracle vs reference --------------------------
     if args.full_size_report:

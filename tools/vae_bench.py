@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""VideoVAE.decode timing at the shipped geometry (GPU box): z [B,8,12,S/8,S/8] -> [B,3,48,S,S]."""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+import multimodal_diffusion_amd as A            # noqa: E402
+from multimodal_diffusion_amd import _lib as L  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--size", type=int, default=256)
+ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--iters", type=int, default=5)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval().to(dev)
+z = torch.randn(args.batch, 8, 12, args.size // 8, args.size // 8, device=dev)
+for _ in range(2):
+    x = vae.decode(z)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.iters):
+    x = vae.decode(z)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / args.iters
+vox = args.batch * 48 * args.size * args.size
+fl = 2 * 2.0 * vox * 64 * 27 * 64
+print(f"decode B={args.batch} {args.size}x{args.size}: {dt*1e3:.2f} ms  ({fl/dt/1e12:.1f} TFLOP/s on the two 3x3x3 convs), "
+      f"out {tuple(x.shape)} finite={bool(torch.isfinite(x).all())}")
+L.prof_enable(True)
+vae.decode(z)
+torch.cuda.synchronize()
+L.prof_enable(False)
+for k, (n, ms, w) in L.prof_report().items():
+    if n:
+        unit = f"{w/ms/1e9:8.1f} TFLOP/s" if "conv3d" in k else f"{w/ms/1e6:8.1f} GB/s"
+        print(f"  {k:40s} x{n}  {ms/n:9.3f} ms  {unit}")
