@@ -235,6 +235,27 @@ int64_t avd_vae_decode_workspace_bytes(const avd_vae_decode_desc* d);
 int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, float* out, void* workspace,
                        int64_t workspace_bytes, avd_stream_t stream);
 
+/* ---- next-1: VideoVAE.encode — avdiff/models/encoders/vae_video3d.py:164-189 (deterministic path):
+ * x [B,in_ch,T,H,W] NCDHW (already cropped to multiples of t_down / s_down) -> n_blocks x [conv3x3x3 + GELU + GroupNorm]
+ * -> AvgPool3d(t_down,s_down,s_down) -> to_lat (1x1x1) -> z [B,lat_ch,T/t_down,H/s_down,W/s_down] NCDHW.
+ * The first conv (in_ch -> 64) runs on the same MFMA kernel with the input padded to 4 channels (K = 32 taps x 4). */
+typedef struct {
+    int B, in_ch, T, H, W;
+    int t_down, s_down;
+    int base, n_blocks, lat_ch;        /* enc_base (64), enc_blocks, latent channels */
+    float gn_eps;
+    const float* const* conv_w;        /* HOST array [n_blocks]: block 0: enc_net.0.0.weight re-laid as [64][32 taps][4]
+                                          (27 real taps, channel 3 and taps 27..31 zero); blocks >= 1: [64][27][64] */
+    const float* const* conv_b;
+    const float* const* gn_w;
+    const float* const* gn_b;
+    const float* to_lat_w;             /* to_lat.weight (or to_mu.weight) [lat_ch,64] */
+    const float* to_lat_b;
+} avd_vae_encode_desc;
+int64_t avd_vae_encode_workspace_bytes(const avd_vae_encode_desc* d);
+int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, float* z, void* workspace,
+                       int64_t workspace_bytes, avd_stream_t stream);
+
 /* device-side sampling-schedule cursor so a captured step can be replayed without host writes:
  * t_now[b] = sched[*cursor], t_prev[b] = sched[*cursor+1] for all b, then (*cursor)++ . */
 int avd_sched_advance(const int64_t* sched, int n_sched, int32_t* cursor, int64_t* t_now, int64_t* t_prev,

@@ -68,6 +68,15 @@ class VaeDecodeDesc(C.Structure):
                 ("to_img_w", C.c_void_p), ("to_img_b", C.c_void_p)]
 
 
+class VaeEncodeDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("in_ch", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("t_down", C.c_int), ("s_down", C.c_int),
+                ("base", C.c_int), ("n_blocks", C.c_int), ("lat_ch", C.c_int), ("gn_eps", C.c_float),
+                ("conv_w", C.POINTER(C.c_void_p)), ("conv_b", C.POINTER(C.c_void_p)),
+                ("gn_w", C.POINTER(C.c_void_p)), ("gn_b", C.POINTER(C.c_void_p)),
+                ("to_lat_w", C.c_void_p), ("to_lat_b", C.c_void_p)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); must list every symbol include/avdiff_hip.h declares
@@ -98,6 +107,8 @@ SIGNATURES = {
     "avd_sched_advance": (_I, [_P, _I, _P, _P, _P, _I, _P]),
     "avd_vae_decode_workspace_bytes": (_L, [C.POINTER(VaeDecodeDesc)]),
     "avd_vae_decode_f32": (_I, [C.POINTER(VaeDecodeDesc), _P, _P, _P, _L, _P]),
+    "avd_vae_encode_workspace_bytes": (_L, [C.POINTER(VaeEncodeDesc)]),
+    "avd_vae_encode_f32": (_I, [C.POINTER(VaeEncodeDesc), _P, _P, _P, _L, _P]),
     "avd_prof_enable": (_I, [_I]),
     "avd_prof_num_tags": (_I, []),
     "avd_prof_tag_name": (C.c_char_p, [_I]),

@@ -25,16 +25,21 @@ constexpr int VBK = 32;
 #define AVD_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
 struct ConvArgs {
-    const float* X;      // padded NDHWC [B, T+2, H+2, W+2, 64]
-    const float* Wt;     // [64][27][64]
+    const float* X;      // padded NDHWC [B, T+2, H+2, W+2, CIN]   (CIN = 64, or 4 = RGB + one zero channel)
+    const float* Wt;     // [64][27][64]  |  [64][32 taps (27 real, 5 zero)][4]
     const float* bias;   // [64]
     float* Y;            // NDHWC [B, T, H, W, 64]
     float* part;         // [B*tiles][2][8][2]
     int T, H, W, tiles;  // tiles = ceil(T*H*W / 128) per sample
 };
 
-__global__ __launch_bounds__(256, 2) void conv3d_k3_c64_gelu_stats_kernel(ConvArgs g) {
+// CIN = 64: a K-tile is half of one tap's channels -> one scalar address shift per K-tile.
+// CIN = 4 (first encoder conv, RGB padded to 4): a K-tile is 8 taps x 4 channels -> every 16-byte chunk of a row comes
+// from its own tap, which LDS-DMA handles because the SOURCE address is per lane (only the LDS side is linear).
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void conv3d_k3_gelu_stats_kernel(ConvArgs g) {
     constexpr int BM = VBM, BN = VC, WM = 64, WN = 32, BK = VBK;
+    constexpr int KTOT = CIN == 64 ? 27 * 64 : 128;
     constexpr int TM = 2, TN = 1;
     constexpr int A_PIECES = BM / 32, B_PIECES = BN / 32;
     constexpr int STAGE = (BM + BN) * BK;
@@ -55,6 +60,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_c64_gelu_stats_kernel(ConvAr
 
     const int r8 = lane >> 3, pc = lane & 7;
     const float* a_src[A_PIECES];
+    int a_c[A_PIECES];                 // logical 16-byte chunk this lane fetches (physical chunk pc, un-swizzled)
     const float* b_src[B_PIECES];
 #pragma unroll
     for (int i = 0; i < A_PIECES; ++i) {
@@ -63,23 +69,35 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_c64_gelu_stats_kernel(ConvAr
         v = v < THW ? v : THW - 1;
         const int w = v % g.W, h = (v / g.W) % g.H, t = v / (g.W * g.H);
         const int64_t pv = (((int64_t)smp * (g.T + 2) + t) * Hp + h) * Wp + w;      // tap (0,0,0) of this voxel
-        a_src[i] = g.X + pv * VC + ((pc ^ ((trow >> 1) & 7)) << 2);
+        a_c[i] = pc ^ ((trow >> 1) & 7);
+        a_src[i] = g.X + pv * CIN + (CIN == 64 ? (a_c[i] << 2) : 0);
     }
 #pragma unroll
     for (int i = 0; i < B_PIECES; ++i) {
         const int trow = (wave + 4 * i) * 8 + r8;
-        b_src[i] = g.Wt + (int64_t)trow * (27 * VC) + ((pc ^ ((trow >> 1) & 7)) << 2);
+        b_src[i] = g.Wt + (int64_t)trow * KTOT + ((pc ^ ((trow >> 1) & 7)) << 2);
     }
     auto stage = [&](int kt, int buf) {
         float* as = smem + buf * STAGE;
         float* bs = as + BM * BK;
-        const int tap = kt >> 1, half = kt & 1;
-        const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
-        const int offA = ((dt * Hp + dh) * Wp + dw) * VC + half * BK;       // same shift for every voxel of the tile
         const int offB = kt * BK;
+        if constexpr (CIN == 64) {
+            const int tap = kt >> 1, half = kt & 1;
+            const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+            const int offA = ((dt * Hp + dh) * Wp + dw) * VC + half * BK;   // same shift for every voxel of the tile
 #pragma unroll
-        for (int i = 0; i < A_PIECES; ++i)
-            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(a_src[i] + offA), AVD_LDS_PTR(as + (wave + 4 * i) * 8 * BK), 16, 0, 0);
+            for (int i = 0; i < A_PIECES; ++i)
+                __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(a_src[i] + offA), AVD_LDS_PTR(as + (wave + 4 * i) * 8 * BK), 16, 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_PIECES; ++i) {
+                int tap = kt * 8 + a_c[i];
+                tap = tap < 27 ? tap : 0;                                    // taps 27..31 carry zero weights
+                const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+                const int offA = ((dt * Hp + dh) * Wp + dw) * CIN;
+                __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(a_src[i] + offA), AVD_LDS_PTR(as + (wave + 4 * i) * 8 * BK), 16, 0, 0);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < B_PIECES; ++i)
             __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(b_src[i] + offB), AVD_LDS_PTR(bs + (wave + 4 * i) * 8 * BK), 16, 0, 0);
@@ -91,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_c64_gelu_stats_kernel(ConvAr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][0][r] = 0.f;
 
-    constexpr int nk = 27 * VC / BK;   // 54
+    constexpr int nk = KTOT / BK;   // 54 | 4
     stage(0, 0);
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
@@ -314,6 +332,64 @@ __global__ __launch_bounds__(256) void upsample_pad_kernel(const float* __restri
     *reinterpret_cast<f32x4*>(Xp + pv * VC + c) = r;
 }
 
+// ---- encoder side (vae_video3d.py:164-189): x [B,Cin<=4,T,H,W] NCDHW -> interior of the padded NDHWC4 buffer ----
+__global__ __launch_bounds__(256) void rgb_to_ndhwc4_pad_kernel(const float* __restrict__ x, float* __restrict__ Xp4,
+                                                                int Cin, int T, int H, int W, int64_t nvox) {
+    const int64_t vox = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (vox >= nvox) return;
+    const int THW = T * H * W;
+    const int smp = (int)(vox / THW), v = (int)(vox % THW);
+    const int w = v % W, h = (v / W) % H, t = v / (W * H);
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < Cin; ++c) o[c] = x[((int64_t)smp * Cin + c) * THW + v];
+    const int64_t pv = (((int64_t)smp * (T + 2) + t + 1) * (H + 2) + h + 1) * (W + 2) + w + 1;
+    *reinterpret_cast<f32x4*>(Xp4 + pv * 4) = o;
+}
+
+// GroupNorm apply + AvgPool3d(td, sd, sd) + to_lat (1x1x1, 64 -> Cl <= 16): one wave per latent voxel.
+// Pooling and the per-channel GroupNorm affine commute, so the window mean is normalised once.
+__global__ __launch_bounds__(256) void gn_pool_tolat_kernel(const float* __restrict__ Y, const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ Wl, const float* __restrict__ bl,
+                                                            float* __restrict__ z, int T, int H, int W, int td, int sd,
+                                                            int Cl, int64_t nlat) {
+    const int lane = threadIdx.x & 63;
+    const int64_t lv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (lv >= nlat) return;
+    const int Tl = T / td, Hl = H / sd, Wl_ = W / sd;
+    const int vol = Tl * Hl * Wl_;
+    const int smp = (int)(lv / vol), r = (int)(lv % vol);
+    const int wl = r % Wl_, hl = (r / Wl_) % Hl, tl = r / (Wl_ * Hl);
+    const int c = (lane & 15) * 4, sub = lane >> 4;             // 16 lanes per voxel, 4 voxels per pass
+    const int win = td * sd * sd;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int j = sub; j < win; j += 4) {
+        const int ww = j % sd, hh = (j / sd) % sd, tt = j / (sd * sd);
+        const int64_t v = (((int64_t)smp * T + tl * td + tt) * H + hl * sd + hh) * W + wl * sd + ww;
+        s += *reinterpret_cast<const f32x4*>(Y + v * VC + c);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s[e] += __shfl_xor(s[e], 16, 64);
+        s[e] += __shfl_xor(s[e], 32, 64);
+    }
+    const float inv = 1.0f / (float)win;
+    const float mean = stats[(smp * VG + c / 8) * 2], rstd = stats[(smp * VG + c / 8) * 2 + 1];
+    const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
+    float xn[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xn[e] = (s[e] * inv - mean) * rstd * gm[e] + bt[e];
+    for (int o = 0; o < Cl; ++o) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(Wl + o * VC + c);
+        float a = xn[0] * wv[0] + xn[1] * wv[1] + xn[2] * wv[2] + xn[3] * wv[3];
+        a += __shfl_xor(a, 1, 64);
+        a += __shfl_xor(a, 2, 64);
+        a += __shfl_xor(a, 4, 64);
+        a += __shfl_xor(a, 8, 64);
+        if (lane == o) z[((int64_t)smp * Cl + o) * vol + r] = a + bl[o];
+    }
+}
+
 static inline int64_t a256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 struct VaePlan {
@@ -397,9 +473,9 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
     for (int blk = 0; blk < d->n_blocks; ++blk) {
         ConvArgs a{Xp, d->conv_w[blk], d->conv_b[blk], Y, part, p.T, p.H, p.W, p.tiles};
         {
-            static const int tag = prof_tag_id("conv3d_k3_c64_gelu_stats_kernel");
+            static const int tag = prof_tag_id("conv3d_k3_gelu_stats_kernel<64>");
             ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st);
-            hipLaunchKernelGGL(conv3d_k3_c64_gelu_stats_kernel, dim3((unsigned)(B * p.tiles)), dim3(256), lds, st, a);
+            hipLaunchKernelGGL(conv3d_k3_gelu_stats_kernel<64>, dim3((unsigned)(B * p.tiles)), dim3(256), lds, st, a);
             AVD_CHECK_LAUNCH("conv3d");
         }
         hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * VG), dim3(256), 0, st, part, stats, p.tiles,
@@ -420,6 +496,107 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
                                d->gn_w[blk], d->gn_b[blk], d->to_img_w, d->to_img_b, out, (int)p.THW, d->out_ch,
                                d->out_tanh, nvox);
             AVD_CHECK_LAUNCH("gn_apply_toimg");
+        }
+    }
+    return AVD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// VideoVAE.encode — vae_video3d.py:164-189 (deterministic path): enc_net -> AvgPool3d(t_down,s_down,s_down) -> to_lat
+// ---------------------------------------------------------------------------------------------------------
+namespace avd {
+struct VaeEncPlan {
+    int tiles;
+    int64_t THW, pad4_b, pad_b, y_b, part_b, stats_b, total;
+};
+static int vae_enc_plan(const avd_vae_encode_desc* d, VaeEncPlan& p) {
+    AVD_REQUIRE(d, AVD_EINVAL, "vae_encode: null descriptor");
+    AVD_REQUIRE(d->B > 0 && d->T > 0 && d->H > 0 && d->W > 0, AVD_EINVAL, "vae_encode: bad input dims");
+    AVD_REQUIRE(d->in_ch >= 1 && d->in_ch <= 4, AVD_EUNSUPPORTED, "vae_encode: 1..4 input channels supported");
+    AVD_REQUIRE(d->base == VC, AVD_EUNSUPPORTED, "vae_encode: encoder width %d unsupported (kernels are built for 64)", d->base);
+    AVD_REQUIRE(d->n_blocks >= 1 && d->n_blocks <= 8, AVD_EUNSUPPORTED, "vae_encode: 1..8 conv blocks supported");
+    AVD_REQUIRE(d->lat_ch >= 1 && d->lat_ch <= 16, AVD_EUNSUPPORTED, "vae_encode: 1..16 latent channels supported");
+    AVD_REQUIRE(d->t_down > 0 && d->s_down > 0 && d->T % d->t_down == 0 && d->H % d->s_down == 0 && d->W % d->s_down == 0,
+                AVD_EINVAL, "vae_encode: T,H,W must be divisible by (t_down, s_down, s_down) — crop first");
+    p.THW = (int64_t)d->T * d->H * d->W;
+    AVD_REQUIRE((int64_t)(d->T + 2) * (d->H + 2) * (d->W + 2) * VC < (1ll << 31), AVD_EUNSUPPORTED,
+                "vae_encode: one sample's activation exceeds 2^31 elements");
+    p.tiles = (int)((p.THW + VBM - 1) / VBM);
+    const int64_t padvox = (int64_t)d->B * (d->T + 2) * (d->H + 2) * (d->W + 2);
+    p.pad4_b = a256(padvox * 4 * 4);
+    p.pad_b = d->n_blocks > 1 ? a256(padvox * VC * 4) : 0;
+    p.y_b = a256((int64_t)d->B * p.THW * VC * 4);
+    p.part_b = a256((int64_t)d->B * p.tiles * 2 * VG * 2 * 4);
+    p.stats_b = a256((int64_t)d->B * VG * 2 * 4);
+    p.total = p.pad4_b + p.pad_b + p.y_b + p.part_b + p.stats_b;
+    return AVD_OK;
+}
+}  // namespace avd
+
+extern "C" int64_t avd_vae_encode_workspace_bytes(const avd_vae_encode_desc* d) {
+    VaeEncPlan p;
+    if (vae_enc_plan(d, p)) return -1;
+    return p.total;
+}
+
+extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, float* z, void* workspace,
+                                  int64_t workspace_bytes, avd_stream_t stream) {
+    VaeEncPlan p;
+    if (int rc = vae_enc_plan(d, p)) return rc;
+    AVD_REQUIRE(x && z && d->conv_w && d->conv_b && d->gn_w && d->gn_b && d->to_lat_w && d->to_lat_b, AVD_EINVAL,
+                "vae_encode: null pointer");
+    AVD_REQUIRE(workspace && workspace_bytes >= p.total, AVD_EWORKSPACE, "vae_encode: workspace %lld < %lld bytes",
+                (long long)workspace_bytes, (long long)p.total);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char* w = static_cast<char*>(workspace);
+    float* Xp4 = reinterpret_cast<float*>(w);
+    float* Xp = reinterpret_cast<float*>(w + p.pad4_b);
+    float* Y = reinterpret_cast<float*>(w + p.pad4_b + p.pad_b);
+    float* part = reinterpret_cast<float*>(w + p.pad4_b + p.pad_b + p.y_b);
+    float* stats = reinterpret_cast<float*>(w + p.pad4_b + p.pad_b + p.y_b + p.part_b);
+    const int B = d->B, T = d->T, H = d->H, W = d->W;
+    const int64_t padvox = (int64_t)B * (T + 2) * (H + 2) * (W + 2);
+
+    hipError_t e = hipMemsetAsync(Xp4, 0, (size_t)padvox * 16, st);
+    if (e == hipSuccess && d->n_blocks > 1) e = hipMemsetAsync(Xp, 0, (size_t)padvox * VC * 4, st);
+    if (e != hipSuccess) return set_error(AVD_ELAUNCH, "vae_encode memset: %s", hipGetErrorString(e));
+    {
+        const int64_t nvox = (int64_t)B * p.THW;
+        hipLaunchKernelGGL(rgb_to_ndhwc4_pad_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, x, Xp4, d->in_ch,
+                           T, H, W, nvox);
+        AVD_CHECK_LAUNCH("rgb_to_ndhwc4_pad");
+    }
+    constexpr int stage_lds = 2 * (VBM + VC) * VBK * 4, epi_lds = 4 * 64 * 36 * 4;
+    constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
+    for (int blk = 0; blk < d->n_blocks; ++blk) {
+        ConvArgs a{blk == 0 ? Xp4 : Xp, d->conv_w[blk], d->conv_b[blk], Y, part, T, H, W, p.tiles};
+        if (blk == 0) {
+            static const int tag = prof_tag_id("conv3d_k3_gelu_stats_kernel<4>");
+            ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * d->in_ch, st);
+            hipLaunchKernelGGL(conv3d_k3_gelu_stats_kernel<4>, dim3((unsigned)(B * p.tiles)), dim3(256), lds, st, a);
+        } else {
+            static const int tag = prof_tag_id("conv3d_k3_gelu_stats_kernel<64>");
+            ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st);
+            hipLaunchKernelGGL(conv3d_k3_gelu_stats_kernel<64>, dim3((unsigned)(B * p.tiles)), dim3(256), lds, st, a);
+        }
+        AVD_CHECK_LAUNCH("conv3d(enc)");
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * VG), dim3(256), 0, st, part, stats, p.tiles,
+                           (double)p.THW * (VC / VG), d->gn_eps);
+        AVD_CHECK_LAUNCH("gn_finalize");
+        if (blk + 1 < d->n_blocks) {
+            const int64_t total4 = (int64_t)B * p.THW * (VC / 4);
+            static const int tag = prof_tag_id("gn_apply_pad_kernel");
+            ProfScope prof(tag, 8.0 * (double)B * p.THW * VC, st);
+            hipLaunchKernelGGL(gn_apply_pad_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, Y, stats,
+                               d->gn_w[blk], d->gn_b[blk], Xp, T, H, W, total4);
+            AVD_CHECK_LAUNCH("gn_apply_pad");
+        } else {
+            const int64_t nlat = (int64_t)B * (T / d->t_down) * (H / d->s_down) * (W / d->s_down);
+            static const int tag = prof_tag_id("gn_pool_tolat_kernel");
+            ProfScope prof(tag, 4.0 * (double)B * p.THW * VC, st);
+            hipLaunchKernelGGL(gn_pool_tolat_kernel, dim3((unsigned)((nlat + 3) / 4)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
+                               d->gn_b[blk], d->to_lat_w, d->to_lat_b, z, T, H, W, d->t_down, d->s_down, d->lat_ch, nlat);
+            AVD_CHECK_LAUNCH("gn_pool_tolat");
         }
     }
     return AVD_OK;

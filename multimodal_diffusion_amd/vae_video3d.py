@@ -3,12 +3,13 @@
 Same config dataclass, constructor, ``from_config`` and ``state_dict`` keys (``enc_net.{i}.0/2``, ``to_lat``,
 ``from_lat``, ``dec_net.{i}.0/2``, ``to_img``) as the reference, so its checkpoints load ``strict=True``.
 ``decode`` (vae_video3d.py:195-214) runs as HIP kernels through ``avd_vae_decode_f32``: from_lat → trilinear upsample
-→ [Conv3d 3x3x3 → GELU → GroupNorm(8)] x dec_blocks → to_img → sigmoid/tanh.  ``encode`` (prompt side of the V→A
-direction, once per sample) is not ported yet and raises.
+→ [Conv3d 3x3x3 → GELU → GroupNorm(8)] x dec_blocks → to_img → sigmoid/tanh.  ``encode`` (:164-189, deterministic
+path) runs through ``avd_vae_encode_f32``: [conv → GELU → GroupNorm] x enc_blocks → AvgPool3d → to_lat.
 """
 from __future__ import annotations
 
 import ctypes as C
+import warnings
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -16,6 +17,8 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
+
+_warned_divisibility = False
 
 
 @dataclass
@@ -74,8 +77,88 @@ class VideoVAE(nn.Module):
     def from_config(cls, d: Dict) -> "VideoVAE":
         return cls(VideoVAEConfig.from_dict(d))
 
-    def encode(self, x: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("VideoVAE.encode is not ported to HIP yet (prompt-side, once per sample)")
+    def _check_divisible(self, T: int, H: int, W: int):
+        """Center-crop to multiples of (t_down, s_down, s_down), warning once (vae_video3d.py:136-160)."""
+        global _warned_divisibility
+        td, sd = self.cfg.t_down, self.cfg.s_down
+        T2, H2, W2 = (T // td) * td, (H // sd) * sd, (W // sd) * sd
+        if (T2, H2, W2) != (T, H, W) and not _warned_divisibility:
+            warnings.warn(f"[VideoVAE] Input (T={T},H={H},W={W}) not divisible by (t_down={td}, s_down={sd}); "
+                          f"center-cropping to (T={T2},H={H2},W={W2}).")
+            _warned_divisibility = True
+        t0, h0, w0 = (T - T2) // 2, (H - H2) // 2, (W - W2) // 2
+        return T2, H2, W2, (t0, t0 + T2, h0, h0 + H2, w0, w0 + W2)
+
+    def _enc_weight(self, i: int) -> torch.Tensor:
+        """Block 0: [64,Cin,3,3,3] -> [64][32 taps][4] (taps 27..31 and channel >= Cin zero); others: tap-major [64][27][64]."""
+        w = self.enc_net[i][0].weight
+        key = ("enc", i, w.data_ptr(), w._version, str(w.device))
+        hit = self._relaid.get(("enc", i))
+        if hit is None or hit[0] != key:
+            wt = w.detach().permute(0, 2, 3, 4, 1).contiguous()              # [out, kt, kh, kw, in]
+            if i == 0:
+                buf = torch.zeros(wt.shape[0], 32, 4, device=w.device, dtype=torch.float32)
+                buf[:, :27, :wt.shape[-1]] = wt.reshape(wt.shape[0], 27, wt.shape[-1])
+                wt = buf
+            self._relaid[("enc", i)] = (key, wt)
+        return self._relaid[("enc", i)][1]
+
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, max_workspace_bytes: int = 12 << 30) -> torch.Tensor:
+        """x [B,3,T,H,W] -> z [B,Cv,T',H',W'] (vae_video3d.py:164-189, deterministic path)."""
+        if self.cfg.variational:
+            raise NotImplementedError("variational=True encode (mu/logvar + KL cache) has no HIP path; shipped configs are deterministic")
+        x = L.dev_f32(x, "x")
+        B, Cin, T, H, W = x.shape
+        if Cin != self.cfg.in_ch:
+            raise RuntimeError(f"expected {self.cfg.in_ch} input channels, got {Cin}")
+        T2, H2, W2, (t0, t1, h0, h1, w0, w1) = self._check_divisible(T, H, W)
+        if (T2, H2, W2) != (T, H, W):
+            x = x[:, :, t0:t1, h0:h1, w0:w1].contiguous()
+        self._kld = None
+        nb = len(self.enc_net)
+        keep = [self._enc_weight(i) for i in range(nb)]
+
+        def tab(ts):
+            arr = (C.c_void_p * nb)()
+            for i, t in enumerate(ts):
+                tt = L.dev_f32(t.detach(), "vae parameter")
+                keep.append(tt)
+                arr[i] = tt.data_ptr()
+            return arr
+
+        cw = tab(keep[:nb])
+        cb = tab([self.enc_net[i][0].bias for i in range(nb)])
+        gw = tab([self.enc_net[i][2].weight for i in range(nb)])
+        gb = tab([self.enc_net[i][2].bias for i in range(nb)])
+        tlw = L.dev_f32(self.to_lat.weight.detach().reshape(self.cfg.lat_ch, self.cfg.enc_base), "to_lat.weight")
+        d = L.VaeEncodeDesc()
+        d.in_ch, d.T, d.H, d.W, d.t_down, d.s_down = Cin, T2, H2, W2, self.cfg.t_down, self.cfg.s_down
+        d.base, d.n_blocks, d.lat_ch, d.gn_eps = self.cfg.enc_base, nb, self.cfg.lat_ch, self.enc_net[0][2].eps
+        d.conv_w, d.conv_b = C.cast(cw, C.POINTER(C.c_void_p)), C.cast(cb, C.POINTER(C.c_void_p))
+        d.gn_w, d.gn_b = C.cast(gw, C.POINTER(C.c_void_p)), C.cast(gb, C.POINTER(C.c_void_p))
+        d.to_lat_w, d.to_lat_b = tlw.data_ptr(), L.dev_f32(self.to_lat.bias.detach()).data_ptr()
+        d.B = 1
+        per = L.lib().avd_vae_encode_workspace_bytes(C.byref(d))
+        if per < 0:
+            raise L.AvdError(L.lib().avd_last_error().decode())
+        chunk = max(1, min(B, max_workspace_bytes // per))
+        d.B = chunk
+        need = L.lib().avd_vae_encode_workspace_bytes(C.byref(d))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        z = torch.empty(B, self.cfg.lat_ch, T2 // self.cfg.t_down, H2 // self.cfg.s_down, W2 // self.cfg.s_down,
+                        device=x.device, dtype=torch.float32)
+        for lo in range(0, B, chunk):
+            hi = min(B, lo + chunk)
+            d.B = hi - lo
+            L.check(L.lib().avd_vae_encode_f32(C.byref(d), x[lo:hi].data_ptr(), z[lo:hi].data_ptr(), self._ws.data_ptr(),
+                                               self._ws.numel(), L.stream_ptr(x.device)))
+        del keep
+        return z
+
+    def kld_loss(self):
+        return getattr(self, "_kld", None)
 
     # conv weight [out,in,kt,kh,kw] -> [out][kt][kh][kw][in] (K = tap-major, channel-minor), cached per parameter version
     def _tap_major(self, i: int) -> torch.Tensor:

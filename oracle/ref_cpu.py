@@ -447,3 +447,16 @@ def synth_vae_decoder(seed: int = 0, cv: int = 8, base: int = 64, n_blocks: int 
     W["to_img.weight"] = u(out_ch, base, 1, 1, 1, fan_in=base)
     W["to_img.bias"] = u(out_ch, fan_in=base)
     return W
+
+
+def vae_encode(x: Tensor, W: Weights, t_down: int = 4, s_down: int = 8, n_blocks: int = 2) -> Tensor:
+    """VideoVAE.encode, deterministic path (vae_video3d.py:164-189); x already divisible by the down factors."""
+    conv3d = torch.nn.functional.conv3d
+    h = x
+    for i in range(n_blocks):
+        cw = W[f"enc_net.{i}.0.weight"]
+        h = gelu_erf(conv3d(h, cw, W[f"enc_net.{i}.0.bias"], padding=1))
+        h = group_norm(h, min(8, cw.shape[0]), W[f"enc_net.{i}.2.weight"], W[f"enc_net.{i}.2.bias"])
+    B, Cc, T, H, Wd = h.shape
+    h = h.view(B, Cc, T // t_down, t_down, H // s_down, s_down, Wd // s_down, s_down).mean(dim=(3, 5, 7))
+    return conv3d(h, W["to_lat.weight"], W["to_lat.bias"])

@@ -459,4 +459,25 @@ def test_vae_decode_vs_oracle_bigger(dev):
     x = vae.to(dev).decode(z.to(dev)).cpu()
     assert rel_err(x, ref) < TOL
     with pytest.raises(NotImplementedError):
-        vae.encode(torch.zeros(1, 3, 4, 8, 8, device=dev))
+        A.VideoVAE(A.VideoVAEConfig(variational=True)).to(dev).encode(torch.zeros(1, 3, 4, 8, 8, device=dev))
+
+
+def test_vae_encode_golden(dev):
+    """Reference VideoVAE.encode (vae_video3d.py:164-189): RGB conv on the 4-channel MFMA path, pool + to_lat, crop."""
+    import warnings
+    import multimodal_diffusion_amd as A
+    g = load_golden("g12_vae_encode.npz")
+    W = split_weights(g)["w"]
+    vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval()
+    missing, unexpected = vae.load_state_dict(W, strict=False)
+    assert not unexpected and all(k.startswith(("dec_net", "from_lat", "to_img")) for k in missing)
+    vae = vae.to(dev)
+    z = vae.encode(G(g["x"], dev)).cpu()
+    assert z.shape == (2, 8, 2, 2, 3)
+    assert rel_err(z, g["z"]) < TOL
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        zc = vae.encode(G(g["x_crop"], dev)).cpu()          # (9,18,17) -> center crop (8,16,16)
+    assert rel_err(zc, g["z_crop"]) < TOL
+    # encode -> decode shapes compose (the V->A prompt path and the A->V output path)
+    assert vae.decode(vae.encode(G(g["x"], dev))).shape == (2, 3, 8, 16, 24)

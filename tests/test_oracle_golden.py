@@ -154,3 +154,10 @@ def test_g11_vae_decode():
     x = torch.randn(1, 2, 3, 5, 4, generator=torch.Generator().manual_seed(0))
     ref = torch.nn.functional.interpolate(x, size=(7, 9, 10), mode="trilinear", align_corners=False)
     assert rel_err(R.trilinear_upsample(x, (7, 9, 10)), ref) < 1e-6
+
+
+def test_g12_vae_encode():
+    g = load_golden("g12_vae_encode.npz")
+    W = split_weights(g)["w"]
+    assert rel_err(R.vae_encode(T(g["x"]), W), g["z"]) < 1e-5
+    assert rel_err(R.vae_encode(T(g["x_crop"])[:, :, 0:8, 1:17, 0:16], W), g["z_crop"]) < 1e-5

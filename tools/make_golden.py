@@ -11,7 +11,7 @@ exits with a message (tests then rely on the committed fixtures alone).
 Fixture list: G1 schedules, G2 timestep embedding, G3 token index maps,
 G4 RMSNorm, G5 Block/MMDiT, G6 MultiModalNoiseHead, G7 ddim_step, G8 one CFG step both directions,
 G9 chained A->V via the reference's own ``sample_one_direction``, G10 TimestepEmbedder(mlp),
-G11 VideoVAE.decode.
+G11 VideoVAE.decode, G12 VideoVAE.encode.
 """
 from __future__ import annotations
 
@@ -259,6 +259,19 @@ def main():
     dec_sd = {k: v for k, v in _sd(vae).items() if k.startswith(("from_lat", "dec_net", "to_img"))}
     _save("g11_vae_decode.npz", z=_np(zz), x=_np(vae.decode(zz)), x_odd=_np(vae.decode(zz[:1], out_size=(6, 24, 40))),
           **_flat("w", dec_sd))
+
+    # ---- G12 VideoVAE.encode (prompt side of V->A): same module, incl. the center-crop of a non-divisible clip ----
+    for name, p_ in vae.named_parameters():
+        if name.startswith(("enc_net", "to_lat")) and p_.dim() == 1:
+            p_.add_(0.1 * torch.randn(p_.shape, generator=g))
+    xx = torch.rand(2, 3, 8, 16, 24, generator=g)
+    x_crop = torch.rand(1, 3, 9, 18, 17, generator=g)           # -> crops to (8,16,16)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        z_crop = vae.encode(x_crop)
+    enc_sd = {k: v for k, v in _sd(vae).items() if k.startswith(("enc_net", "to_lat"))}
+    _save("g12_vae_encode.npz", x=_np(xx), z=_np(vae.encode(xx)), x_crop=_np(x_crop), z_crop=_np(z_crop), **_flat("w", enc_sd))
 
     # ---- optional: full-size live comparison oracle vs reference --------------------------
     if args.full_size_report:
