@@ -36,6 +36,7 @@ extern "C" {
 #define AVD_ACT_NONE 0
 #define AVD_ACT_GELU 1        /* exact erf GELU (torch.nn.functional.gelu default) */
 #define AVD_ACT_SILU 2
+#define AVD_ACT_TANH 3        /* conv1d only (AudioCodec.decode output) */
 
 typedef void* avd_stream_t;   /* hipStream_t */
 
@@ -255,6 +256,16 @@ typedef struct {
 int64_t avd_vae_encode_workspace_bytes(const avd_vae_encode_desc* d);
 int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, float* z, void* workspace,
                        int64_t workspace_bytes, avd_stream_t stream);
+
+/* ---- next-2: AudioCodec layers — avdiff/models/encoders/audio_codec.py:88-133, :158-214.
+ * NCL conv1d (odd k <= 15, zero padding k/2, stride 1) with optional nearest-neighbour upsampling of the INPUT by
+ * `upsample` folded into the indexing (decode's F.interpolate(mode="nearest") x hop), then act in {none, GELU, tanh}.
+ * x [B,Cin,Lin], w [Cout,Cin,k], bias [Cout] or NULL, out [B,Cout,Lin*upsample]. */
+int avd_conv1d_act_f32(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout,
+                       int Lin, int upsample, int k, int act, avd_stream_t stream);
+/* audio_codec.py:158-182: right-pad with zeros / crop to Fa*hop samples, then avg_pool1d(kernel = stride = hop).
+ * x [rows, L] -> out [rows, Fa]. */
+int avd_avgpool_frames_f32(const float* x, float* out, int rows, int L, int Fa, int hop, avd_stream_t stream);
 
 /* device-side sampling-schedule cursor so a captured step can be replayed without host writes:
  * t_now[b] = sched[*cursor], t_prev[b] = sched[*cursor+1] for all b, then (*cursor)++ . */

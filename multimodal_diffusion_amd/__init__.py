@@ -13,5 +13,6 @@ from .sampler import (DenoiseEngine, LinearAdapter, add_sinusoidal_timestep, bui
                       tokens_to_latents_audio)
 from .schedules import ModalitySchedule, build_schedules_from_config   # noqa: F401
 from .vae_video3d import VideoVAE, VideoVAEConfig                      # noqa: F401
+from .audio_codec import AudioCodec, AudioCodecConfig                  # noqa: F401
 
 __version__ = "0.1.0"

@@ -16,7 +16,7 @@ import torch
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("AVDIFF_HIP_LIB", _HERE / "csrc" / "libavdiff_hip.so"))
 
-ACT_NONE, ACT_GELU, ACT_SILU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_SILU, ACT_TANH = 0, 1, 2, 3
 EINVAL, EUNSUPPORTED, ELAUNCH, EWORKSPACE = -1, -2, -3, -4
 
 
@@ -109,6 +109,8 @@ SIGNATURES = {
     "avd_vae_decode_f32": (_I, [C.POINTER(VaeDecodeDesc), _P, _P, _P, _L, _P]),
     "avd_vae_encode_workspace_bytes": (_L, [C.POINTER(VaeEncodeDesc)]),
     "avd_vae_encode_f32": (_I, [C.POINTER(VaeEncodeDesc), _P, _P, _P, _L, _P]),
+    "avd_conv1d_act_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "avd_avgpool_frames_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "avd_prof_enable": (_I, [_I]),
     "avd_prof_num_tags": (_I, []),
     "avd_prof_tag_name": (C.c_char_p, [_I]),

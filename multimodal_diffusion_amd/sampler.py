@@ -52,8 +52,15 @@ def build_components(cfg: Dict, device: torch.device, vid_vae: Optional[nn.Modul
                      aud_codec: Optional[nn.Module] = None):
     """(vid_vae, aud_codec, adapt_v, adapt_a, core, head, tstep_dim) as sample_clip.py:75-109.
 
-    The codec/VAE slots carry whatever the caller passes (``None`` by default): they sit outside the per-step path.
+    The codec / VAE are built from ``cfg["video"]`` / ``cfg["audio"]`` like the reference unless the caller passes
+    its own modules (anything with ``encode`` / ``decode``); they sit outside the per-step path.
     """
+    if vid_vae is None and "video" in cfg:
+        from .vae_video3d import VideoVAE
+        vid_vae = VideoVAE.from_config(cfg["video"]).to(device).eval()
+    if aud_codec is None and "audio" in cfg:
+        from .audio_codec import AudioCodec
+        aud_codec = AudioCodec.from_config(cfg["audio"]).to(device).eval()
     d = int(cfg["tokenizer"]["width"])
     out_v = int(cfg["model"]["heads"]["video"]["out_dim"])
     out_a = int(cfg["model"]["heads"]["audio"]["out_dim"])

@@ -460,3 +460,40 @@ def vae_encode(x: Tensor, W: Weights, t_down: int = 4, s_down: int = 8, n_blocks
     B, Cc, T, H, Wd = h.shape
     h = h.view(B, Cc, T // t_down, t_down, H // s_down, s_down, Wd // s_down, s_down).mean(dim=(3, 5, 7))
     return conv3d(h, W["to_lat.weight"], W["to_lat.bias"])
+
+
+# --------------------------------------------------------------------------------------
+# AudioCodec (audio_codec.py:184-214) — loop boundary, next-2
+# --------------------------------------------------------------------------------------
+
+def _exact_pool(Lw: int, Fa: int):
+    hop = max(1, int(round(Lw / Fa)))
+    if Fa * hop < Lw:
+        hop += 1
+    return hop, Fa * hop
+
+
+def codec_encode(wav: Tensor, W: Weights, frames_per_clip: Optional[int] = 150, hop: int = 320) -> Tensor:
+    conv1d = torch.nn.functional.conv1d
+    h = gelu_erf(conv1d(wav, W["pre.0.0.weight"], W["pre.0.0.bias"], padding=4))
+    h = gelu_erf(conv1d(h, W["pre.1.0.weight"], W["pre.1.0.bias"], padding=4))
+    Lw = h.shape[-1]
+    if frames_per_clip is None:
+        Fa, hp = math.ceil(Lw / hop), hop
+    else:
+        Fa = frames_per_clip
+        hp, _ = _exact_pool(Lw, Fa)
+    total = Fa * hp
+    h = torch.nn.functional.pad(h, (0, total - Lw)) if total > Lw else h[..., :total]
+    h = h.view(h.shape[0], h.shape[1], Fa, hp).mean(-1)
+    return conv1d(h, W["to_lat.weight"], W["to_lat.bias"])
+
+
+def codec_decode(z: Tensor, W: Weights, hop: int = 320) -> Tensor:
+    conv1d = torch.nn.functional.conv1d
+    h = conv1d(z, W["from_lat.weight"], W["from_lat.bias"])
+    h = h.repeat_interleave(hop, dim=-1)                      # nearest-neighbour x hop
+    pad = W["smooth.0.weight"].shape[-1] // 2
+    h = gelu_erf(conv1d(h, W["smooth.0.weight"], W["smooth.0.bias"], padding=pad))
+    h = gelu_erf(conv1d(h, W["smooth.2.weight"], W["smooth.2.bias"], padding=pad))
+    return torch.tanh(conv1d(h, W["smooth.4.weight"], W["smooth.4.bias"], padding=pad))

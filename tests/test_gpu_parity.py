@@ -481,3 +481,62 @@ def test_vae_encode_golden(dev):
     assert rel_err(zc, g["z_crop"]) < TOL
     # encode -> decode shapes compose (the V->A prompt path and the A->V output path)
     assert vae.decode(vae.encode(G(g["x"], dev))).shape == (2, 3, 8, 16, 24)
+
+
+# ------------------------------------------------------------------------------------------------- AudioCodec (next-2)
+def test_audio_codec_golden(dev):
+    """Reference AudioCodec.encode / decode (audio_codec.py:184-214) with the shipped hop / frame geometry."""
+    from multimodal_diffusion_amd.audio_codec import AudioCodec
+    g = load_golden("g13_audio_codec.npz")
+    codec = AudioCodec.from_config({"sr": 16000, "latent": {"channels": 8, "frames_per_clip": 150},
+                                    "codec": {"hop_samples": 320, "hidden": 64, "smooth_kernel": 7}}).eval()
+    codec.load_state_dict(split_weights(g)["w"], strict=True)
+    codec = codec.to(dev)
+    z = codec.encode(G(g["wav"], dev)).cpu()
+    assert z.shape == (2, 8, 150) and rel_err(z, g["z"]) < TOL
+    w = codec.decode(G(g["z_in"], dev)).cpu()
+    assert w.shape == (2, 1, 3200) and rel_err(w, g["wav_out"]) < TOL
+    assert float(w.abs().max()) <= 1.0
+
+
+def test_sample_one_direction_end_to_end(dev, full):
+    """Reference-signature entry point, both directions, codec + VAE + loop all on HIP, vs the oracle pipeline.
+    (The reference's own V->A branch crashes on a permute bug, sample_clip.py:286-289; A->V runs.)"""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd.audio_codec import AudioCodec
+    ws, (core, head, av, aa) = full
+    torch.manual_seed(3)
+    vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval().to(dev)
+    codec = AudioCodec.from_config({"sr": 16000, "latent": {"channels": 8, "frames_per_clip": 150},
+                                    "codec": {"hop_samples": 320}}).eval().to(dev)
+    cfg = {"tokenizer": {"width": 512, "video": {"tube": {"t": 2, "h": 4, "w": 4}}, "audio": {"chunk": {"length": 4, "stride": 4}}},
+           "video": {"fps": 16, "size": [32, 32], "latent": {"channels": 8, "t_down": 4, "s_down": 8}},
+           "audio": {"sr": 16000, "latent": {"channels": 8, "frames_per_clip": 150}},
+           "data": {"clip_seconds": 0.5},
+           "diffusion": {m: {"steps": 1000, "sampler_steps": 3, "schedule": "cosine", "min_beta": 1e-4, "max_beta": 0.02}
+                         for m in ("video", "audio")},
+           "sampling": {"ddim_eta": 0.0, "guidance_scale": {"video": 2.0, "audio": 2.0}}}
+    wav = (0.1 * torch.randn(48000, generator=torch.Generator().manual_seed(5))).numpy()
+    kw = dict(cfg=cfg, vid_vae=vae, aud_codec=codec, adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, device=dev)
+    torch.manual_seed(77)
+    res = A.sample_one_direction(prompt_modality="audio", prompt_video=None, prompt_audio=wav, **kw)
+    assert res["video"].shape == (8, 32, 32, 3) and res["video"].dtype == np.uint8 and res["fps"] == 16
+    # oracle pipeline on the same draw
+    Wc = {k: v.detach().cpu() for k, v in codec.state_dict().items()}
+    Wv = {k: v.detach().cpu() for k, v in vae.state_dict().items()}
+    torch.manual_seed(77)
+    z0 = torch.randn(1, 8, 2, 4, 4, device=dev).cpu()
+    z_a0 = R.codec_encode(torch.from_numpy(wav).view(1, 1, -1), Wc)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    zf = R.sample_a2v(z0, z_a0, R.sampling_schedule(1000, 3), abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"], core=ws["core"],
+                      head=ws["head"], n_layers=8, n_heads=8, guidance=2.0)
+    frames = (R.vae_decode(zf, Wv).clamp(0, 1)[0].permute(1, 2, 3, 0).numpy() * 255.0).astype(np.uint8)
+    diff = np.abs(frames.astype(np.int32) - res["video"].astype(np.int32))
+    assert diff.max() <= 1 and (diff > 0).mean() < 1e-3        # <= 1 LSB on >= 99.9 % of pixels (SURVEY §8c)
+    # V -> A with the layout the reference's comment intends
+    vid = (torch.rand(8, 32, 32, 3, generator=torch.Generator().manual_seed(6)) * 255).to(torch.uint8).numpy()
+    out = A.sample_one_direction(prompt_modality="video", prompt_video=vid, prompt_audio=None, **kw)
+    assert out["audio"].shape == (48000,) and out["sr"] == 16000 and np.isfinite(out["audio"]).all()
+    assert np.abs(out["audio"]).max() <= 1.0
+    with pytest.raises(ValueError):
+        A.sample_one_direction(prompt_modality="smell", prompt_video=None, prompt_audio=wav, **kw)

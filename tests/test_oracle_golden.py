@@ -161,3 +161,10 @@ def test_g12_vae_encode():
     W = split_weights(g)["w"]
     assert rel_err(R.vae_encode(T(g["x"]), W), g["z"]) < 1e-5
     assert rel_err(R.vae_encode(T(g["x_crop"])[:, :, 0:8, 1:17, 0:16], W), g["z_crop"]) < 1e-5
+
+
+def test_g13_audio_codec():
+    g = load_golden("g13_audio_codec.npz")
+    W = split_weights(g)["w"]
+    assert rel_err(R.codec_encode(T(g["wav"]), W), g["z"]) < 1e-5
+    assert rel_err(R.codec_decode(T(g["z_in"]), W), g["wav_out"]) < 1e-5

@@ -11,7 +11,7 @@ exits with a message (tests then rely on the committed fixtures alone).
 Fixture list: G1 schedules, G2 timestep embedding, G3 token index maps,
 G4 RMSNorm, G5 Block/MMDiT, G6 MultiModalNoiseHead, G7 ddim_step, G8 one CFG step both directions,
 G9 chained A->V via the reference's own ``sample_one_direction``, G10 TimestepEmbedder(mlp),
-G11 VideoVAE.decode, G12 VideoVAE.encode.
+G11 VideoVAE.decode, G12 VideoVAE.encode, G13 AudioCodec.
 """
 from __future__ import annotations
 
@@ -272,6 +272,20 @@ def main():
         z_crop = vae.encode(x_crop)
     enc_sd = {k: v for k, v in _sd(vae).items() if k.startswith(("enc_net", "to_lat"))}
     _save("g12_vae_encode.npz", x=_np(xx), z=_np(vae.encode(xx)), x_crop=_np(x_crop), z_crop=_np(z_crop), **_flat("w", enc_sd))
+
+    # ---- G13 AudioCodec encode / decode (next-2), shipped geometry: hop 320, 150 frames, 1 s and 3 s clips ------
+    from avdiff.models.encoders.audio_codec import AudioCodec
+    torch.manual_seed(13)
+    codec = AudioCodec.from_config({"sr": 16000, "latent": {"channels": 8, "frames_per_clip": 150},
+                                    "codec": {"hop_samples": 320, "hidden": 64, "smooth_kernel": 7}}).eval()
+    g = torch.Generator().manual_seed(14)
+    for name, p_ in codec.named_parameters():
+        if p_.dim() == 1:
+            p_.add_(0.05 * torch.randn(p_.shape, generator=g))
+    wav = 0.3 * torch.randn(2, 1, 16000, generator=g)
+    zc = torch.randn(2, 8, 10, generator=g)
+    _save("g13_audio_codec.npz", wav=_np(wav), z=_np(codec.encode(wav)), z_in=_np(zc), wav_out=_np(codec.decode(zc)),
+          **_flat("w", _sd(codec)))
 
     # ---- optional: full-size live comparison oracle vs reference --------------------------
     if args.full_size_report:
