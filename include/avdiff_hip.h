@@ -267,6 +267,15 @@ int avd_conv1d_act_f32(const float* x, const float* w, const float* bias, float*
  * x [rows, L] -> out [rows, Fa]. */
 int avd_avgpool_frames_f32(const float* x, float* out, int rows, int L, int Fa, int hop, avd_stream_t stream);
 
+/* ---- next-3: sliding-window stitching — avdiff/models/infer/stream_infer.py:85-116 (crossfade_audio),
+ * :119-143 (crossfade_video).  N windows of L positions x `inner` values placed every `hop` positions, weighted by
+ * w[L] (host-built fade table), divided by the summed weights clamped at 1e-6; out has (N-1)*hop + L positions.
+ * The u8 form divides by 255 on input and clips / scales / truncates to uint8 on output like the reference. */
+int avd_crossfade_f32(const float* chunks, const float* w, float* out, int N, int L, int hop, int64_t inner,
+                      avd_stream_t stream);
+int avd_crossfade_u8(const uint8_t* chunks, const float* w, uint8_t* out, int N, int L, int hop, int64_t inner,
+                     avd_stream_t stream);
+
 /* device-side sampling-schedule cursor so a captured step can be replayed without host writes:
  * t_now[b] = sched[*cursor], t_prev[b] = sched[*cursor+1] for all b, then (*cursor)++ . */
 int avd_sched_advance(const int64_t* sched, int n_sched, int32_t* cursor, int64_t* t_now, int64_t* t_prev,

@@ -111,6 +111,8 @@ SIGNATURES = {
     "avd_vae_encode_f32": (_I, [C.POINTER(VaeEncodeDesc), _P, _P, _P, _L, _P]),
     "avd_conv1d_act_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "avd_avgpool_frames_f32": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "avd_crossfade_f32": (_I, [_P, _P, _P, _I, _I, _I, _L, _P]),
+    "avd_crossfade_u8": (_I, [_P, _P, _P, _I, _I, _I, _L, _P]),
     "avd_prof_enable": (_I, [_I]),
     "avd_prof_num_tags": (_I, []),
     "avd_prof_tag_name": (C.c_char_p, [_I]),

@@ -1,0 +1,171 @@
+"""Sliding-window long-form generation — mirror of ``avdiff/models/infer/stream_infer.py``.
+
+The reference splits the prompt into windows (3 s window / 1 s hop), calls ``sample_one_direction`` once per window
+(B = 1, sequentially) and cross-fades the results on the host.  Windows are independent samples, so here they are one
+batch: the prompt windows are encoded together, ``DenoiseEngine`` steps all windows at once (they are the natural
+large-batch feed for the data-parallel path), the outputs are decoded together and stitched by a HIP kernel.
+
+``split_*`` are host-side slicing (as in the reference); the fade tables are built on the host with the reference's
+fp32 numpy expressions and uploaded; ``crossfade_*`` keep the reference's numpy-in / numpy-out signatures.
+File I/O and the CLI of the reference script are out of scope.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import schedule_utils as su
+from .sampler import DenoiseEngine
+
+
+def split_audio_into_windows(y: np.ndarray, sr: int, win_s: float, hop_s: float) -> Tuple[np.ndarray, int, int]:
+    """[L] -> [N, win] (last window zero-padded), stream_infer.py:40-58."""
+    n = len(y)
+    win, hop = int(round(sr * win_s)), int(round(sr * hop_s))
+    if n <= win:
+        return y[None, :], win, hop
+    starts = list(range(0, n, hop))
+    out = []
+    for s in starts:
+        seg = y[s:min(n, s + win)]
+        out.append(np.pad(seg, (0, win - len(seg))) if len(seg) < win else seg)
+        if s + win >= n:
+            break
+    return np.stack(out, axis=0), win, hop
+
+
+def split_frames_into_windows(frames: np.ndarray, fps: int, win_s: float, hop_s: float) -> Tuple[np.ndarray, int, int]:
+    """[T,H,W,3] -> [N, win, H, W, 3] (last window padded by repeating its last frame), stream_infer.py:61-82."""
+    n = frames.shape[0]
+    win, hop = int(round(fps * win_s)), int(round(fps * hop_s))
+    if n <= win:
+        return frames[None, ...], win, hop
+    out = []
+    for s in range(0, n, hop):
+        seg = frames[s:min(n, s + win)]
+        if seg.shape[0] < win:
+            seg = np.concatenate([seg, np.repeat(seg[-1:], win - seg.shape[0], axis=0)], axis=0)
+        out.append(seg)
+        if s + win >= n:
+            break
+    return np.stack(out, axis=0), win, hop
+
+
+def audio_fade_window(L_: int, fade: int) -> np.ndarray:
+    """Cosine fade-in / fade-out table (stream_infer.py:103-106); all ones for fade <= 0."""
+    w = np.ones(L_, dtype=np.float32)
+    if fade > 0:
+        w[:fade] = 0.5 * (1 - np.cos(np.linspace(0, np.pi, fade, dtype=np.float32)))
+        w[-fade:] = 0.5 * (1 + np.cos(np.linspace(0, np.pi, fade, dtype=np.float32)))
+    return w
+
+
+def video_fade_window(L_: int, fade: int) -> np.ndarray:
+    """Triangular ramp table in frames (stream_infer.py:130-137)."""
+    w = np.ones(L_, dtype=np.float32)
+    if fade > 0:
+        ramp = np.linspace(0, 1, fade, dtype=np.float32)
+        w[:fade] *= ramp
+        w[-fade:] *= ramp[::-1]
+    return w
+
+
+def crossfade_tensor(chunks: torch.Tensor, w: torch.Tensor, hop: int) -> torch.Tensor:
+    """chunks [N, L, ...] (float32 or uint8, on the device), w [L] -> [(N-1)*hop + L, ...]."""
+    if not chunks.is_cuda:
+        raise L.AvdError("crossfade needs ROCm device tensors (no CPU fallback)")
+    chunks = chunks.contiguous()
+    N, L_ = chunks.shape[:2]
+    inner = int(np.prod(chunks.shape[2:])) if chunks.dim() > 2 else 1
+    w = w.to(chunks.device, torch.float32).contiguous()
+    out = torch.empty((N - 1) * hop + L_, *chunks.shape[2:], device=chunks.device, dtype=chunks.dtype)
+    fn = L.lib().avd_crossfade_u8 if chunks.dtype == torch.uint8 else L.lib().avd_crossfade_f32
+    if chunks.dtype not in (torch.uint8, torch.float32):
+        raise TypeError("crossfade takes float32 or uint8 chunks")
+    L.check(fn(chunks.data_ptr(), w.data_ptr(), out.data_ptr(), N, L_, hop, inner, L.stream_ptr(chunks.device)))
+    return out
+
+
+def crossfade_audio(chunks: np.ndarray, sr: int, hop: int, win: int, fade_s: float, device="cuda") -> np.ndarray:
+    """[N, L] float32 -> stitched [ (N-1)*hop + L ] (stream_infer.py:85-116)."""
+    fade = int(round(sr * fade_s))
+    w = torch.from_numpy(audio_fade_window(chunks.shape[1], fade))
+    out = crossfade_tensor(torch.from_numpy(np.ascontiguousarray(chunks, dtype=np.float32)).to(device), w, hop)
+    return out.cpu().numpy()
+
+
+def crossfade_video(chunks: np.ndarray, hop: int, win: int, fade_f: int, device="cuda") -> np.ndarray:
+    """[N, T, H, W, 3] uint8 -> stitched [T_total, H, W, 3] uint8 (stream_infer.py:119-143)."""
+    w = torch.from_numpy(video_fade_window(chunks.shape[1], int(fade_f)))
+    out = crossfade_tensor(torch.from_numpy(np.ascontiguousarray(chunks)).to(device), w, hop)
+    return out.cpu().numpy()
+
+
+@torch.no_grad()
+def stream_generate(*, cfg: Dict, vid_vae, aud_codec, adapt_v, adapt_a, core, head, tstep_dim: int, prompt_modality: str,
+                    prompt_video: Optional[np.ndarray], prompt_audio: Optional[np.ndarray], device: torch.device,
+                    init_noise: Optional[torch.Tensor] = None, max_windows_per_batch: int = 32) -> Dict[str, np.ndarray]:
+    """The body of the reference's ``main()`` (stream_infer.py:146-225) minus file I/O, with all windows batched.
+
+    Returns {"audio": wav, "sr"} for a video prompt or {"video": frames uint8, "fps"} for an audio prompt.
+    ``init_noise`` [N_windows, *latent] fixes the initial latents (the reference draws them window by window).
+    """
+    st = cfg.get("streaming", {})
+    win_s, hop_s = float(st.get("window_seconds", 3.0)), float(st.get("hop_seconds", 1.0))
+    xfade_s = float(st.get("crossfade_seconds", 0.25))
+    fps, sr = int(cfg["video"]["fps"]), int(cfg["audio"]["sr"])
+    t_p, p = int(cfg["tokenizer"]["video"]["tube"]["t"]), int(cfg["tokenizer"]["video"]["tube"]["h"])
+    l_chunk, s_chunk = int(cfg["tokenizer"]["audio"]["chunk"]["length"]), int(cfg["tokenizer"]["audio"]["chunk"]["stride"])
+    Cv, t_down, s_down = (int(cfg["video"]["latent"][k]) for k in ("channels", "t_down", "s_down"))
+    Ca, Fa = int(cfg["audio"]["latent"]["channels"]), int(cfg["audio"]["latent"]["frames_per_clip"])
+    H, W = int(cfg["video"]["size"][0]), int(cfg["video"]["size"][1])
+    eta = float(cfg["sampling"].get("ddim_eta", 0.0))
+
+    if prompt_modality == "video":
+        if prompt_video is None:
+            raise ValueError("prompt_video frames required for prompt_modality=video")
+        chunks, win, hop = split_frames_into_windows(prompt_video, fps=fps, win_s=win_s, hop_s=hop_s)
+        frames = torch.from_numpy(np.ascontiguousarray(chunks)).to(device).float() / 255.0      # [N,T,H,W,3]
+        z_p = vid_vae.encode(frames.permute(0, 4, 1, 2, 3).contiguous())
+        target, lat = "audio", (Ca, Fa)
+        n_prompt = (z_p.shape[2] // t_p) * (z_p.shape[3] // p) * (z_p.shape[4] // p)
+        guide = float(cfg["sampling"]["guidance_scale"].get("audio", 3.0))
+    elif prompt_modality == "audio":
+        if prompt_audio is None:
+            raise ValueError("prompt_audio required for prompt_modality=audio")
+        chunks, win, hop = split_audio_into_windows(prompt_audio, sr=sr, win_s=win_s, hop_s=hop_s)
+        z_p = aud_codec.encode(torch.from_numpy(np.ascontiguousarray(chunks, dtype=np.float32)).to(device)[:, None, :])
+        T_in = int(round(cfg["data"]["clip_seconds"] * fps))
+        target, lat = "video", (Cv, max(1, T_in // t_down), H // s_down, W // s_down)
+        n_prompt = (z_p.shape[-1] - l_chunk) // s_chunk + 1
+        guide = float(cfg["sampling"]["guidance_scale"].get("video", 3.0))
+    else:
+        raise ValueError("prompt_modality must be 'video' or 'audio'")
+
+    c = cfg["diffusion"][target]
+    abar = su.alphas_cumprod_from_betas(su.make_beta_schedule(int(c["steps"]), kind=c["schedule"], min_beta=c["min_beta"],
+                                                              max_beta=c["max_beta"]))[1]
+    sched = su.make_sampling_schedule(int(c["steps"]), int(c["sampler_steps"]))
+    Nw = z_p.shape[0]
+    z0 = init_noise.to(device) if init_noise is not None else torch.randn(Nw, *lat, device=device)
+    outs = []
+    for lo in range(0, Nw, max_windows_per_batch):
+        hi = min(Nw, lo + max_windows_per_batch)
+        eng = DenoiseEngine(adapt_v=adapt_v, adapt_a=adapt_a, core=core, head=head, tstep_dim=tstep_dim, target=target,
+                            latent_shape=(hi - lo, *lat), prompt_tokens=n_prompt, alpha_bar=abar, guidance=guide, eta=eta,
+                            tube=(t_p, p, p), chunk=(l_chunk, s_chunk))
+        eng.set_prompt(z_p[lo:hi].float().contiguous())
+        outs.append(eng.run(z0[lo:hi].contiguous(), sched))
+    z = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+
+    if target == "audio":
+        wav = aud_codec.decode(z)[:, 0, :].contiguous()                       # [N, L]
+        w = torch.from_numpy(audio_fade_window(wav.shape[1], int(round(sr * xfade_s))))
+        return {"audio": crossfade_tensor(wav, w, int(round(sr * hop_s))).cpu().numpy(), "sr": sr}
+    x = vid_vae.decode(z).clamp(0, 1)                                         # [N,3,T,H,W]
+    frames_u8 = (x.permute(0, 2, 3, 4, 1) * 255.0).to(torch.uint8).contiguous()   # as the reference's astype(np.uint8)
+    w = torch.from_numpy(video_fade_window(frames_u8.shape[1], int(round(xfade_s * fps))))
+    return {"video": crossfade_tensor(frames_u8, w, int(round(fps * hop_s))).cpu().numpy(), "fps": fps}

@@ -497,3 +497,21 @@ def codec_decode(z: Tensor, W: Weights, hop: int = 320) -> Tensor:
     h = gelu_erf(conv1d(h, W["smooth.0.weight"], W["smooth.0.bias"], padding=pad))
     h = gelu_erf(conv1d(h, W["smooth.2.weight"], W["smooth.2.bias"], padding=pad))
     return torch.tanh(conv1d(h, W["smooth.4.weight"], W["smooth.4.bias"], padding=pad))
+
+
+# --------------------------------------------------------------------------------------
+# stream_infer stitching (stream_infer.py:85-143) — next-3.  numpy, fp32, same accumulation order.
+# --------------------------------------------------------------------------------------
+
+def crossfade(chunks, w, hop: int):
+    """chunks [N, L, ...] float32, w [L] -> weighted overlap-add / summed weights (clamped 1e-6)."""
+    import numpy as np
+    N, Lw = chunks.shape[:2]
+    shape = (Lw,) + (1,) * (chunks.ndim - 2)
+    y = np.zeros(((N - 1) * hop + Lw,) + chunks.shape[2:], dtype=np.float32)
+    nrm = np.zeros(((N - 1) * hop + Lw,) + (1,) * (chunks.ndim - 2), dtype=np.float32)
+    ww = w.astype(np.float32).reshape(shape)
+    for i in range(N):
+        y[i * hop:i * hop + Lw] += chunks[i] * ww
+        nrm[i * hop:i * hop + Lw] += ww
+    return (y / np.maximum(nrm, 1e-6)).astype(np.float32)

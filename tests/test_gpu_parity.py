@@ -540,3 +540,52 @@ def test_sample_one_direction_end_to_end(dev, full):
     assert np.abs(out["audio"]).max() <= 1.0
     with pytest.raises(ValueError):
         A.sample_one_direction(prompt_modality="smell", prompt_video=None, prompt_audio=wav, **kw)
+
+
+# ------------------------------------------------------------------------------------------------- stream_infer (next-3)
+def test_crossfade_golden_bit_exact(dev):
+    from multimodal_diffusion_amd import stream_infer as S
+    g = load_golden("g14_stream_stitch.npz")
+    assert np.array_equal(S.crossfade_audio(g["a_chunks"], sr=1000, hop=400, win=1000, fade_s=0.25, device=dev), g["a_fade"])
+    assert np.array_equal(S.crossfade_audio(g["a_chunks"], sr=1000, hop=400, win=1000, fade_s=0.0, device=dev), g["a_rect"])
+    assert np.array_equal(S.crossfade_video(g["v_chunks"], hop=4, win=12, fade_f=3, device=dev), g["v_fade"])
+    assert np.array_equal(S.crossfade_video(g["v_chunks"], hop=4, win=12, fade_f=0, device=dev), g["v_rect"])
+
+
+def test_stream_generate_equals_per_window_sampling(dev, full):
+    """All windows batched through one engine == the reference's per-window loop + cross-fade (same initial latents)."""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd import stream_infer as S
+    ws, (core, head, av, aa) = full
+    torch.manual_seed(8)
+    vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval().to(dev)
+    codec = A.AudioCodec.from_config({"sr": 16000, "latent": {"channels": 8, "frames_per_clip": 150},
+                                      "codec": {"hop_samples": 320}}).eval().to(dev)
+    cfg = {"tokenizer": {"width": 512, "video": {"tube": {"t": 2, "h": 4, "w": 4}}, "audio": {"chunk": {"length": 4, "stride": 4}}},
+           "video": {"fps": 16, "size": [32, 32], "latent": {"channels": 8, "t_down": 4, "s_down": 8}},
+           "audio": {"sr": 16000, "latent": {"channels": 8, "frames_per_clip": 150}},
+           "data": {"clip_seconds": 0.5}, "streaming": {"window_seconds": 0.5, "hop_seconds": 0.25, "crossfade_seconds": 0.125},
+           "diffusion": {m: {"steps": 1000, "sampler_steps": 2, "schedule": "cosine", "min_beta": 1e-4, "max_beta": 0.02}
+                         for m in ("video", "audio")},
+           "sampling": {"ddim_eta": 0.0, "guidance_scale": {"video": 2.0, "audio": 2.0}}}
+    wav = (0.1 * torch.randn(18000, generator=torch.Generator().manual_seed(9))).numpy()
+    kw = dict(cfg=cfg, vid_vae=vae, aud_codec=codec, adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, device=dev)
+    chunks, win, hop = S.split_audio_into_windows(wav, sr=16000, win_s=0.5, hop_s=0.25)
+    noise = torch.randn(chunks.shape[0], 8, 2, 4, 4, generator=torch.Generator().manual_seed(10))
+    out = S.stream_generate(prompt_modality="audio", prompt_video=None, prompt_audio=wav, init_noise=noise, **kw)
+    # per-window reference flow with the product's single-window entry point pieces
+    per = []
+    abar = A.schedule_utils.alphas_cumprod_from_betas(A.schedule_utils.make_beta_schedule(1000))[1]
+    sched = A.schedule_utils.make_sampling_schedule(1000, 2)
+    for i in range(chunks.shape[0]):
+        z_p = codec.encode(torch.from_numpy(chunks[i]).to(dev).view(1, 1, -1))
+        eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video",
+                              latent_shape=(1, 8, 2, 4, 4), prompt_tokens=37, alpha_bar=abar, guidance=2.0)
+        eng.set_prompt(z_p)
+        x = vae.decode(eng.run(noise[i:i + 1].to(dev), sched)).clamp(0, 1)
+        per.append((x[0].permute(1, 2, 3, 0).cpu().numpy() * 255.0).astype(np.uint8))
+    ref = R.crossfade(np.stack(per).astype(np.float32) / 255.0, S.video_fade_window(8, 2), 4)
+    ref = (np.clip(ref, 0, 1) * 255.0).astype(np.uint8)
+    assert out["video"].shape == ref.shape and out["fps"] == 16
+    d = np.abs(out["video"].astype(np.int32) - ref.astype(np.int32))
+    assert d.max() <= 1 and (d > 0).mean() < 1e-3

@@ -168,3 +168,19 @@ def test_g13_audio_codec():
     W = split_weights(g)["w"]
     assert rel_err(R.codec_encode(T(g["wav"]), W), g["z"]) < 1e-5
     assert rel_err(R.codec_decode(T(g["z_in"]), W), g["wav_out"]) < 1e-5
+
+
+def test_g14_stream_stitch_oracle_and_host_split():
+    """next-3: the cross-fade oracle and the product's host-side window splitting vs the reference's helpers."""
+    from multimodal_diffusion_amd import stream_infer as S
+    g = load_golden("g14_stream_stitch.npz")
+    assert np.array_equal(R.crossfade(g["a_chunks"], S.audio_fade_window(1000, 250), 400), g["a_fade"])
+    assert np.array_equal(R.crossfade(g["a_chunks"], S.audio_fade_window(1000, 0), 400), g["a_rect"])
+    v = R.crossfade(g["v_chunks"].astype(np.float32) / 255.0, S.video_fade_window(12, 3), 4)
+    assert np.array_equal((np.clip(v, 0, 1) * 255.0).astype(np.uint8), g["v_fade"])
+    sa, wa, ha = S.split_audio_into_windows(g["y_long"], sr=1000, win_s=3.0, hop_s=1.0)
+    sf, wf, hf = S.split_frames_into_windows(g["f_long"], fps=4, win_s=3.0, hop_s=1.0)
+    assert np.array_equal(sa, g["split_a"]) and np.array_equal(sf, g["split_f"])
+    assert [wa, ha, wf, hf] == list(g["split_meta"])
+    one, _, _ = S.split_audio_into_windows(g["y_long"][:100], sr=1000, win_s=3.0, hop_s=1.0)
+    assert one.shape == (1, 100)

@@ -11,7 +11,8 @@ exits with a message (tests then rely on the committed fixtures alone).
 Fixture list: G1 schedules, G2 timestep embedding, G3 token index maps,
 G4 RMSNorm, G5 Block/MMDiT, G6 MultiModalNoiseHead, G7 ddim_step, G8 one CFG step both directions,
 G9 chained A->V via the reference's own ``sample_one_direction``, G10 TimestepEmbedder(mlp),
-G11 VideoVAE.decode, G12 VideoVAE.encode, G13 AudioCodec.
+G11 VideoVAE.decode, G12 VideoVAE.encode, G13 AudioCodec,
+G14 stream_infer splitting / cross-fade stitching.
 """
 from __future__ import annotations
 
@@ -286,6 +287,28 @@ def main():
     zc = torch.randn(2, 8, 10, generator=g)
     _save("g13_audio_codec.npz", wav=_np(wav), z=_np(codec.encode(wav)), z_in=_np(zc), wav_out=_np(codec.decode(zc)),
           **_flat("w", _sd(codec)))
+
+    # ---- G14 stream_infer stitching (next-3).  The reference module imports `avdiff.infer.sample_clip`, a path that
+    # does not exist in its own tree (the package lives at avdiff.models.infer — SURVEY §0.3); alias the package name
+    # it asks for to the one that exists so its pure-numpy helpers can be driven unmodified.
+    import avdiff.models.infer as _infer_pkg
+    import avdiff.models.infer.sample_clip as _sc_mod
+    sys.modules.setdefault("avdiff.infer", _infer_pkg)
+    sys.modules.setdefault("avdiff.infer.sample_clip", _sc_mod)
+    from avdiff.models.infer import stream_infer as si
+    rng = np.random.default_rng(15)
+    a_chunks = rng.standard_normal((4, 1000)).astype(np.float32)
+    v_chunks = rng.integers(0, 256, size=(3, 12, 4, 5, 3), dtype=np.uint8)
+    y_long = rng.standard_normal(7300).astype(np.float32)
+    f_long = rng.integers(0, 256, size=(23, 2, 2, 3), dtype=np.uint8)
+    sa, wa, ha = si.split_audio_into_windows(y_long, sr=1000, win_s=3.0, hop_s=1.0)
+    sf, wf, hf = si.split_frames_into_windows(f_long, fps=4, win_s=3.0, hop_s=1.0)
+    _save("g14_stream_stitch.npz", a_chunks=a_chunks, v_chunks=v_chunks,
+          a_fade=si.crossfade_audio(a_chunks, sr=1000, hop=400, win=1000, fade_s=0.25),
+          a_rect=si.crossfade_audio(a_chunks, sr=1000, hop=400, win=1000, fade_s=0.0),
+          v_fade=si.crossfade_video(v_chunks, hop=4, win=12, fade_f=3),
+          v_rect=si.crossfade_video(v_chunks, hop=4, win=12, fade_f=0),
+          y_long=y_long, f_long=f_long, split_a=sa, split_f=sf, split_meta=np.array([wa, ha, wf, hf]))
 
     # ---- optional: full-size live comparison oracle vs reference --------------------------
     if args.full_size_report:
