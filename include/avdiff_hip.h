@@ -135,6 +135,8 @@ typedef struct {
     int p0, p1, p2;
     int Nt, Np;
     const float* temb_freqs;   /* optional device table [tdim/2], see avd_timestep_embedding_f32; may be NULL */
+    int temb_add;              /* 0: concat [adapter(d-tdim) | temb(tdim)] as the sampler (sample_clip.py:59-70);
+                                  1: adapter(d) + temb(d) as the trainer (train/trainer.py:45-49); needs tdim == d */
 } avd_embed_desc;
 /* floats of scratch `tok_ws` must hold (tokens + the [B,tdim] timestep embedding); -1 on a bad descriptor */
 int64_t avd_embed_workspace_floats(const avd_embed_desc* desc);

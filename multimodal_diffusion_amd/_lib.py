@@ -28,7 +28,7 @@ class EmbedDesc(C.Structure):
     _fields_ = [("target_kind", C.c_int), ("target_first", C.c_int), ("B", C.c_int), ("d", C.c_int),
                 ("tdim", C.c_int), ("C", C.c_int), ("T", C.c_int), ("H", C.c_int), ("W", C.c_int),
                 ("p0", C.c_int), ("p1", C.c_int), ("p2", C.c_int), ("Nt", C.c_int), ("Np", C.c_int),
-                ("temb_freqs", C.c_void_p)]
+                ("temb_freqs", C.c_void_p), ("temb_add", C.c_int)]
 
 
 class BlockWeights(C.Structure):

@@ -149,7 +149,9 @@ static int head_forward(const avd_head_weights* w, const float* h, RowMap hm, in
 // ---------------------------------------------------------------- fused front end
 static int check_embed(const avd_embed_desc* e) {
     AVD_REQUIRE(e, AVD_EINVAL, "embed: null descriptor");
-    AVD_REQUIRE(e->B > 0 && e->d > 0 && e->tdim >= 0 && e->tdim < e->d, AVD_EINVAL, "embed: bad widths");
+    AVD_REQUIRE(e->B > 0 && e->d > 0 && e->tdim >= 0, AVD_EINVAL, "embed: bad widths");
+    AVD_REQUIRE(e->temb_add ? e->tdim == e->d : e->tdim < e->d, AVD_EINVAL,
+                "embed: timestep width %d does not fit token width %d in %s mode", e->tdim, e->d, e->temb_add ? "add" : "concat");
     AVD_REQUIRE(e->d % 4 == 0 && e->tdim % 4 == 0, AVD_EUNSUPPORTED, "embed: d and tdim must be multiples of 4");
     AVD_REQUIRE(e->Nt > 0 && e->Np >= 0, AVD_EINVAL, "embed: bad token counts");
     if (e->target_kind == 0) {
@@ -183,12 +185,19 @@ static int embed_cfg_pair(const avd_embed_desc* e, const float* z, const float* 
     } else {
         if (int rc = audio_tokens_f32(z, tok, B, e->C, e->T, e->p0, e->p1, st)) return rc;
     }
+    if (e->tdim > 0)
+        if (int rc = temb_f32(t_now, e->temb_freqs, temb, B, e->tdim, 10000.f, st)) return rc;
     // adapter GEMM straight into the cond half's target rows (segmented C: one segment per sample)
     float* c0 = X2 + (e->target_first ? 0 : (int64_t)e->Np * d);
     const RowMap cm{d, e->Nt, (int64_t)N * d};
+    if (e->temb_add) {
+        // trainer-style embedding (train/trainer.py:45-49): tokens + temb, both d wide.  The per-sample embedding row is
+        // the GEMM's residual operand through a row map with zero row stride (one segment of Nt rows per sample).
+        const RowMap rm{0, e->Nt, (int64_t)e->tdim};
+        if (int rc = gemm_f32(tok, RowMap{D, 0, 0}, Wt, bt, temb, rm, c0, cm, (int64_t)B * e->Nt, d, D, AVD_ACT_NONE, st)) return rc;
+        return assemble_f32(X2, temb, Xp, B, N, d, 0, e->Nt, e->Np, e->target_first, st);
+    }
     if (int rc = gemm_f32(tok, RowMap{D, 0, 0}, Wt, bt, nullptr, cm, c0, cm, (int64_t)B * e->Nt, d - e->tdim, D, AVD_ACT_NONE, st)) return rc;
-    if (e->tdim > 0)
-        if (int rc = temb_f32(t_now, e->temb_freqs, temb, B, e->tdim, 10000.f, st)) return rc;
     return assemble_f32(X2, temb, Xp, B, N, d, e->tdim, e->Nt, e->Np, e->target_first, st);
 }
 

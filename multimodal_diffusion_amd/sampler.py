@@ -103,17 +103,21 @@ class DenoiseEngine:
 
     def __init__(self, *, adapt_v: LinearAdapter, adapt_a: LinearAdapter, core: MMDiT, head: MultiModalNoiseHead,
                  tstep_dim: int, target: str, latent_shape: Tuple[int, ...], prompt_tokens: int, alpha_bar: torch.Tensor,
-                 guidance: float, eta: float = 0.0, tube=(2, 4, 4), chunk=(4, 4), split_streams: bool = False):
+                 guidance: float, eta: float = 0.0, tube=(2, 4, 4), chunk=(4, 4), split_streams: bool = False,
+                 temb_mode: str = "concat"):
         if target not in ("video", "audio"):
             raise ValueError("target must be 'video' or 'audio'")
         if eta < 0:
             raise ValueError("eta must be >= 0")
+        if temb_mode not in ("concat", "add"):
+            raise ValueError("temb_mode must be 'concat' (sampler, sample_clip.py:59-70) or 'add' (trainer, trainer.py:45-49)")
+        self.temb_mode = temb_mode
         self.target = target
         self.core, self.head = core, head
         self.adapt_t = adapt_v if target == "video" else adapt_a
         self.adapt_p = adapt_a if target == "video" else adapt_v
-        self.tdim = int(tstep_dim)
         self.d = core.cfg.d_model
+        self.tdim = self.d if temb_mode == "add" else int(tstep_dim)     # the trainer embeds at token width
         self.tube, self.chunk = tuple(tube), tuple(chunk)
         self.guidance, self.eta = float(guidance), float(eta)
         self.device = core.final_norm.scale.device
@@ -141,6 +145,10 @@ class DenoiseEngine:
         e.Np = int(prompt_tokens)
         self._freqs = Fn.temb_freqs(self.tdim, 10000, self.device) if self.tdim >= 2 else None
         e.temb_freqs = L.ptr(self._freqs)
+        e.temb_add = 1 if temb_mode == "add" else 0
+        w_out = self.adapt_t.proj.weight.shape[0]
+        if w_out != (self.d if temb_mode == "add" else self.d - self.tdim):
+            raise ValueError(f"adapter width {w_out} does not match temb_mode='{temb_mode}' (d={self.d}, tdim={self.tdim})")
         self.embed = e
         self.N = e.Nt + e.Np
         self.alpha_bar = alpha_bar.to(self.device, torch.float32).contiguous()
@@ -177,12 +185,20 @@ class DenoiseEngine:
         d, td = self.d, self.tdim
         Xp = torch.empty(B, tok.shape[1], d, device=self.device, dtype=torch.float32)
         w, b = self.adapt_p.proj.weight.detach(), self.adapt_p.proj.bias.detach()
-        # GEMM writes straight into the first d-tdim columns (ldc = d)
-        L.check(L.lib().avd_gemm_bias_act_f32(tok.data_ptr(), tok.shape[2], L.dev_f32(w).data_ptr(), L.dev_f32(b).data_ptr(),
-                                              None, 0, Xp.data_ptr(), d, B * tok.shape[1], d - td, tok.shape[2],
-                                              L.ACT_NONE, L.stream_ptr(self.device)))
-        if td:
-            Xp[..., d - td:] = su.timestep_embedding(torch.zeros(B, dtype=torch.long, device=self.device), td)[:, None, :]
+        t0 = su.timestep_embedding(torch.zeros(B, dtype=torch.long, device=self.device), td) if td else None
+        if self.temb_mode == "add":
+            # adapter(tok) + temb(0): the broadcast embedding rides in as the GEMM's residual operand
+            res = t0[:, None, :].expand(B, tok.shape[1], d).contiguous()
+            L.check(L.lib().avd_gemm_bias_act_f32(tok.data_ptr(), tok.shape[2], L.dev_f32(w).data_ptr(), L.dev_f32(b).data_ptr(),
+                                                  res.data_ptr(), d, Xp.data_ptr(), d, B * tok.shape[1], d, tok.shape[2],
+                                                  L.ACT_NONE, L.stream_ptr(self.device)))
+        else:
+            # GEMM writes straight into the first d-tdim columns (ldc = d)
+            L.check(L.lib().avd_gemm_bias_act_f32(tok.data_ptr(), tok.shape[2], L.dev_f32(w).data_ptr(), L.dev_f32(b).data_ptr(),
+                                                  None, 0, Xp.data_ptr(), d, B * tok.shape[1], d - td, tok.shape[2],
+                                                  L.ACT_NONE, L.stream_ptr(self.device)))
+            if td:
+                Xp[..., d - td:] = t0[:, None, :]
         self.Xp = Xp
         return Xp
 

@@ -245,8 +245,11 @@ def timestep_mlp(t: Tensor, W: Weights, dim: int) -> Tensor:
 # one CFG denoising step, batched (sample_clip.py loop bodies)
 # --------------------------------------------------------------------------------------
 
-def embed_with_time(tok: Tensor, w: Tensor, b: Tensor, t: Tensor, tdim: int) -> Tensor:
+def embed_with_time(tok: Tensor, w: Tensor, b: Tensor, t: Tensor, tdim: int, mode: str = "concat") -> Tensor:
+    """mode "concat": sampler (sample_clip.py:59-70); "add": trainer (train/trainer.py:45-49, embedding at token width)."""
     x = linear(tok, w, b)
+    if mode == "add":
+        return x + timestep_embedding(t, x.shape[-1], dtype=x.dtype)[:, None, :]
     e = timestep_embedding(t, tdim, dtype=x.dtype)[:, None, :].expand(-1, x.shape[1], -1)
     return torch.cat([x, e], dim=-1)
 
@@ -268,13 +271,13 @@ def eps_pair(Xt: Tensor, Xp: Tensor, target_first: bool, core: Weights, head: We
 def denoise_step_a2v(z_v: Tensor, z_a0: Tensor, t_now: Tensor, t_prev: Tensor, alpha_bar: Tensor, *,
                      adapt_v: Weights, adapt_a: Weights, core: Weights, head: Weights,
                      n_layers: int, n_heads: int, tdim: int = 256, tube=(2, 4, 4), chunk=(4, 4),
-                     guidance: float = 3.5, eta: float = 0.0, return_eps: bool = False):
+                     guidance: float = 3.5, eta: float = 0.0, return_eps: bool = False, temb_mode: str = "concat"):
     """Audio prompt -> video target (sample_clip.py:359-389), any batch size."""
     B, C, T, H, Wd = z_v.shape
     tok_v = tube_patch(z_v, *tube)
     tok_a = audio_tokens(z_a0, *chunk)
-    Xv = embed_with_time(tok_v, adapt_v["proj.weight"], adapt_v["proj.bias"], t_now, tdim)
-    Xa = embed_with_time(tok_a, adapt_a["proj.weight"], adapt_a["proj.bias"], torch.zeros_like(t_now), tdim)
+    Xv = embed_with_time(tok_v, adapt_v["proj.weight"], adapt_v["proj.bias"], t_now, tdim, temb_mode)
+    Xa = embed_with_time(tok_a, adapt_a["proj.weight"], adapt_a["proj.bias"], torch.zeros_like(t_now), tdim, temb_mode)
     e_c, e_n = eps_pair(Xv, Xa, True, core, head, "video", n_layers, n_heads)
     eps_tok = e_n + guidance * (e_c - e_n)
     eps_lat = tube_unpatch(eps_tok, C, T, H, Wd, *tube)

@@ -356,6 +356,30 @@ def test_full_step_v2a_vs_oracle(dev, full):
     assert rel_err(eng.step(z_a.to(dev), tn.to(dev), tp.to(dev)).cpu(), ref) < TOL
 
 
+def test_trainer_style_add_embedding(dev, full):
+    """next-4: adapters of width d with the timestep embedding ADDED (train/trainer.py:45-49) instead of concatenated."""
+    import multimodal_diffusion_amd as A
+    ws, (core, head, _, _) = full
+    g = torch.Generator().manual_seed(21)
+    B = 2
+    av, aa = A.LinearAdapter(256, 512), A.LinearAdapter(32, 512)
+    Wav = {k: v.detach().clone() for k, v in av.state_dict().items()}
+    Waa = {k: v.detach().clone() for k, v in aa.state_dict().items()}
+    z_v = torch.randn(B, 8, 12, 8, 8, generator=g)
+    z_a = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn, tp = torch.tensor([982, 500]), torch.tensor([966, 480])
+    ref = R.denoise_step_a2v(z_v, z_a, tn, tp, abar, adapt_v=Wav, adapt_a=Waa, core=ws["core"], head=ws["head"], n_layers=8,
+                             n_heads=8, guidance=3.0, temb_mode="add")
+    eng = A.DenoiseEngine(adapt_v=av.to(dev), adapt_a=aa.to(dev), core=core, head=head, tstep_dim=256, target="video",
+                          latent_shape=tuple(z_v.shape), prompt_tokens=37, alpha_bar=abar, guidance=3.0, temb_mode="add")
+    eng.set_prompt(z_a.to(dev))
+    assert rel_err(eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)).cpu(), ref) < TOL
+    with pytest.raises(ValueError):      # concat-mode engine refuses d-wide adapters
+        A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video",
+                        latent_shape=tuple(z_v.shape), prompt_tokens=37, alpha_bar=abar, guidance=3.0)
+
+
 def test_bench_size_properties(dev, full):
     """BASELINE config C3 at full size (256², B=32): properties that need no oracle run.
     - determinism: two runs are bit-identical

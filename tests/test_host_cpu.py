@@ -145,3 +145,40 @@ def test_bench_flop_model_matches_survey():
         nv = 6 * (size // 32) ** 2
         got = bench.step_flops_per_sample(nv, 37) / 1e9
         assert abs(got - want) / want < 2e-3, (size, got, want)
+
+
+def test_checkpoint_interop(tmp_path, small_model):
+    """next-4: both checkpoint layouts of the reference load; the trainer layout reports its embedding mode."""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd import checkpoint as CK
+    _, W, meta = small_model
+
+    def fresh(adapter_out):
+        core = A.MMDiT(d_model=meta["d"], n_layers=meta["n_layers"], n_heads=meta["n_heads"], mlp_ratio=meta["mlp_ratio"])
+        head = A.MultiModalNoiseHead({"video": 128, "audio": 128}, {"video": 256, "audio": 32}, hidden_dim=64)
+        return dict(core=core, head=head, adapt_v=A.LinearAdapter(256, adapter_out), adapt_a=A.LinearAdapter(32, adapter_out))
+
+    # (1) sampler layout: {name}_state_dict (sample_clip.py:122-126)
+    mods = fresh(64)
+    p1 = tmp_path / "sampler.pt"
+    torch.save({f"{k}_state_dict": W[k] for k in ("core", "head", "adapt_v", "adapt_a")}, p1)
+    CK.load_checkpoint_maybe({"paths": {"ckpt_path": str(p1)}}, mods)
+    assert torch.equal(mods["core"].state_dict()["blocks.0.mlp.fc1.weight"], W["core"]["blocks.0.mlp.fc1.weight"])
+    CK.load_checkpoint_maybe({"paths": {}}, mods)                                # no path: random weights, no error
+    with pytest.raises(FileNotFoundError):
+        CK.load_checkpoint_maybe({"paths": {"ckpt_path": str(tmp_path / "nope.pt")}}, mods)
+
+    # (2) trainer layout (trainer.py:407-423): d-wide adapters (add-mode), DDP prefixes, EMA of the core
+    mods = fresh(128)
+    ema = {k: v * 0.5 for k, v in W["core"].items()}
+    tr = {"step": 1234, "core": {f"module.{k}": v for k, v in W["core"].items()}, "head": W["head"],
+          "adapt_v": {"proj.weight": torch.randn(128, 256), "proj.bias": torch.zeros(128)},
+          "adapt_a": {"proj.weight": torch.randn(128, 32), "proj.bias": torch.zeros(128)}, "opt": {}, "ema": ema}
+    p2 = tmp_path / "trainer.pt"
+    torch.save(tr, p2)
+    info = CK.load_trainer_checkpoint(p2, mods)
+    assert info == {"step": 1234, "loaded": ["adapt_v", "adapt_a", "core", "head"], "temb_mode": "add"}
+    assert torch.equal(mods["core"].state_dict()["final_norm.scale"], W["core"]["final_norm.scale"])
+    CK.load_trainer_checkpoint(p2, mods, use_ema=True)
+    assert torch.equal(mods["core"].state_dict()["final_norm.scale"], ema["final_norm.scale"])
+    assert CK.load_trainer_checkpoint(tr, fresh(64) | {"adapt_v": None, "adapt_a": None})["temb_mode"] is None
