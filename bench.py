@@ -115,12 +115,21 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse N > 1 on a 1-GPU box)")
+    ap.add_argument("--share-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (with --backend gloo)")
     args = ap.parse_args()
 
     from multimodal_diffusion_amd import dist as D, schedule_utils as su, _lib as L
     import multimodal_diffusion_amd as A
 
-    rank, world, local = D.init_from_env("nccl" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else None)
+    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if multi and args.backend == "nccl" and not args.share_device:
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world, local = D.init_from_env(args.backend if multi else None)
+    if args.share_device:
+        local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
@@ -138,7 +147,7 @@ def main():
     # conditioning: root draws the global batch of prompt latents, ONE broadcast, each rank keeps its shard
     gshape = (B * world, 8, 150)
     cond = torch.randn(gshape, generator=torch.Generator().manual_seed(2)) if rank == 0 else None
-    cond_all = D.broadcast_conditioning(cond, gshape, dev)
+    cond_all = D.broadcast_conditioning(cond, gshape, dev if args.backend == "nccl" else torch.device("cpu")).to(dev)
     z_a0 = D.local_conditioning(cond_all, rank, world)
     z0 = torch.randn(lat, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
 
@@ -188,7 +197,7 @@ def main():
     run_steps(args.steps)
     torch.cuda.synchronize()
     D.barrier()
-    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev if args.backend == "nccl" else torch.device("cpu"))
     assert torch.isfinite(za).all(), "non-finite latent after the timed region"
 
     out = None

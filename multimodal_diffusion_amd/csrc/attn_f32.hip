@@ -55,7 +55,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_f32_kernel(const float* __res
     const float* kp = base + d;
     const float* vp = base + 2 * d;
 
-    // ---- Q fragment: lane (q = l31, half hi) holds Q[q][32*hi + s], s = 0..31, pre-scaled ----
+    // ---- Q fragment: lane (q = l31, half hi) holds Q[q][32*hi + s], s = 0..31, pre-scaled by scale*log2(e) so the
+    //      scores come out of the MFMA already in the exp2 domain (one multiply per score saved in the softmax) ----
+    scale *= LOG2E;
     const int q_row = qb * (NW * 32) + wave * 32 + l31;
     float qf[32];
     {
@@ -150,18 +152,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_f32_kernel(const float* __res
         for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s1[r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f((s0[r] - m_new) * LOG2E);
-            s1[r] = __builtin_amdgcn_exp2f((s1[r] - m_new) * LOG2E);
+            s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
             ps += s0[r] + s1[r];
         }
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
+        if (__any(m_new > m_run)) {          // wave-uniform: skip the O rescale when no row's running max moved
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+        l_run += ps;
+        m_run = m_new;
 
         // ---- O^T += V^T · P^T ; step s consumes key row kappa(s,hi) of each 32-key half (reads Vs only) ----
 #pragma unroll

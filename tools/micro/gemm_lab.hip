@@ -120,7 +120,7 @@ void run(const char* name, const float* A, const float* W, float* C, int M, int 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-template <int BM, int BN, int WM, int WN, int EPI, int WPS, int ILV = 0>
+template <int BM, int BN, int WM, int WN, int EPI, int WPS, int ILV = 0, int PIPE = 0>
 __global__ __launch_bounds__(256, WPS) void kd(const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
                                               float* __restrict__ C, int M, int N, int K, int nbn) {
     constexpr int BK = 32;
@@ -187,6 +187,7 @@ __global__ __launch_bounds__(256, WPS) void kd(const float* __restrict__ A, cons
         float* nas = smem + (cur ^ 1) * STAGE;
         float* nbs = nas + BM * BK;
         const int k1 = (kt + 1) * BK;
+        if (PIPE == 0) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
             f32x4 af[TM], bf[TN];
@@ -201,13 +202,56 @@ __global__ __launch_bounds__(256, WPS) void kd(const float* __restrict__ A, cons
 #pragma unroll
                     for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
                 if (ILV == 1 && more) {
-                    // one DMA piece after each MFMA group of the first kk steps: its issue hides under the matrix pipe
                     const int pi = kk * 4 + s;
                     if (pi < A_PIECES)
                         __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[pi] + k1), LDS_PTR(nas + (wave + 4 * pi) * 8 * BK), 16, 0, 0);
                     else if (pi < A_PIECES + B_PIECES)
                         __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[pi - A_PIECES] + k1), LDS_PTR(nbs + (wave + 4 * (pi - A_PIECES)) * 8 * BK), 16, 0, 0);
                 }
+            }
+        }
+        } else if (PIPE == 2) {
+            // all 16 fragment reads of the K tile up front (one exposed LDS latency per K tile, +48 VGPRs)
+            f32x4 af[4][TM], bf[4][TN];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[kk][i] = *reinterpret_cast<const f32x4*>(as + a_row[i] + (((2 * kk + hi) ^ a_sw[i]) << 2));
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[kk][j] = *reinterpret_cast<const f32x4*>(bs + b_row[j] + (((2 * kk + hi) ^ b_sw[j]) << 2));
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk][i][s], bf[kk][j][s], acc[i][j], 0, 0, 0);
+        } else {
+            // fragments for step kk+1 are requested BEFORE step kk's MFMAs: only the first read of a K tile is exposed
+            f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(as + a_row[i] + (((0 + hi) ^ a_sw[i]) << 2));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(bs + b_row[j] + (((0 + hi) ^ b_sw[j]) << 2));
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (kk < 3) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = *reinterpret_cast<const f32x4*>(as + a_row[i] + (((2 * (kk + 1) + hi) ^ a_sw[i]) << 2));
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bf[(kk + 1) & 1][j] = *reinterpret_cast<const f32x4*>(bs + b_row[j] + (((2 * (kk + 1) + hi) ^ b_sw[j]) << 2));
+                    __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);   // DS reads first ...
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i][s], bf[kk & 1][j][s], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, 4 * TM * TN, 0);         // ... then this step's MFMAs
             }
         }
         __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): next stage landed
@@ -253,12 +297,128 @@ __global__ __launch_bounds__(256, WPS) void kd(const float* __restrict__ A, cons
     }
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int WPS, int ILV = 0>
+
+// kd3: as kd (scalar epilogue) but a 3-deep LDS ring with a COUNTED vmcnt: tile k+2 is issued before tile k's MFMAs,
+// the end-of-tile wait only retires tile k+1 (the newest tile's DMA stays in flight across the raw s_barrier).
+template <int BM, int BN, int WM, int WN, int WPS>
+__global__ __launch_bounds__(256, WPS) void kd3(const float* __restrict__ A, const float* __restrict__ W, float* __restrict__ C,
+                                               int M, int N, int K, int nbn) {
+    constexpr int BK = 32;
+    constexpr int WAVES_N = BN / WN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int A_PIECES = BM / 32, B_PIECES = BN / 32;
+    constexpr int STAGE = (BM + BN) * BK;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nwg = gridDim.x;
+    int wg;
+    { const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7; wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3); }
+    const int bm = wg / nbn, bn = wg % nbn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int r8 = lane >> 3, pc = lane & 7;
+    const float* a_src[A_PIECES]; const float* b_src[B_PIECES];
+#pragma unroll
+    for (int i = 0; i < A_PIECES; ++i) {
+        const int trow = (wave + 4 * i) * 8 + r8;
+        int row = bm * BM + trow; row = row < M ? row : M - 1;
+        a_src[i] = A + (size_t)row * K + ((pc ^ ((trow >> 1) & 7)) << 2);
+    }
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) {
+        const int trow = (wave + 4 * i) * 8 + r8;
+        int n = bn * BN + trow; n = n < N ? n : N - 1;
+        b_src[i] = W + (size_t)n * K + ((pc ^ ((trow >> 1) & 7)) << 2);
+    }
+    auto stage = [&](int kt, int buf) {
+        float* as = smem + buf * STAGE;
+        float* bs = as + BM * BK;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(a_src[i] + k0), LDS_PTR(as + (wave + 4 * i) * 8 * BK), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[i] + k0), LDS_PTR(bs + (wave + 4 * i) * 8 * BK), 16, 0, 0);
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = K / BK;
+    stage(0, 0);
+    if (nk > 1) stage(1, 1);
+    // retire tile 0, leave tile 1 in flight: vmcnt(A_PIECES + B_PIECES)
+    if (nk > 1) __builtin_amdgcn_s_waitcnt(0x0f70 | (A_PIECES + B_PIECES)); else __builtin_amdgcn_s_waitcnt(0x0f70);
+    __builtin_amdgcn_s_barrier();
+    int a_row[TM], a_sw[TM], b_row[TN], b_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { const int r = wm * WM + i * 32 + l31; a_row[i] = r * BK; a_sw[i] = (r >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { const int r = wn * WN + j * 32 + l31; b_row[j] = r * BK; b_sw[j] = (r >> 1) & 7; }
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        int nxt2 = cur + 2; if (nxt2 >= 3) nxt2 -= 3;
+        if (kt + 2 < nk) stage(kt + 2, nxt2);
+        const float* as = smem + cur * STAGE;
+        const float* bs = as + BM * BK;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + a_row[i] + (((2 * kk + hi) ^ a_sw[i]) << 2));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + b_row[j] + (((2 * kk + hi) ^ b_sw[j]) << 2));
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+        }
+        // tile kt+1 must have landed; tile kt+2 (just issued) may stay in flight
+        if (kt + 2 < nk) __builtin_amdgcn_s_waitcnt(0x0f70 | (A_PIECES + B_PIECES)); else __builtin_amdgcn_s_waitcnt(0x0f70);
+        __builtin_amdgcn_s_barrier();
+        cur = cur + 1 == 3 ? 0 : cur + 1;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = bn * BN + wn * WN + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = bm * BM + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (m < M && n < N) C[(size_t)m * N + n] = acc[i][j][r];
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN, int WPS>
+void rund3(const char* name, const float* A, const float* W, float* C, int M, int N, int K) {
+    const int lds = 3 * (BM + BN) * 32 * 4;
+    auto kern = kd3<BM, BN, WM, WN, WPS>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 5; ++i) kern<<<nbm * nbn, 256, lds>>>(A, W, C, M, N, K, nbn);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    const int it = 20;
+    for (int i = 0; i < it; ++i) kern<<<nbm * nbn, 256, lds>>>(A, W, C, M, N, K, nbn);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= it;
+    printf("%-36s M=%d N=%d K=%d lds=%d: %8.1f us %7.1f TF\n", name, M, N, K, lds, ms * 1e3, 2.0 * M * N * K / ms / 1e9);
+}
+
+template <int BM, int BN, int WM, int WN, int EPI, int WPS, int ILV = 0, int PIPE = 0>
 void rund(const char* name, const float* A, const float* W, float* C, int M, int N, int K) {
     int lds = 2 * (BM + BN) * 32 * 4;
     const int epi_lds = 4 * WM * (WN + 4) * 4;
     if (EPI && epi_lds > lds) lds = epi_lds;
-    auto kern = kd<BM, BN, WM, WN, EPI, WPS, ILV>;
+    auto kern = kd<BM, BN, WM, WN, EPI, WPS, ILV, PIPE>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int nbm = (M + BM - 1) / BM, nbn = (N + BN - 1) / BN;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -324,7 +484,15 @@ int main(int argc, char** argv) {
         rund<128, 128, 64, 64, 0, 2>("GLDS 128x128 scalar-epi", A, W, C, M, N, K);
         rund<128, 128, 64, 64, 1, 2>("GLDS 128x128 lds-epi+bias", A, W, C, M, N, K);
         rund<128, 128, 64, 64, 1, 2, 1>("GLDS 128x128 lds-epi ILV", A, W, C, M, N, K);
+        rund<128, 128, 64, 64, 1, 2, 0, 1>("GLDS 128x128 lds-epi PIPE", A, W, C, M, N, K);
+        rund<128, 128, 64, 64, 1, 2, 0, 2>("GLDS 128x128 lds-epi ALLFRAG", A, W, C, M, N, K);
+        rund<128, 64, 64, 32, 1, 2, 0, 2>("GLDS 128x64 lds-epi ALLFRAG", A, W, C, M, N, K);
+        rund<128, 64, 64, 32, 1, 2, 0, 1>("GLDS 128x64 lds-epi PIPE", A, W, C, M, N, K);
         rund<128, 64, 64, 32, 1, 2, 1>("GLDS 128x64 lds-epi ILV", A, W, C, M, N, K);
+        rund<128, 64, 64, 32, 0, 2>("GLDS 128x64 scalar-epi (2 stage)", A, W, C, M, N, K);
+        rund3<128, 64, 64, 32, 2>("GLDS3 128x64 3-stage counted vmcnt", A, W, C, M, N, K);
+        rund3<64, 64, 32, 32, 4>("GLDS3 64x64 3-stage counted vmcnt", A, W, C, M, N, K);
+        rund3<128, 128, 64, 64, 1>("GLDS3 128x128 3-stage (1 blk/CU)", A, W, C, M, N, K);
         rund<128, 64, 64, 32, 1, 2>("GLDS 128x64 lds-epi+bias", A, W, C, M, N, K);
         rund<64, 64, 32, 32, 1, 4>("GLDS 64x64 lds-epi+bias", A, W, C, M, N, K);
         run<128, 128, 64, 64, 32, 1, 2>("128x128 bk32 v1 no-gload", A, W, C, M, N, K);
