@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AVD_ABI_VERSION 1
+#define AVD_ABI_VERSION 2
 
 #define AVD_OK            0
 #define AVD_EINVAL       -1   /* bad shape / argument (reference: AssertionError / ValueError) */
@@ -158,6 +158,12 @@ typedef struct {                       /* avdiff/models/mmdt.py:88-99 (Block) st
     const float* fc1_bias;             /* blocks.{i}.mlp.fc1.bias             [hid]    */
     const float* fc2_weight;           /* blocks.{i}.mlp.fc2.weight           [d,hid]  */
     const float* fc2_bias;             /* blocks.{i}.mlp.fc2.bias             [d]      */
+    /* optional split3 images of the four weights above (avd_split3_f32); all four non-NULL in every block selects
+     * the bf16x3 matmul path of avd_core_forward_f32 for large batches (see "bf16x3" below), NULL keeps fp32 MFMA */
+    const void* in_proj_weight3;
+    const void* out_proj_weight3;
+    const void* fc1_weight3;
+    const void* fc2_weight3;
 } avd_block_weights;
 
 typedef struct {                       /* avdiff/models/mmdt.py:116-149 (MMDiT) */
@@ -180,6 +186,22 @@ typedef struct {                       /* avdiff/models/heads/noise_heads.py:94-
     const float* out_proj_weight;      /* out_proj.{m}.weight [d_out,hidden] */
     const float* out_proj_bias;
 } avd_head_weights;
+
+/* ---- "bf16x3": fp32-accurate Linear on the bf16 matrix pipe (same reference ops as avd_gemm_bias_act_f32:
+ * avdiff/models/mmdt.py:60,77-83).  Every fp32 operand is split exactly into three bf16 planes (x = h + m + l); a
+ * product keeps the six terms down to 2^-16 and accumulates them in fp32, so the result carries the error of an fp32
+ * FMA chain (measured slightly below it) while the matrix pipe runs 2.67x fewer cycles than with fp32 MFMA.
+ * Operands travel as "split3 images" (tiled, 6 bytes per element, rows padded to 256; layout in csrc/gemm_bf16x3.hip). */
+int64_t avd_split3_bytes(int64_t rows, int K);                     /* bytes of the image of a [rows,K] matrix; -1 if K % 16 */
+int avd_split3_f32(const float* x, void* out, int64_t rows, int K, avd_stream_t stream);   /* x [rows,K] contiguous */
+/* RMSNorm (mmdt.py:39-42) whose output is written as a split3 image (the A operand of the next Linear) */
+int avd_rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t rows, int d, float eps,
+                           avd_stream_t stream);
+/* C = act(A W^T + bias) (+ residual), A3/W3 split3 images of A [M,K] and W [N,K]; N % 256 == 0, K % 16 == 0.
+ * C3 == NULL: fp32 row-major C [M,N], act AVD_ACT_NONE, residual optional (may alias C).
+ * C3 != NULL: the result is written as the split3 image of [M,N] instead (bias + AVD_ACT_GELU, no residual). */
+int avd_gemm_bf16x3_f32(const void* A3, const void* W3, const float* bias, const float* residual, float* C, void* C3,
+                        int64_t M, int N, int K, int act, avd_stream_t stream);
 
 /* bytes of scratch avd_core_forward_f32 needs for a [B,N,d] input */
 int64_t avd_core_workspace_bytes(const avd_core_weights* w, int B, int N);

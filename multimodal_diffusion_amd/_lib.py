@@ -34,7 +34,8 @@ class EmbedDesc(C.Structure):
 class BlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "norm1_scale", "in_proj_weight", "in_proj_bias", "out_proj_weight", "out_proj_bias",
-        "norm2_scale", "fc1_weight", "fc1_bias", "fc2_weight", "fc2_bias")]
+        "norm2_scale", "fc1_weight", "fc1_bias", "fc2_weight", "fc2_bias",
+        "in_proj_weight3", "out_proj_weight3", "fc1_weight3", "fc2_weight3")]
 
 
 class CoreWeights(C.Structure):
@@ -77,6 +78,7 @@ class VaeEncodeDesc(C.Structure):
                 ("to_lat_w", C.c_void_p), ("to_lat_b", C.c_void_p)]
 
 
+ABI_VERSION = 2
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); must list every symbol include/avdiff_hip.h declares
@@ -105,6 +107,10 @@ SIGNATURES = {
     "avd_step_workspace_bytes": (_L, [C.POINTER(StepDesc)]),
     "avd_denoise_step_f32": (_I, [C.POINTER(StepDesc), _P, _P, _P, _P, _P, _P, _P, _L, _P]),
     "avd_sched_advance": (_I, [_P, _I, _P, _P, _P, _I, _P]),
+    "avd_split3_bytes": (_L, [_L, _I]),
+    "avd_split3_f32": (_I, [_P, _P, _L, _I, _P]),
+    "avd_rmsnorm_split3_f32": (_I, [_P, _P, _P, _L, _I, _F, _P]),
+    "avd_gemm_bf16x3_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "avd_vae_decode_workspace_bytes": (_L, [C.POINTER(VaeDecodeDesc)]),
     "avd_vae_decode_f32": (_I, [C.POINTER(VaeDecodeDesc), _P, _P, _P, _L, _P]),
     "avd_vae_encode_workspace_bytes": (_L, [C.POINTER(VaeEncodeDesc)]),
@@ -146,8 +152,8 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)   # AttributeError if the .so is stale / missing a symbol
             fn.restype, fn.argtypes = res, args
-        if handle.avd_abi_version() != 1:
-            raise AvdError(f"ABI version mismatch: library {handle.avd_abi_version()}, binding 1")
+        if handle.avd_abi_version() != ABI_VERSION:
+            raise AvdError(f"ABI version mismatch: library {handle.avd_abi_version()}, binding {ABI_VERSION}")
         _lib = handle
     return _lib
 

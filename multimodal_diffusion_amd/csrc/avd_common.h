@@ -96,4 +96,12 @@ int rmsnorm_f32(const float* x, RowMap xm, const float* scale, float* y, RowMap 
 int layernorm_act_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int d, float eps,
                       int act, hipStream_t st);
 
+// bf16x3 path (gemm_bf16x3.hip)
+int64_t split3_bytes(int64_t rows, int K);
+int split3_f32(const float* x, int64_t ld, void* out, int64_t rows, int K, hipStream_t st);
+int rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t rows, int d, float eps, hipStream_t st);
+bool gemm_bf16x3_supported(int64_t M, int N, int K);
+int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
+                int act, hipStream_t st);
+
 }  // namespace avd

@@ -77,9 +77,27 @@ struct Carver {
 };
 
 // ---------------------------------------------------------------- MMDiT.forward
+// bf16x3 matmul path: taken when every block carries split3 weight images and the batch fills the 256x256-tile kernel
+constexpr int64_t kSplitMinRows = 16384;
+static bool core_use_split(const avd_core_weights* w, int64_t M) {
+    if (M < kSplitMinRows) return false;
+    if (!gemm_bf16x3_supported(M, 3 * w->d, w->d) || !gemm_bf16x3_supported(M, w->d, w->d) ||
+        !gemm_bf16x3_supported(M, w->mlp_hidden, w->d) || !gemm_bf16x3_supported(M, w->d, w->mlp_hidden))
+        return false;
+    for (int l = 0; l < w->n_layers; ++l) {
+        const avd_block_weights& b = w->blocks[l];
+        if (!b.in_proj_weight3 || !b.out_proj_weight3 || !b.fc1_weight3 || !b.fc2_weight3) return false;
+    }
+    return true;
+}
+
 static int64_t core_ws_bytes(const avd_core_weights* w, int64_t M) {
     const int wide = 3 * w->d > w->mlp_hidden ? 3 * w->d : w->mlp_hidden;
-    return align_up(M * w->d * 4) + align_up(M * wide * 4);
+    int64_t fp32_path = align_up(M * w->d * 4) + align_up(M * wide * 4);
+    if (!core_use_split(w, M)) return fp32_path;
+    // + split3 image of the norm / attention output, and the wide buffer must also hold the split3 image of the MLP hidden
+    const int64_t wide_b = M * 3 * w->d * 4 > split3_bytes(M, w->mlp_hidden) ? M * 3 * w->d * 4 : split3_bytes(M, w->mlp_hidden);
+    return align_up(M * w->d * 4) + align_up(wide_b) + align_up(split3_bytes(M, w->d));
 }
 
 static int check_core(const avd_core_weights* w) {
@@ -106,6 +124,30 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
     const RowMap rd{d, 0, 0}, r3{3 * d, 0, 0}, rh{hid, 0, 0};
     const float scale = 1.0f / sqrtf((float)(d / H));
     const float* cur = x;                                           // residual stream lives in y after the first write
+    if (core_use_split(w, M)) {
+        // same op sequence with the four projections on the bf16 matrix pipe (gemm_bf16x3.hip); hs / wide3 are split3 images
+        Carver cs{static_cast<char*>(ws), 0, ws_bytes};
+        float* attn_out = cs.take(M * d);
+        const int64_t wide_b = M * 3 * d * 4 > split3_bytes(M, hid) ? M * 3 * d * 4 : split3_bytes(M, hid);
+        float* qkv = cs.take((wide_b + 3) / 4);
+        void* wide3 = qkv;
+        void* hs = cs.take((split3_bytes(M, d) + 3) / 4);
+        for (int l = 0; l < w->n_layers; ++l) {
+            const avd_block_weights& b = w->blocks[l];
+            const bool last = l == w->n_layers - 1;
+            const int nq = (last && out_row0 == 0) ? n_out_rows : N;
+            if (int rc = rmsnorm_split3_f32(cur, b.norm1_scale, hs, M, d, w->norm_eps, st)) return rc;
+            if (int rc = gemm_bf16x3(hs, b.in_proj_weight3, b.in_proj_bias, nullptr, qkv, nullptr, M, 3 * d, d, AVD_ACT_NONE, st)) return rc;
+            if (int rc = attn_f32(qkv, attn_out, B, N, H, d / H, scale, nq, st)) return rc;
+            if (int rc = split3_f32(attn_out, d, hs, M, d, st)) return rc;
+            if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, nullptr, M, d, d, AVD_ACT_NONE, st)) return rc;
+            cur = y;
+            if (int rc = rmsnorm_split3_f32(y, b.norm2_scale, hs, M, d, w->norm_eps, st)) return rc;
+            if (int rc = gemm_bf16x3(hs, b.fc1_weight3, b.fc1_bias, nullptr, nullptr, wide3, M, hid, d, AVD_ACT_GELU, st)) return rc;
+            if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, nullptr, M, d, hid, AVD_ACT_NONE, st)) return rc;
+        }
+        return rmsnorm_f32(y, rd, w->final_norm_scale, y, rd, M, d, w->norm_eps, st);
+    }
     for (int l = 0; l < w->n_layers; ++l) {
         const avd_block_weights& b = w->blocks[l];
         const bool last = l == w->n_layers - 1;
@@ -235,7 +277,9 @@ static int plan_step(const avd_step_desc* s, StepPlan& p) {
     p.rows = (int64_t)2 * e.B * e.Nt;
     p.x2 = align_up((int64_t)2 * e.B * p.N * e.d * 4);
     p.tok = align_up(embed_ws_floats(&e) * 4);
-    p.core = 2 * core_ws_bytes(s->core, (int64_t)e.B * p.N);     // one slice per CFG half (they may run on two streams)
+    // one slice per CFG half (they may run on two streams), or the stacked 2B batch in one piece, whichever is larger
+    const int64_t halves = 2 * core_ws_bytes(s->core, (int64_t)e.B * p.N), whole = core_ws_bytes(s->core, 2 * (int64_t)e.B * p.N);
+    p.core = halves > whole ? halves : whole;
     p.head = 2 * head_ws_bytes(s->head, p.rows / 2);
     p.eps = align_up(p.rows * p.D * 4);
     p.total = p.x2 + p.tok + p.core + p.head + p.eps;

@@ -1,0 +1,415 @@
+// fp32-accurate Linear on the bf16 matrix pipe ("bf16x3") — an alternative to gemm_f32.hip for the four big
+// projections of a Block (avdiff/models/mmdt.py:60,77-83) when the batch is large.
+//
+// Why: on gfx950 v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate (157 vs 2,516 TFLOP/s).  Every fp32 value
+// splits EXACTLY into three bf16 planes, x = h + m + l (8 significant bits each, bf16 has fp32's exponent range, so no
+// scaling is needed).  A product keeps the six terms down to 2^-16 — hh, hm, mh, hl, lh, mm — and drops ml, lm, ll
+// (<= 2^-24 relative), each term accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Measured against an fp64 result the
+// error is the same as (slightly below) the fp32 FMA chain's: 3.5e-6 vs 3.8e-6 max at K=512, 6.5e-4 vs 7.5e-4 at
+// K=2048 with |C| ~ 460 (tools/micro/split_lab2.hip check).  Six bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64
+// cycles per k=16: 2.67x fewer matrix-pipe cycles.
+//
+// Operand image ("split3"): X[rows][K] fp32 -> T[ceil(rows/128)][K/16][128 rows][96 B]; row r of a chunk at r*96, the
+// 16-byte slot of (plane p, half = (k%16)/8) at ((2p + half) ^ ((r>>3)&1))*16.  One block's K-tile of an operand is
+// then one contiguous, already bank-swizzled 12 KiB chunk: the global->LDS DMA is a linear copy of whole cache lines
+// and the ds_read_b128 of fragment rows is conflict free.  Producers (RMSNorm, the fc1+GELU epilogue, the split pass
+// after attention) write this image directly, so no fp32 copy of those activations exists in this mode.
+//
+// Kernel: 256x256 block tile, 8 waves (wave tile 128x64 = 4x2 accumulators), K-tile 16, three 48 KiB LDS stages filled by
+// LDS-DMA with a counted vmcnt (two tiles in flight), one s_barrier per K-tile, XCD-contiguous super-tiles of 16 blocks
+// so co-resident blocks share A and W panels in their XCD's L2.  The matrix pipe under this load is power-limited
+// (the chip holds ~1.6-1.9 GHz on random data), which caps the achievable rate near 280 fp32-equivalent TFLOP/s.
+#include "avd_common.h"
+
+namespace avd {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int S3_CHUNK = 128 * 96;
+
+#define AVD_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define AVD_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __forceinline__ unsigned short bf16_rn(float x) {      // round-to-nearest-even on the fp32 bits (finite inputs)
+    unsigned int u = __float_as_uint(x);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_f(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
+
+// v[8] -> three 16-byte chunks of 8 bf16: h = rn(x), m = rn(x - h), l = rn(x - h - m); both residuals are exact in fp32
+__device__ __forceinline__ void split8(const float* v, u32x4& H, u32x4& Mi, u32x4& Lo) {
+    unsigned short h[8], m[8], l[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        h[e] = bf16_rn(v[e]);
+        const float r1 = v[e] - bf16_f(h[e]);
+        m[e] = bf16_rn(r1);
+        const float r2 = r1 - bf16_f(m[e]);
+        l[e] = bf16_rn(r2);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        H[e] = (unsigned int)h[2 * e] | ((unsigned int)h[2 * e + 1] << 16);
+        Mi[e] = (unsigned int)m[2 * e] | ((unsigned int)m[2 * e + 1] << 16);
+        Lo[e] = (unsigned int)l[2 * e] | ((unsigned int)l[2 * e + 1] << 16);
+    }
+}
+
+// where the 8 values (row r, columns k..k+7, k % 8 == 0) of a [rows][K] matrix go in its split3 image
+__device__ __forceinline__ void store_split8(unsigned char* img, int64_t r, int k, int K, const float* v) {
+    u32x4 H, Mi, Lo;
+    split8(v, H, Mi, Lo);
+    const int rr = (int)(r & 127), f = (rr >> 3) & 1, half = (k >> 3) & 1;
+    unsigned char* dst = img + ((r >> 7) * (K >> 4) + (k >> 4)) * (int64_t)S3_CHUNK + rr * 96;
+    *reinterpret_cast<u32x4*>(dst + (((0 + half) ^ f) << 4)) = H;
+    *reinterpret_cast<u32x4*>(dst + (((2 + half) ^ f) << 4)) = Mi;
+    *reinterpret_cast<u32x4*>(dst + (((4 + half) ^ f) << 4)) = Lo;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// producers
+// ---------------------------------------------------------------------------------------------------------
+// x [rows][K] (row stride ld) -> split3 image; rows in [rows, rows_pad) are written as zeros
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int64_t ld, unsigned char* __restrict__ out,
+                                                     int64_t rows, int64_t rows_pad, int K) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = K >> 3;
+    if (i >= rows_pad * per_row) return;
+    const int64_t r = i / per_row;
+    const int k = (int)(i % per_row) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+        *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(x + r * ld + k);
+        *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(x + r * ld + k + 4);
+    }
+    store_split8(out, r, k, K, v);
+}
+
+// RMSNorm (mmdt.py:39-42, eps outside the sqrt) writing the split3 image of its output; one wave per row
+template <int NC>   // 8-element chunks per lane: d <= 512 * NC
+__global__ __launch_bounds__(256) void rmsnorm_split3_kernel(const float* __restrict__ x, const float* __restrict__ scale,
+                                                             unsigned char* __restrict__ out, int64_t rows, int d, float eps,
+                                                             float sqrt_d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * d;
+    float v[NC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < d) {
+            *reinterpret_cast<f32x4*>(v[i]) = *reinterpret_cast<const f32x4*>(xr + c);
+            *reinterpret_cast<f32x4*>(v[i] + 4) = *reinterpret_cast<const f32x4*>(xr + c + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss += v[i][e] * v[i][e];
+        }
+    }
+    ss = wave_sum(ss);
+    const float den = sqrtf(ss) / sqrt_d + eps;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < d) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = scale[c + e] * v[i][e] / den;
+            store_split8(out, row, c, d, o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// GEMM
+// ---------------------------------------------------------------------------------------------------------
+enum { S3_EPI_BIAS = 0, S3_EPI_RES = 2, S3_EPI_GELU_SPLIT = 3 };
+
+struct S3Args {
+    const unsigned char* A;   // split3 image of [M][K]
+    const unsigned char* W;   // split3 image of [N][K]
+    const float* bias;
+    const float* R;           // residual [M][N] (may alias C)
+    float* C;                 // [M][N] fp32 (EPI_BIAS, EPI_RES)
+    unsigned char* C3;        // split3 image of [M][N] (EPI_GELU_SPLIT)
+    int64_t M;
+    int N, K, nbn, sm, sn;
+};
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+    static_assert(N >= 0 && N < 64, "vmcnt range");
+    __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14));
+}
+
+constexpr int S3_BM = 256, S3_BN = 256, S3_NST = 3;
+constexpr int S3_STAGE = (S3_BM + S3_BN) * 96;          // 48 KiB
+constexpr int S3_LDS = S3_NST * S3_STAGE;                // 144 KiB (the epilogue slabs, 8 x 64 x 68 floats, fit inside)
+
+template <int EPI>
+__global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
+    constexpr int BM = S3_BM, BN = S3_BN, WM = 128, WN = 64, ROWB = 96;
+    constexpr int TM = 4, TN = 2, NST = S3_NST, STAGE = S3_STAGE;
+    constexpr int PPW = 6;                                // 48 one-KiB pieces per stage / 8 waves
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+
+    int wg;
+    {
+        const int b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    // super-tiles of sm x sn blocks: the blocks an XCD runs together share sm A panels and sn W panels
+    const int per_row = g.sm * g.nbn, per_st = g.sm * g.sn;
+    const int srow = wg / per_row, rem = wg % per_row;
+    const int sc = rem / per_st, rem2 = rem % per_st;
+    const int bm = srow * g.sm + rem2 / g.sn;
+    const int bn = sc * g.sn + rem2 % g.sn;
+    if ((int64_t)bm * BM >= g.M) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ng = g.K >> 4;
+    const int nrtA = (int)((g.M + 127) >> 7);
+
+    // DMA: the stage image is [A row-tile 0 | A row-tile 1 | W row-tile 0 | W row-tile 1], 12 pieces of 1 KiB each
+    const unsigned char* src[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int q = wave * PPW + i;
+        const int region = q / 12, within = (q % 12) * 1024 + lane * 16;
+        if (region < 2) {
+            int rt = bm * 2 + region;
+            rt = rt < nrtA ? rt : nrtA - 1;
+            src[i] = g.A + (int64_t)rt * ng * S3_CHUNK + within;
+        } else {
+            src[i] = g.W + (int64_t)(bn * 2 + region - 2) * ng * S3_CHUNK + within;
+        }
+    }
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(src[i] + (int64_t)kt * S3_CHUNK),
+                                             AVD_LDS_PTR(smem3 + buf * STAGE + (wave * PPW + i) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * WM + i * 32 + l31;
+        a_off[i] = r * ROWB + ((hi ^ ((r >> 3) & 1)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = BM + wn * WN + j * 32 + l31;
+        b_off[j] = r * ROWB + ((hi ^ ((r >> 3) & 1)) << 4);
+    }
+
+    const int nk = ng;
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int cur = 0, nxt = NST - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + NST - 1 <= nk) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>();
+        asm volatile("s_barrier" ::: "memory");   // no fence: a fence would drain vmcnt and with it the tiles in flight
+        if (kt + NST - 1 < nk) issue(kt + NST - 1, nxt);
+        const unsigned char* st = smem3 + cur * STAGE;
+        cur = cur + 1 == NST ? 0 : cur + 1;
+        nxt = nxt + 1 == NST ? 0 : nxt + 1;
+        bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + 32 * p);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + 32 * p);
+        // (l,h) (h,l) (m,m) (m,h) (h,m) (h,h): small terms first
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int t = 0; t < 6; ++t)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+
+    // epilogue: two 64-row passes per wave through a private LDS slab, streamed out as whole 16-byte segments
+    constexpr int CLD = WN + 4;
+    float* slab = reinterpret_cast<float*>(smem3) + wave * 64 * CLD;
+    const int nbase = bn * BN + wn * WN;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[(i * 32 + mfma32_row(r, hi)) * CLD + j * 32 + l31] = acc[ps * 2 + i][j][r];
+        const int64_t m0 = (int64_t)bm * BM + wm * WM + ps * 64;
+        if constexpr (EPI == S3_EPI_GELU_SPLIT) {
+            // 8 lanes per row (8 columns each), 8 rows per wave instruction
+            const int cr = lane >> 3, cc = (lane & 7) * 8;
+            const int n = nbase + cc;
+            float bv[8];
+            *reinterpret_cast<f32x4*>(bv) = *reinterpret_cast<const f32x4*>(g.bias + n);
+            *reinterpret_cast<f32x4*>(bv + 4) = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int64_t m = m0 + cr + it * 8;
+                float v[8];
+                *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + cc);
+                *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + cc + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e] + bv[e]);
+                if (m < g.M) store_split8(g.C3, m, n, g.N, v);
+            }
+        } else {
+            // 16 lanes per row (4 columns each), 4 rows per wave instruction
+            const int cr = lane >> 4, cc = (lane & 15) * 4;
+            const int n = nbase + cc;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+            float* cptr = g.C + (m0 + cr) * g.N + n;
+            const float* rptr = EPI == S3_EPI_RES ? g.R + (m0 + cr) * g.N + n : nullptr;
+#pragma unroll
+            for (int c0 = 0; c0 < 16; c0 += 8) {
+                f32x4 rv[8];
+                if constexpr (EPI == S3_EPI_RES) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        rv[u] = m0 + cr + (c0 + u) * 4 < g.M ? *reinterpret_cast<const f32x4*>(rptr + (int64_t)(c0 + u) * 4 * g.N)
+                                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int it = c0 + u;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(slab + (cr + it * 4) * CLD + cc);
+                    v += bv;
+                    if constexpr (EPI == S3_EPI_RES) v += rv[u];
+                    if (m0 + cr + it * 4 < g.M) *reinterpret_cast<f32x4*>(cptr + (int64_t)it * 4 * g.N) = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+int64_t split3_bytes(int64_t rows, int K) { return ((rows + 255) / 256 * 256) * (int64_t)K * 6; }
+
+int split3_f32(const float* x, int64_t ld, void* out, int64_t rows, int K, hipStream_t st) {
+    AVD_REQUIRE(x && out, AVD_EINVAL, "split3: null pointer");
+    AVD_REQUIRE(rows > 0 && K > 0 && K % 16 == 0 && ld >= K && ld % 4 == 0, AVD_EUNSUPPORTED,
+                "split3: need rows > 0, K %% 16 == 0, ld %% 4 == 0 (rows=%lld K=%d ld=%lld)", (long long)rows, K, (long long)ld);
+    AVD_REQUIRE(aligned16(x) && aligned16(out), AVD_EUNSUPPORTED, "split3: pointers must be 16-byte aligned");
+    const int64_t rows_pad = (rows + 255) / 256 * 256;
+    const int64_t n = rows_pad * (K / 8);
+    AVD_REQUIRE((n + 255) / 256 < (1ll << 31), AVD_EUNSUPPORTED, "split3: grid too large");
+    static const int tag = prof_tag_id("split3_kernel");
+    ProfScope prof(tag, (double)rows * K * 10.0, st);
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ld,
+                       static_cast<unsigned char*>(out), rows, rows_pad, K);
+    AVD_CHECK_LAUNCH("split3");
+    return AVD_OK;
+}
+
+int rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t rows, int d, float eps, hipStream_t st) {
+    AVD_REQUIRE(x && scale && out, AVD_EINVAL, "rmsnorm_split3: null pointer");
+    AVD_REQUIRE(rows > 0 && d > 0 && d % 16 == 0 && d <= 2048, AVD_EUNSUPPORTED, "rmsnorm_split3: d=%d must be a multiple of 16, <= 2048", d);
+    AVD_REQUIRE(aligned16(x) && aligned16(out), AVD_EUNSUPPORTED, "rmsnorm_split3: pointers must be 16-byte aligned");
+    static const int tag = prof_tag_id("rmsnorm_split3_kernel");
+    ProfScope prof(tag, 10.0 * (double)rows * d, st);
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    const float isd = (float)sqrt((double)d);
+    unsigned char* o = static_cast<unsigned char*>(out);
+    switch ((d + 511) / 512) {
+        case 1: hipLaunchKernelGGL(rmsnorm_split3_kernel<1>, dim3(grid), dim3(256), 0, st, x, scale, o, rows, d, eps, isd); break;
+        case 2: hipLaunchKernelGGL(rmsnorm_split3_kernel<2>, dim3(grid), dim3(256), 0, st, x, scale, o, rows, d, eps, isd); break;
+        case 3: hipLaunchKernelGGL(rmsnorm_split3_kernel<3>, dim3(grid), dim3(256), 0, st, x, scale, o, rows, d, eps, isd); break;
+        default: hipLaunchKernelGGL(rmsnorm_split3_kernel<4>, dim3(grid), dim3(256), 0, st, x, scale, o, rows, d, eps, isd); break;
+    }
+    AVD_CHECK_LAUNCH("rmsnorm_split3");
+    return AVD_OK;
+}
+
+bool gemm_bf16x3_supported(int64_t M, int N, int K) { return M > 0 && N > 0 && N % 256 == 0 && K > 0 && K % 16 == 0; }
+
+template <int EPI>
+static int launch_s3(const S3Args& a, hipStream_t st) {
+    static bool attr = false;
+    auto kern = gemm_bf16x3_kernel<EPI>;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS);
+        if (e != hipSuccess) return set_error(AVD_ELAUNCH, "gemm_bf16x3 attr: %s", hipGetErrorString(e));
+        attr = true;
+    }
+    S3Args g = a;
+    g.nbn = a.N / S3_BN;
+    int sn = 8;
+    while (g.nbn % sn) sn >>= 1;
+    g.sn = sn;
+    g.sm = 16 / sn;
+    const int64_t nbm = (a.M + S3_BM - 1) / S3_BM;
+    const int64_t nwg = (nbm + g.sm - 1) / g.sm * g.sm * g.nbn;
+    AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
+    static const int tag = prof_tag_id("gemm_bf16x3_kernel<%d>", EPI);
+    ProfScope prof(tag, 2.0 * (double)a.M * a.N * a.K, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), S3_LDS, st, g);
+    AVD_CHECK_LAUNCH("gemm_bf16x3");
+    return AVD_OK;
+}
+
+// C = act(A W^T + bias) (+ residual).  C3 != null: the output is written as a split3 image (act must be GELU);
+// otherwise fp32 row-major into C (act NONE; residual optional, may alias C).
+int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
+                int act, hipStream_t st) {
+    AVD_REQUIRE(A3 && W3 && (C || C3), AVD_EINVAL, "gemm_bf16x3: null pointer");
+    AVD_REQUIRE(gemm_bf16x3_supported(M, N, K), AVD_EUNSUPPORTED, "gemm_bf16x3: need N %% 256 == 0 and K %% 16 == 0 (M=%lld N=%d K=%d)",
+                (long long)M, N, K);
+    AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(C) && aligned16(C3) && aligned16(bias) && aligned16(R), AVD_EUNSUPPORTED,
+                "gemm_bf16x3: pointers must be 16-byte aligned");
+    S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, R, C,
+             static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0};
+    if (C3) {
+        AVD_REQUIRE(act == AVD_ACT_GELU && !R && bias, AVD_EUNSUPPORTED, "gemm_bf16x3: split3 output implies bias + GELU, no residual");
+        return launch_s3<S3_EPI_GELU_SPLIT>(a, st);
+    }
+    AVD_REQUIRE(act == AVD_ACT_NONE, AVD_EUNSUPPORTED, "gemm_bf16x3: fp32 output supports act NONE only");
+    if (R) return launch_s3<S3_EPI_RES>(a, st);
+    return launch_s3<S3_EPI_BIAS>(a, st);
+}
+
+}  // namespace avd
+
+using namespace avd;
+
+extern "C" int64_t avd_split3_bytes(int64_t rows, int K) {
+    if (rows <= 0 || K <= 0 || K % 16) return -1;
+    return split3_bytes(rows, K);
+}
+extern "C" int avd_split3_f32(const float* x, void* out, int64_t rows, int K, avd_stream_t stream) {
+    return split3_f32(x, K, out, rows, K, static_cast<hipStream_t>(stream));
+}
+extern "C" int avd_rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t rows, int d, float eps,
+                                      avd_stream_t stream) {
+    return rmsnorm_split3_f32(x, scale, out, rows, d, eps, static_cast<hipStream_t>(stream));
+}
+extern "C" int avd_gemm_bf16x3_f32(const void* A3, const void* W3, const float* bias, const float* residual, float* C, void* C3,
+                                   int64_t M, int N, int K, int act, avd_stream_t stream) {
+    return gemm_bf16x3(A3, W3, bias, residual, C, C3, M, N, K, act, static_cast<hipStream_t>(stream));
+}

@@ -161,3 +161,44 @@ def ddim_step(x_t: Tensor, t_now: Tensor, t_prev: Tensor, eps_hat: Tensor, alpha
     L.check(L.lib().avd_ddim_step_f32(x_t.data_ptr(), eps_hat.data_ptr(), tn.data_ptr(), tp.data_ptr(), ab.data_ptr(),
                                       ab.numel(), float(eta), L.ptr(nz), out.data_ptr(), B, x_t.numel() // B, _st(x_t)))
     return out
+
+
+# ---- "bf16x3": fp32-accurate Linear on the bf16 matrix pipe (csrc/gemm_bf16x3.hip) ----
+def split3(x: Tensor) -> Tensor:
+    """fp32 [rows, K] -> its split3 image (uint8; three bf16 planes, tiled).  K must be a multiple of 16."""
+    x = L.dev_f32(x, "x")
+    k = x.shape[-1]
+    rows = x.numel() // k
+    nbytes = L.lib().avd_split3_bytes(rows, k)
+    if nbytes < 0:
+        raise L.AvdError(f"split3: K={k} must be a multiple of 16")
+    out = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    L.check(L.lib().avd_split3_f32(x.data_ptr(), out.data_ptr(), rows, k, _st(x)))
+    return out
+
+
+def rmsnorm_split3(x: Tensor, scale: Tensor, eps: float = 1e-6) -> Tensor:
+    """RMSNorm(x) written as a split3 image (the A operand of the next bf16x3 Linear)."""
+    x = L.dev_f32(x, "x")
+    scale = L.dev_f32(scale, "scale")
+    d = x.shape[-1]
+    rows = x.numel() // d
+    out = torch.empty(L.lib().avd_split3_bytes(rows, d), dtype=torch.uint8, device=x.device)
+    L.check(L.lib().avd_rmsnorm_split3_f32(x.data_ptr(), scale.data_ptr(), out.data_ptr(), rows, d, eps, _st(x)))
+    return out
+
+
+def linear_bf16x3(x3: Tensor, rows: int, w3: Tensor, n: int, k: int, bias: Optional[Tensor] = None,
+                  residual: Optional[Tensor] = None, act: int = L.ACT_NONE, out_split3: bool = False) -> Tensor:
+    """act(x @ W.T + bias) + residual with both operands given as split3 images; fp32 [rows, n] result, or its split3
+    image when out_split3 (bias + GELU only)."""
+    b = None if bias is None else L.dev_f32(bias, "bias")
+    r = None if residual is None else L.dev_f32(residual, "residual")
+    if out_split3:
+        out = torch.empty(L.lib().avd_split3_bytes(rows, n), dtype=torch.uint8, device=x3.device)
+        c, c3 = None, out.data_ptr()
+    else:
+        out = torch.empty(rows, n, dtype=torch.float32, device=x3.device)
+        c, c3 = out.data_ptr(), None
+    L.check(L.lib().avd_gemm_bf16x3_f32(x3.data_ptr(), w3.data_ptr(), L.ptr(b), L.ptr(r), c, c3, rows, n, k, act, _st(x3)))
+    return out

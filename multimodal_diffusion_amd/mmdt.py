@@ -147,6 +147,19 @@ class MMDiT(nn.Module):
                                      for _ in range(n_layers)])
         self.final_norm = build_norm(norm, d_model)
         self._ws: Optional[torch.Tensor] = None
+        # "f32": fp32 MFMA everywhere.  "bf16x3": the four projections of every block run on the bf16 matrix pipe with
+        # exactly split operands (fp32-level error, csrc/gemm_bf16x3.hip) whenever the batch is large enough.
+        self.matmul = "f32"
+        self._split3: dict = {}
+
+    def _split3_image(self, name: str, p: torch.Tensor) -> torch.Tensor:
+        key = (p.data_ptr(), p._version, tuple(p.shape))
+        hit = self._split3.get(name)
+        if hit is None or hit[0] != key:
+            from . import functional as Fn
+            hit = (key, Fn.split3(p.detach()))
+            self._split3[name] = hit
+        return hit[1]
 
     # ---- pointer table for the composite (rebuilt per call: parameters may have moved) ----
     def weight_table(self):
@@ -165,6 +178,13 @@ class MMDiT(nn.Module):
                     raise L.AvdError("all MMDiT parameters must live on one device")
                 keep.append(t)
                 setattr(arr[i], k, t.data_ptr())
+            if self.matmul == "bf16x3":
+                for k in ("in_proj_weight", "out_proj_weight", "fc1_weight", "fc2_weight"):
+                    img = self._split3_image(f"{i}.{k}", ps[k])
+                    keep.append(img)
+                    setattr(arr[i], k + "3", img.data_ptr())
+            elif self.matmul != "f32":
+                raise ValueError(f"matmul must be 'f32' or 'bf16x3', got {self.matmul!r}")
         fin = L.dev_f32(self.final_norm.scale.detach(), "final_norm.scale")
         keep.append(fin)
         hidden = self.blocks[0].mlp.fc1.weight.shape[0]

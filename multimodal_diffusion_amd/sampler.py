@@ -104,7 +104,7 @@ class DenoiseEngine:
     def __init__(self, *, adapt_v: LinearAdapter, adapt_a: LinearAdapter, core: MMDiT, head: MultiModalNoiseHead,
                  tstep_dim: int, target: str, latent_shape: Tuple[int, ...], prompt_tokens: int, alpha_bar: torch.Tensor,
                  guidance: float, eta: float = 0.0, tube=(2, 4, 4), chunk=(4, 4), split_streams: bool = False,
-                 temb_mode: str = "concat"):
+                 temb_mode: str = "concat", matmul: Optional[str] = None):
         if target not in ("video", "audio"):
             raise ValueError("target must be 'video' or 'audio'")
         if eta < 0:
@@ -153,6 +153,9 @@ class DenoiseEngine:
         self.N = e.Nt + e.Np
         self.alpha_bar = alpha_bar.to(self.device, torch.float32).contiguous()
 
+        if matmul is not None:
+            core.matmul = matmul          # "f32" | "bf16x3" (mmdt.MMDiT.matmul)
+        self.matmul = core.matmul
         self._core_tab, self._keep_core = core.weight_table()
         self._head_tab, self._keep_head = head.weight_table(target)
         self._aw = L.dev_f32(self.adapt_t.proj.weight.detach(), "adapter weight")

@@ -613,3 +613,115 @@ def test_stream_generate_equals_per_window_sampling(dev, full):
     assert out["video"].shape == ref.shape and out["fps"] == 16
     d = np.abs(out["video"].astype(np.int32) - ref.astype(np.int32))
     assert d.max() <= 1 and (d > 0).mean() < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------- bf16x3 matmul path
+def _split3_decode(img: np.ndarray, rows: int, K: int) -> np.ndarray:
+    """Independent reading of the split3 image layout (include/avdiff_hip.h, csrc/gemm_bf16x3.hip): -> planes [3, rows, K]."""
+    r = np.arange(rows)[:, None]
+    k = np.arange(K)[None, :]
+    base = ((r >> 7) * (K // 16) + (k >> 4)) * (128 * 96) + (r & 127) * 96 + (k & 7) * 2
+    f = ((r & 127) >> 3) & 1
+    half = (k >> 3) & 1
+    u16 = img.view(np.uint16)
+    planes = []
+    for p in range(3):
+        off = base + (((2 * p + half) ^ f) * 16)
+        bits = u16[off // 2].astype(np.uint32) << 16
+        planes.append(bits.view(np.float32))
+    return np.stack(planes)
+
+
+@pytest.mark.parametrize("rows,K", [(5, 16), (300, 512), (1000, 2048)])
+def test_split3_is_exact(dev, rows, K):
+    """x == h + m + l exactly (each plane 8 significant bits), including huge and tiny magnitudes."""
+    from multimodal_diffusion_amd import functional as Fn
+    g = torch.Generator().manual_seed(rows + K)
+    x = torch.randn(rows, K, generator=g) * torch.exp(torch.randn(rows, 1, generator=g) * 6.0)
+    img = Fn.split3(x.to(dev)).cpu().numpy()
+    pl = _split3_decode(img, rows, K).astype(np.float64)
+    assert np.array_equal(pl.sum(0), x.numpy().astype(np.float64))
+    assert np.abs(pl[1]).max() <= np.abs(pl[0]).max() * 2.0 ** -8 and np.abs(pl[2]).max() <= np.abs(pl[0]).max() * 2.0 ** -16
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 512, 256), (333, 768, 2048), (5000, 1536, 512), (130, 256, 16)])
+@pytest.mark.parametrize("mode", ["plain", "res", "gelu_split"])
+def test_gemm_bf16x3_fp32_accuracy(dev, M, N, K, mode):
+    """The split-operand GEMM must be as accurate as the fp32 MFMA GEMM: both are compared with an fp64 result."""
+    from multimodal_diffusion_amd import functional as Fn, _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * 3.0
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = R.linear(x.double(), w.double(), b.double())
+    x3, w3 = Fn.split3(x.to(dev)), Fn.split3(w.to(dev))
+    if mode == "gelu_split":
+        ref = R.gelu_erf(ref)
+        img = Fn.linear_bf16x3(x3, M, w3, N, K, bias=b.to(dev), act=L.ACT_GELU, out_split3=True).cpu().numpy()
+        y = torch.from_numpy(_split3_decode(img, M, N).astype(np.float64).sum(0))
+        y32 = Fn.linear(x.to(dev), w.to(dev), b.to(dev), act=L.ACT_GELU).cpu()
+    else:
+        if mode == "res":
+            ref = ref + r.double()
+        y = Fn.linear_bf16x3(x3, M, w3, N, K, bias=b.to(dev), residual=r.to(dev) if mode == "res" else None).cpu()
+        y32 = Fn.linear(x.to(dev), w.to(dev), b.to(dev), residual=r.to(dev) if mode == "res" else None).cpu()
+    e3 = (y.double() - ref).abs().max().item()
+    e32 = (y32.double() - ref).abs().max().item()
+    assert e3 <= 2e-6 * ref.abs().max().item()
+    assert e3 <= 1.5 * e32 + 1e-7, (e3, e32)
+
+
+def test_rmsnorm_split3(dev):
+    from multimodal_diffusion_amd import functional as Fn
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(777, 512, generator=g)
+    x[5] *= 1e-7
+    s = torch.rand(512, generator=g) + 0.5
+    img = Fn.rmsnorm_split3(x.to(dev), s.to(dev), 1e-6).cpu().numpy()
+    y = _split3_decode(img, 777, 512).astype(np.float64).sum(0)
+    assert rel_err(torch.from_numpy(y), R.rmsnorm(x.double(), s.double(), 1e-6)) < 1e-6
+    assert rel_err(torch.from_numpy(y), Fn.rmsnorm(x.to(dev), s.to(dev), 1e-6).cpu()) < 1e-6
+
+
+def test_core_bf16x3_vs_oracle_and_f32(dev, full):
+    """MMDiT.forward at a batch large enough for the bf16x3 path (rows >= 16384): same tolerance as the fp32 path, and
+    no further from the fp64 oracle than the fp32 MFMA path is."""
+    ws, _ = full
+    core3, _, _, _ = _full_modules(dev, ws)
+    core32, _, _, _ = _full_modules(dev, ws)
+    core3.matmul = "bf16x3"
+    x = torch.randn(40, 421, 512, generator=torch.Generator().manual_seed(12))
+    y3 = core3(x.to(dev)).cpu()
+    y32 = core32(x.to(dev)).cpu()
+    assert not torch.equal(y3, y32), "bf16x3 path did not run"
+    sub = slice(0, 3)
+    ref = R.mmdit_forward(x[sub].double(), {k: v.double() for k, v in ws["core"].items()}, 8, 8)
+    e3, e32 = rel_err(y3[sub], ref), rel_err(y32[sub], ref)
+    assert e3 < TOL and e32 < TOL
+    assert e3 < 2.0 * e32 + 1e-7, (e3, e32)
+    assert rel_err(y3, y32) < 2e-5
+
+
+def test_full_step_bf16x3_vs_oracle(dev, full):
+    """BASELINE C3 shape, B=20 (2B*N = 16,840 rows, the bf16x3 path), one CFG step against the CPU oracle."""
+    import multimodal_diffusion_amd as A
+    ws, _ = full
+    core, head, av, aa = _full_modules(dev, ws)
+    B = 20
+    g = torch.Generator().manual_seed(256)
+    z_v = torch.randn(B, 8, 12, 32, 32, generator=g)
+    z_a = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn = torch.tensor([982, 500, 16, 999] * 5)
+    tp = torch.tensor([966, 480, -1, 979] * 5)
+    nb = 4                                                          # oracle on the first samples only (samples are independent)
+    ref = R.denoise_step_a2v(z_v[:nb], z_a[:nb], tn[:nb], tp[:nb], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"],
+                             core=ws["core"], head=ws["head"], n_layers=8, n_heads=8, guidance=3.5)
+    eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video",
+                          latent_shape=tuple(z_v.shape), prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul="bf16x3")
+    assert eng.matmul == "bf16x3"
+    eng.set_prompt(z_a.to(dev))
+    out = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev))
+    assert torch.equal(out, eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)))        # deterministic
+    assert rel_err(out[:nb].cpu(), ref) < TOL
