@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--matmul", default="f32", choices=["f32", "bf16x3"],
                     help="f32: fp32 MFMA everywhere; bf16x3: block projections on the bf16 matrix pipe with exactly split "
                          "fp32 operands (same fp32-level error, see csrc/gemm_bf16x3.hip)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed-region) measurement of the other matmul mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -284,11 +285,57 @@ def main():
             cdt = (time.perf_counter() - c0) / args.cpu_steps
         got = eng.step(z0, tn.to(dev), tp.to(dev)).cpu()
         err = float((got - ref).abs().max() / max(1.0, float(ref.abs().max())))
+        cpu_ref = ref
         out["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "steps/s", "cores": cores, "kind": "port",
                                "sample": f"{args.cpu_steps} timed steps (+1 warm-up) of the same batch-{B} {size}x{size} step, "
                                          f"fp32 torch CPU oracle, {cores} threads",
                                "ms_per_step": 1e3 * cdt}
         out["parity_rel_err_vs_cpu_oracle"] = err
+
+    # ---- the other matmul mode, measured the same way right after (N=1 only; never part of `value`)
+    if rank == 0 and world == 1 and not args.no_alt:
+        other = "bf16x3" if args.matmul == "f32" else "f32"
+        eng2 = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=tdim, target="video",
+                               latent_shape=lat, prompt_tokens=na, alpha_bar=abar, guidance=args.guidance,
+                               split_streams=bool(args.split_streams), matmul=other)
+        eng2.set_prompt(z_a0)
+        eng2.begin(sched)
+        za2, zb2 = z0.clone(), torch.empty_like(z0)
+
+        def run2(k):
+            nonlocal za2, zb2
+            for i in range(k):
+                if i % S == 0:
+                    eng2.rewind()
+                    za2.copy_(z0)
+                eng2.advance(za2, zb2)
+                za2, zb2 = zb2, za2
+
+        run2(args.warmup)
+        torch.cuda.synchronize()
+        a0 = time.perf_counter()
+        run2(args.steps)
+        torch.cuda.synchronize()
+        adt = time.perf_counter() - a0
+        alt = {"matmul": other, "value": args.steps / adt, "unit": "steps/s", "ms_per_step": 1e3 * adt / args.steps,
+               "algorithmic_tflops": step_flops_per_sample(nv, na) * B * args.steps / adt / 1e12,
+               "dtype": "f32" if other == "f32" else "f32 via 3xbf16 split operands (6-term products, f32 accumulate)"}
+        if not args.no_roofline:
+            L.prof_enable(True)
+            run2(5)
+            torch.cuda.synchronize()
+            L.prof_enable(False)
+            rep = L.prof_report()
+            dom = max((k for k in rep if k.startswith("gemm")), key=lambda k: rep[k][1])
+            n, ms, work = rep[dom]
+            ach = work / (ms * 1e-3) / 1e12
+            peak = PEAK_BF16X3_EQUIV_TFLOPS if dom.startswith("gemm_bf16x3") else PEAK_F32_MATRIX_TFLOPS
+            alt["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": pmc_traffic(dom), "avg_launch_us": 1e3 * ms / max(n, 1)}
+        if "cpu_baseline" in out:
+            got2 = eng2.step(z0, tn.to(dev), tp.to(dev)).cpu()
+            alt["parity_rel_err_vs_cpu_oracle"] = float((got2 - cpu_ref).abs().max() / max(1.0, float(cpu_ref.abs().max())))
+        out["alt"] = alt
 
     if rank == 0:
         print(json.dumps(out))

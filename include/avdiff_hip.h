@@ -197,6 +197,9 @@ int avd_split3_f32(const float* x, void* out, int64_t rows, int K, avd_stream_t 
 /* RMSNorm (mmdt.py:39-42) whose output is written as a split3 image (the A operand of the next Linear) */
 int avd_rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t rows, int d, float eps,
                            avd_stream_t stream);
+/* avd_attn_fwd_f32 whose [B*N, H*Dh] result is written as a split3 image (rows >= n_query of a sample are left untouched) */
+int avd_attn_fwd_split3_f32(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query,
+                            avd_stream_t stream);
 /* C = act(A W^T + bias) (+ residual), A3/W3 split3 images of A [M,K] and W [N,K]; N % 256 == 0, K % 16 == 0.
  * C3 == NULL: fp32 row-major C [M,N], act AVD_ACT_NONE, residual optional (may alias C).
  * C3 != NULL: the result is written as the split3 image of [M,N] instead (bias + AVD_ACT_GELU, no residual). */

@@ -30,7 +30,7 @@ constexpr float LOG2E = 1.4426950408889634f;
 #define AVD_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define AVD_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-template <int NW>
+template <int NW, bool SPLIT = false>   // SPLIT: `out` is the split3 image of the [B*N, d] result (bf16x3 path)
 __global__ __launch_bounds__(NW * 64, 2) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                               int N, int H, float scale, int n_query, int nqb) {
     constexpr int PPW = 16 / NW;       // 1-KiB DMA pieces (4 key rows) per wave per operand per tile
@@ -190,7 +190,31 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_f32_kernel(const float* __res
     // ---- normalise and store: lane (q, hi) holds O[q][8*g + 4*hi + (0..3)] in regs 4g..4g+3 ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q_row < n_query) {
+    if constexpr (SPLIT) {
+        // a split3 chunk is 8 consecutive d: the two half-lanes of a query hold 4 + 4 of every chunk -> swap so that the
+        // low half-lane owns even chunks and the high half-lane odd ones, then store four 8-value chunks each
+        float ch[8][4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ch[g4][e] = o0[4 * g4 + e] * inv;
+                ch[4 + g4][e] = o1[4 * g4 + e] * inv;
+            }
+        unsigned char* img = reinterpret_cast<unsigned char*>(out);
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float send = hi ? ch[c][e] : ch[c + 1][e];
+                const float recv = __shfl_xor(send, 32, 64);
+                v[e] = hi ? recv : ch[c][e];
+                v[4 + e] = hi ? ch[c + 1][e] : recv;
+            }
+            if (q_row < n_query) store_split8(img, (int64_t)b * N + q_row, h * ATT_DH + 8 * (c + hi), d, v);
+        }
+    } else if (q_row < n_query) {
         float* dst = out + ((int64_t)b * N + q_row) * d + h * ATT_DH + 4 * hi;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
@@ -202,7 +226,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_f32_kernel(const float* __res
     }
 }
 
-int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st) {
+template <bool SPLIT>
+static int attn_launch(const float* qkv, float* out, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st) {
     AVD_REQUIRE(qkv && out, AVD_EINVAL, "attn: null pointer");
     AVD_REQUIRE(B > 0 && N > 0 && H > 0, AVD_EINVAL, "attn: bad dims B=%d N=%d H=%d", B, N, H);
     AVD_REQUIRE(Dh == ATT_DH, AVD_EUNSUPPORTED, "attn: head_dim %d unsupported (kernel is built for 64)", Dh);
@@ -214,15 +239,24 @@ int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float sc
     // 2-wave blocks (64 query rows) waste the fewest padded rows on the ragged N of this model
     // (421 -> 448); 4-wave blocks halve K/V re-reads when N is a comfortable multiple of 128.
     const int pad2 = ((n_query + 63) / 64) * 64, pad4 = ((n_query + 127) / 128) * 128;
-    static const int tag4 = prof_tag_id("attn_f32_kernel<4>"), tag2 = prof_tag_id("attn_f32_kernel<2>");
+    static const int tag4 = prof_tag_id(SPLIT ? "attn_f32_kernel<4, true>" : "attn_f32_kernel<4>"),
+                     tag2 = prof_tag_id(SPLIT ? "attn_f32_kernel<2, true>" : "attn_f32_kernel<2>");
     ProfScope prof(pad4 == pad2 ? tag4 : tag2, 4.0 * (double)B * H * (double)n_query * N * ATT_DH, st);
     if (pad4 == pad2) {
-        hipLaunchKernelGGL(attn_f32_kernel<4>, dim3((pad4 / 128) * H * B), dim3(256), 0, st, qkv, out, N, H, scale, n_query, pad4 / 128);
+        hipLaunchKernelGGL((attn_f32_kernel<4, SPLIT>), dim3((pad4 / 128) * H * B), dim3(256), 0, st, qkv, out, N, H, scale, n_query, pad4 / 128);
     } else {
-        hipLaunchKernelGGL(attn_f32_kernel<2>, dim3((pad2 / 64) * H * B), dim3(128), 0, st, qkv, out, N, H, scale, n_query, pad2 / 64);
+        hipLaunchKernelGGL((attn_f32_kernel<2, SPLIT>), dim3((pad2 / 64) * H * B), dim3(128), 0, st, qkv, out, N, H, scale, n_query, pad2 / 64);
     }
     AVD_CHECK_LAUNCH("attn_f32");
     return AVD_OK;
+}
+
+int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st) {
+    return attn_launch<false>(qkv, out, B, N, H, Dh, scale, n_query, st);
+}
+int attn_f32_split3(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st) {
+    AVD_REQUIRE((H * Dh) % 16 == 0, AVD_EUNSUPPORTED, "attn: split3 output needs d %% 16 == 0");
+    return attn_launch<true>(qkv, static_cast<float*>(out3), B, N, H, Dh, scale, n_query, st);
 }
 
 }  // namespace avd
@@ -230,4 +264,9 @@ int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float sc
 extern "C" int avd_attn_fwd_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float scale,
                                 int n_query, avd_stream_t stream) {
     return avd::attn_f32(qkv, out, B, N, H, Dh, scale, n_query, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int avd_attn_fwd_split3_f32(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query,
+                                       avd_stream_t stream) {
+    return avd::attn_f32_split3(qkv, out3, B, N, H, Dh, scale, n_query, static_cast<hipStream_t>(stream));
 }

@@ -76,6 +76,49 @@ struct RowMap {
     }
 };
 
+// ---- split3 operand image of the bf16x3 matmul path (layout and rationale: gemm_bf16x3.hip) ----
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int S3_CHUNK = 128 * 96;
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 -> two bf16 (round to nearest even) packed in one dword: v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned int pk_bf16(float a, float b) {
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned int p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned int p) { return __uint_as_float(p & 0xffff0000u); }
+
+// v[8] -> three 16-byte chunks of 8 bf16: h = rn(x), m = rn(x - h), l = rn(x - h - m); both residuals are exact in fp32
+__device__ __forceinline__ void split8(const float* v, u32x4& H, u32x4& Mi, u32x4& Lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = v[2 * e], b = v[2 * e + 1];
+        const unsigned int h = pk_bf16(a, b);
+        const float ra = a - bf16_lo(h), rb = b - bf16_hi(h);
+        const unsigned int m = pk_bf16(ra, rb);
+        const float sa = ra - bf16_lo(m), sb = rb - bf16_hi(m);
+        H[e] = h;
+        Mi[e] = m;
+        Lo[e] = pk_bf16(sa, sb);
+    }
+}
+
+// where the 8 values (row r, columns k..k+7, k % 8 == 0) of a [rows][K] matrix go in its split3 image
+__device__ __forceinline__ void store_split8(unsigned char* img, int64_t r, int k, int K, const float* v) {
+    u32x4 H, Mi, Lo;
+    split8(v, H, Mi, Lo);
+    const int rr = (int)(r & 127), f = (rr >> 3) & 1, half = (k >> 3) & 1;
+    unsigned char* dst = img + ((r >> 7) * (K >> 4) + (k >> 4)) * (int64_t)S3_CHUNK + rr * 96;
+    *reinterpret_cast<u32x4*>(dst + (((0 + half) ^ f) << 4)) = H;
+    *reinterpret_cast<u32x4*>(dst + (((2 + half) ^ f) << 4)) = Mi;
+    *reinterpret_cast<u32x4*>(dst + (((4 + half) ^ f) << 4)) = Lo;
+}
+
 // measurement hooks (see avd_prof_enable): RAII bracket around one launch
 extern bool g_prof_on;
 void prof_mark(int tag, double work, hipStream_t st, bool begin);
@@ -101,6 +144,7 @@ int64_t split3_bytes(int64_t rows, int K);
 int split3_f32(const float* x, int64_t ld, void* out, int64_t rows, int K, hipStream_t st);
 int rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t rows, int d, float eps, hipStream_t st);
 bool gemm_bf16x3_supported(int64_t M, int N, int K);
+int attn_f32_split3(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st);
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
                 int act, hipStream_t st);
 

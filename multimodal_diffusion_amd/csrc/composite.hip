@@ -97,7 +97,8 @@ static int64_t core_ws_bytes(const avd_core_weights* w, int64_t M) {
     if (!core_use_split(w, M)) return fp32_path;
     // + split3 image of the norm / attention output, and the wide buffer must also hold the split3 image of the MLP hidden
     const int64_t wide_b = M * 3 * w->d * 4 > split3_bytes(M, w->mlp_hidden) ? M * 3 * w->d * 4 : split3_bytes(M, w->mlp_hidden);
-    return align_up(M * w->d * 4) + align_up(wide_b) + align_up(split3_bytes(M, w->d));
+    const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d));
+    return split_path > fp32_path ? split_path : fp32_path;
 }
 
 static int check_core(const avd_core_weights* w) {
@@ -127,7 +128,6 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
     if (core_use_split(w, M)) {
         // same op sequence with the four projections on the bf16 matrix pipe (gemm_bf16x3.hip); hs / wide3 are split3 images
         Carver cs{static_cast<char*>(ws), 0, ws_bytes};
-        float* attn_out = cs.take(M * d);
         const int64_t wide_b = M * 3 * d * 4 > split3_bytes(M, hid) ? M * 3 * d * 4 : split3_bytes(M, hid);
         float* qkv = cs.take((wide_b + 3) / 4);
         void* wide3 = qkv;
@@ -138,8 +138,7 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
             const int nq = (last && out_row0 == 0) ? n_out_rows : N;
             if (int rc = rmsnorm_split3_f32(cur, b.norm1_scale, hs, M, d, w->norm_eps, st)) return rc;
             if (int rc = gemm_bf16x3(hs, b.in_proj_weight3, b.in_proj_bias, nullptr, qkv, nullptr, M, 3 * d, d, AVD_ACT_NONE, st)) return rc;
-            if (int rc = attn_f32(qkv, attn_out, B, N, H, d / H, scale, nq, st)) return rc;
-            if (int rc = split3_f32(attn_out, d, hs, M, d, st)) return rc;
+            if (int rc = attn_f32_split3(qkv, hs, B, N, H, d / H, scale, nq, st)) return rc;
             if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, nullptr, M, d, d, AVD_ACT_NONE, st)) return rc;
             cur = y;
             if (int rc = rmsnorm_split3_f32(y, b.norm2_scale, hs, M, d, w->norm_eps, st)) return rc;

@@ -23,50 +23,8 @@
 
 namespace avd {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-constexpr int S3_CHUNK = 128 * 96;
-
 #define AVD_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define AVD_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
-
-__device__ __forceinline__ unsigned short bf16_rn(float x) {      // round-to-nearest-even on the fp32 bits (finite inputs)
-    unsigned int u = __float_as_uint(x);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-__device__ __forceinline__ float bf16_f(unsigned short h) { return __uint_as_float((unsigned int)h << 16); }
-
-// v[8] -> three 16-byte chunks of 8 bf16: h = rn(x), m = rn(x - h), l = rn(x - h - m); both residuals are exact in fp32
-__device__ __forceinline__ void split8(const float* v, u32x4& H, u32x4& Mi, u32x4& Lo) {
-    unsigned short h[8], m[8], l[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        h[e] = bf16_rn(v[e]);
-        const float r1 = v[e] - bf16_f(h[e]);
-        m[e] = bf16_rn(r1);
-        const float r2 = r1 - bf16_f(m[e]);
-        l[e] = bf16_rn(r2);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        H[e] = (unsigned int)h[2 * e] | ((unsigned int)h[2 * e + 1] << 16);
-        Mi[e] = (unsigned int)m[2 * e] | ((unsigned int)m[2 * e + 1] << 16);
-        Lo[e] = (unsigned int)l[2 * e] | ((unsigned int)l[2 * e + 1] << 16);
-    }
-}
-
-// where the 8 values (row r, columns k..k+7, k % 8 == 0) of a [rows][K] matrix go in its split3 image
-__device__ __forceinline__ void store_split8(unsigned char* img, int64_t r, int k, int K, const float* v) {
-    u32x4 H, Mi, Lo;
-    split8(v, H, Mi, Lo);
-    const int rr = (int)(r & 127), f = (rr >> 3) & 1, half = (k >> 3) & 1;
-    unsigned char* dst = img + ((r >> 7) * (K >> 4) + (k >> 4)) * (int64_t)S3_CHUNK + rr * 96;
-    *reinterpret_cast<u32x4*>(dst + (((0 + half) ^ f) << 4)) = H;
-    *reinterpret_cast<u32x4*>(dst + (((2 + half) ^ f) << 4)) = Mi;
-    *reinterpret_cast<u32x4*>(dst + (((4 + half) ^ f) << 4)) = Lo;
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // producers

@@ -725,3 +725,16 @@ def test_full_step_bf16x3_vs_oracle(dev, full):
     out = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev))
     assert torch.equal(out, eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)))        # deterministic
     assert rel_err(out[:nb].cpu(), ref) < TOL
+
+
+def test_attention_split3_output(dev):
+    """The attention kernel's split3 epilogue holds exactly the fp32 values of the plain kernel."""
+    import ctypes as C
+    from multimodal_diffusion_amd import functional as Fn, _lib as L
+    B, N, H = 3, 133, 8
+    qkv = torch.randn(B, N, 3 * H * 64, generator=torch.Generator().manual_seed(5)).to(dev)
+    ref = Fn.attention(qkv, H).cpu().double().numpy().reshape(B * N, H * 64)
+    img = torch.zeros(L.lib().avd_split3_bytes(B * N, H * 64), dtype=torch.uint8, device=dev)
+    L.check(L.lib().avd_attn_fwd_split3_f32(qkv.data_ptr(), img.data_ptr(), B, N, H, 64, 0.125, N, L.stream_ptr(dev)))
+    got = _split3_decode(img.cpu().numpy(), B * N, H * 64).astype(np.float64).sum(0)
+    assert np.array_equal(got, ref)
