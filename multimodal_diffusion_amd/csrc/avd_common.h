@@ -80,7 +80,8 @@ struct RowMap {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int S3_CHUNK = 128 * 96;
+constexpr int S3_CHUNK = 128 * 96;   // one (128-row tile, 16-k group) chunk: three planes of [128 rows][32 B]
+constexpr int S3_PLANE = 128 * 32;
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -112,11 +113,11 @@ __device__ __forceinline__ void split8(const float* v, u32x4& H, u32x4& Mi, u32x
 __device__ __forceinline__ void store_split8(unsigned char* img, int64_t r, int k, int K, const float* v) {
     u32x4 H, Mi, Lo;
     split8(v, H, Mi, Lo);
-    const int rr = (int)(r & 127), f = (rr >> 3) & 1, half = (k >> 3) & 1;
-    unsigned char* dst = img + ((r >> 7) * (K >> 4) + (k >> 4)) * (int64_t)S3_CHUNK + rr * 96;
-    *reinterpret_cast<u32x4*>(dst + (((0 + half) ^ f) << 4)) = H;
-    *reinterpret_cast<u32x4*>(dst + (((2 + half) ^ f) << 4)) = Mi;
-    *reinterpret_cast<u32x4*>(dst + (((4 + half) ^ f) << 4)) = Lo;
+    const int rr = (int)(r & 127), half = (k >> 3) & 1;
+    unsigned char* dst = img + ((r >> 7) * (K >> 4) + (k >> 4)) * (int64_t)S3_CHUNK + rr * 32 + ((half ^ ((rr >> 3) & 1)) << 4);
+    *reinterpret_cast<u32x4*>(dst) = H;
+    *reinterpret_cast<u32x4*>(dst + S3_PLANE) = Mi;
+    *reinterpret_cast<u32x4*>(dst + 2 * S3_PLANE) = Lo;
 }
 
 // measurement hooks (see avd_prof_enable): RAII bracket around one launch

@@ -9,9 +9,10 @@
 // K=2048 with |C| ~ 460 (tools/micro/split_lab2.hip check).  Six bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64
 // cycles per k=16: 2.67x fewer matrix-pipe cycles.
 //
-// Operand image ("split3"): X[rows][K] fp32 -> T[ceil(rows/128)][K/16][128 rows][96 B]; row r of a chunk at r*96, the
-// 16-byte slot of (plane p, half = (k%16)/8) at ((2p + half) ^ ((r>>3)&1))*16.  One block's K-tile of an operand is
-// then one contiguous, already bank-swizzled 12 KiB chunk: the global->LDS DMA is a linear copy of whole cache lines
+// Operand image ("split3"): X[rows][K] fp32 -> T[ceil(rows/128)][K/16][3 planes][128 rows][32 B]; inside a 12 KiB chunk
+// the 16 bytes of (plane p, row r, half = (k%16)/8) sit at p*4096 + r*32 + (half ^ ((r>>3)&1))*16.  One block's K-tile of
+// an operand is then one contiguous, already bank-swizzled chunk, and a producer's store of one plane for consecutive
+// rows is contiguous too: the global->LDS DMA is a linear copy of whole cache lines
 // and the ds_read_b128 of fragment rows is conflict free.  Producers (RMSNorm, the fc1+GELU epilogue, the split pass
 // after attention) write this image directly, so no fp32 copy of those activations exists in this mode.
 //
@@ -107,7 +108,7 @@ constexpr int S3_LDS = S3_NST * S3_STAGE;                // 144 KiB (the epilogu
 
 template <int EPI>
 __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
-    constexpr int BM = S3_BM, BN = S3_BN, WM = 128, WN = 64, ROWB = 96;
+    constexpr int BM = S3_BM, BN = S3_BN, WM = 128, WN = 64;
     constexpr int TM = 4, TN = 2, NST = S3_NST, STAGE = S3_STAGE;
     constexpr int PPW = 6;                                // 48 one-KiB pieces per stage / 8 waves
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
@@ -164,12 +165,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = wm * WM + i * 32 + l31;
-        a_off[i] = r * ROWB + ((hi ^ ((r >> 3) & 1)) << 4);
+        a_off[i] = (r >> 7) * S3_CHUNK + (r & 127) * 32 + ((hi ^ ((r >> 3) & 1)) << 4);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int r = BM + wn * WN + j * 32 + l31;
-        b_off[j] = r * ROWB + ((hi ^ ((r >> 3) & 1)) << 4);
+        b_off[j] = (r >> 7) * S3_CHUNK + (r & 127) * 32 + ((hi ^ ((r >> 3) & 1)) << 4);
     }
 
     const int nk = ng;
@@ -187,11 +188,11 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + 32 * p);
+            for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + S3_PLANE * p);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + 32 * p);
+            for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + S3_PLANE * p);
         // (l,h) (h,l) (m,m) (m,h) (h,m) (h,h): small terms first
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
         constexpr int PB[6] = {0, 2, 1, 0, 1, 0};

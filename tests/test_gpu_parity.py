@@ -620,14 +620,13 @@ def _split3_decode(img: np.ndarray, rows: int, K: int) -> np.ndarray:
     """Independent reading of the split3 image layout (include/avdiff_hip.h, csrc/gemm_bf16x3.hip): -> planes [3, rows, K]."""
     r = np.arange(rows)[:, None]
     k = np.arange(K)[None, :]
-    base = ((r >> 7) * (K // 16) + (k >> 4)) * (128 * 96) + (r & 127) * 96 + (k & 7) * 2
     f = ((r & 127) >> 3) & 1
     half = (k >> 3) & 1
+    base = ((r >> 7) * (K // 16) + (k >> 4)) * (128 * 96) + (r & 127) * 32 + ((half ^ f) * 16) + (k & 7) * 2
     u16 = img.view(np.uint16)
     planes = []
     for p in range(3):
-        off = base + (((2 * p + half) ^ f) * 16)
-        bits = u16[off // 2].astype(np.uint32) << 16
+        bits = u16[(base + p * 4096) // 2].astype(np.uint32) << 16
         planes.append(bits.view(np.float32))
     return np.stack(planes)
 
