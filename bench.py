@@ -53,16 +53,14 @@ PEAK_BF16X3_EQUIV_TFLOPS = PEAK_BF16_MATRIX_TFLOPS / 6.0
 def pmc_traffic(kernel_tag: str):
     """HBM-side bytes per launch of `kernel_tag` from the newest committed PMC pass (tools/pmc_traffic.py), or None.
     The PMC passes cannot run inside this process (rocprofv3 wraps the command), so the figure is read back."""
-    files = sorted((ROOT / "profiles").glob("r*_traffic.json"))
-    if not files:
-        return None
-    try:
-        ks = json.loads(files[-1].read_text())["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
-    for name, v in ks.items():
-        if kernel_tag in name:
-            return v["traffic_bytes_per_launch"]
+    for f in sorted((ROOT / "profiles").glob("r*_traffic*.json"), reverse=True):      # newest round first
+        try:
+            ks = json.loads(f.read_text())["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        for name, v in ks.items():
+            if kernel_tag in name:
+                return v["traffic_bytes_per_launch"]
     return None
 
 
