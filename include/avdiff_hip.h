@@ -200,6 +200,17 @@ int avd_rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_
 /* avd_attn_fwd_f32 whose [B*N, H*Dh] result is written as a split3 image (rows >= n_query of a sample are left untouched) */
 int avd_attn_fwd_split3_f32(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query,
                             avd_stream_t stream);
+/* bf16x3 attention (csrc/attn_bf16x3.hip): in_proj writes q, k, v as a "qkv3 image" (three bf16 planes per value, per
+ * (part, sample, head) rows of 384 B, q pre-multiplied by qscale = softmax scale * log2 e), the attention kernel reads it.
+ * Same reference op as avd_attn_fwd_f32 (mmdt.py:51-61), same fp32-level error. */
+int64_t avd_qkv3_bytes(int B, int N, int H);                       /* bytes of the image for [B,N,3*H*64] */
+/* qkv = A W^T + bias, A3/W3 split3 images of A [M,K] (M = B*tokens rows) and in_proj_weight [3*heads*64, K] */
+int avd_gemm_bf16x3_qkv3_f32(const void* A3, const void* W3, const float* bias, void* qkv3, int64_t M, int tokens,
+                             int heads, int K, float qscale, avd_stream_t stream);
+/* softmax(q k^T) v from a qkv3 image; out3 == NULL: fp32 out [B,N,H*64]; else the split3 image of [B*N, H*64].
+ * Rows >= n_query of every sample are not computed and left untouched. */
+int avd_attn_fwd_qkv3_f32(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query,
+                          avd_stream_t stream);
 /* C = act(A W^T + bias) (+ residual), A3/W3 split3 images of A [M,K] and W [N,K]; N % 256 == 0, K % 16 == 0.
  * C3 == NULL: fp32 row-major C [M,N], act AVD_ACT_NONE, residual optional (may alias C).
  * C3 != NULL: the result is written as the split3 image of [M,N] instead (bias + AVD_ACT_GELU, no residual). */

@@ -111,6 +111,9 @@ SIGNATURES = {
     "avd_split3_f32": (_I, [_P, _P, _L, _I, _P]),
     "avd_rmsnorm_split3_f32": (_I, [_P, _P, _P, _L, _I, _F, _P]),
     "avd_attn_fwd_split3_f32": (_I, [_P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "avd_qkv3_bytes": (_L, [_I, _I, _I]),
+    "avd_gemm_bf16x3_qkv3_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
+    "avd_attn_fwd_qkv3_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "avd_gemm_bf16x3_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
     "avd_vae_decode_workspace_bytes": (_L, [C.POINTER(VaeDecodeDesc)]),
     "avd_vae_decode_f32": (_I, [C.POINTER(VaeDecodeDesc), _P, _P, _P, _L, _P]),

@@ -1,0 +1,286 @@
+// fp32-accurate attention on the bf16 matrix pipe — the bf16x3 counterpart of attn_f32.hip
+// (nn.MultiheadAttention's scaled-dot-product step, avdiff/models/mmdt.py:51-61), used with gemm_bf16x3.hip.
+//
+// Both contractions run on v_mfma_f32_32x32x16_bf16 with exactly split operands (x = h + m + l, six product terms,
+// fp32 accumulation; rationale and error analysis in gemm_bf16x3.hip):
+//   S^T = K Q^T : K and Q planes come from the qkv3 image the in_proj GEMM epilogue wrote (q pre-multiplied by
+//                 scale * log2 e, so the scores are already in the exp2 domain);
+//   softmax     : in registers, as in attn_f32.hip (a lane holds 16 + 16 keys of ONE query column);
+//   O^T = V^T P^T: P is split in registers (v_cvt_pk_bf16_f32) and, because an MFMA may sum k in any order, the score
+//                 accumulators feed the B operand without moving between lanes; V stays row-major [key][d] in LDS and is
+//                 read transposed by ds_read_b64_tr_b16 (4 keys x 16 d per 16-lane group) in the key order P has.
+// K/V tiles of 64 keys are 24 KiB contiguous, pre-swizzled pieces of the image: the global->LDS DMA is a linear copy.
+// Measured (B=64, N=421, H=8): 153 us against 232 us for the fp32-MFMA kernel, i.e. ~0.9 PFLOP/s of bf16 MFMA issue,
+// which is where softmax VALU work and the power-limited clock leave a bf16 attention loop on this chip.
+#include "avd_common.h"
+
+namespace avd {
+
+constexpr int A3_DH = 64, A3_KT = 64, A3_NW = 4;
+constexpr float A3_NEG = -1.0e30f;
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#define AVD_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define AVD_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+template <bool SPLIT_OUT>   // SPLIT_OUT: the [B*N, H*64] result is written as a split3 image (A operand of out_proj)
+__global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsigned char* __restrict__ img, float* __restrict__ out,
+                                                                    int Bt, int N, int Npad, int H, int n_query, int nqb) {
+    constexpr int NW = A3_NW, ROWB = QKV3_ROWB;
+    constexpr int PPW = 24 / NW;                       // 1-KiB DMA pieces per wave per 24 KiB operand tile
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[A3_KT * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[A3_KT * ROWB];
+
+    // XCD-aware 1-D grid: the q-blocks of one (sample, head) — which re-read the same K/V — share an L2
+    int qb, h, b;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = id & 7;
+        const int w = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+        qb = w % nqb;
+        h = (w / nqb) % H;
+        b = w / (nqb * H);
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int64_t hstride = (int64_t)Npad * ROWB;
+    const unsigned char* Qb = img + (((int64_t)0 * Bt + b) * H + h) * hstride;
+    const unsigned char* Kb = img + (((int64_t)1 * Bt + b) * H + h) * hstride;
+    const unsigned char* Vb = img + (((int64_t)2 * Bt + b) * H + h) * hstride;
+
+    // Q fragments: lane (q = l31, half hi), d-step s: Q[q][16 s + 8 hi .. +7] of each plane
+    const int q_row = qb * (NW * 32) + wave * 32 + l31;
+    bf16x8 qf[4][3];
+    {
+        const unsigned char* src = Qb + (int64_t)(q_row < N ? q_row : N - 1) * ROWB + hi * 16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) qf[s][p] = *reinterpret_cast<const bf16x8*>(src + p * 128 + s * 32);
+    }
+
+    // DMA of tile kt: linear, except that rows past the last token are fetched from token N-1 (finite filler: the scores
+    // of those keys are masked, and a zero probability times a finite V is zero)
+    auto dma = [&](const unsigned char* gsrc, unsigned char* ldst, int kt) {
+        const int last_row = N - 1 - kt * A3_KT;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + NW * i;
+            const int off = p * 1024 + lane * 16;
+            int row = off / ROWB;
+            const int within = off - row * ROWB;
+            row = row < last_row ? row : last_row;
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(gsrc + ((int64_t)kt * A3_KT + row) * ROWB + within), AVD_LDS_PTR(ldst + p * 1024), 16,
+                                             0, 0);
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = A3_NEG, l_run = 0.f;
+
+    const int nkt = (N + A3_KT - 1) / A3_KT;
+    dma(Kb, Ks, 0);
+    dma(Vb, Vs, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+    __syncthreads();
+
+    // K row reads: key = 32 kb + l31, chunk (2 s + hi) ^ ((key>>1)&7)  (the swizzle is the same for key and key + 32)
+    const int ksw = (l31 >> 1) & 7;
+    const int k_rd = l31 * ROWB;
+    // V transposed reads: 16-lane group g = lane>>4 takes d columns 16 (g&1) .. +15 of a 32-d block; lane 4q+p of the group
+    // supplies the address of key row q, columns 4p .. 4p+3, and receives column (lane & 15) of the four rows
+    const int i16 = lane & 15, cb = (lane >> 4) & 1;
+    const int v_q = i16 >> 2, v_p = i16 & 3;
+
+    const bool active = qb * (NW * 32) + wave * 32 < n_query;   // wave-uniform: a wave of padding rows only loads
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = (kt + 1) < nkt;
+        if (!active) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+            if (more) dma(Kb, Ks, kt + 1);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __syncthreads();
+            if (more) dma(Vb, Vs, kt + 1);
+            continue;
+        }
+        // ---- S^T = K Q^T for keys [0,32) and [32,64) of the tile (reads Ks only) ----
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+        // (K plane, Q plane) resp. (V plane, P plane): (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 ka[3], kb2[3];
+            const int ch = ((2 * s + hi) ^ ksw) << 4;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                ka[p] = *reinterpret_cast<const bf16x8*>(Ks + k_rd + p * 128 + ch);
+                kb2[p] = *reinterpret_cast<const bf16x8*>(Ks + k_rd + 32 * ROWB + p * 128 + ch);
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[PA[t]], qf[s][PB[t]], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[PA[t]], qf[s][PB[t]], s1, 0, 0, 0);
+            }
+        }
+        // K is free once every wave is here; V(kt) (issued a phase ago) has landed after the wait
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        if (more) dma(Kb, Ks, kt + 1);
+
+        if (!more && (N & (A3_KT - 1))) {   // ragged last tile: keys >= N contribute nothing
+            const int kbase = kt * A3_KT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kbase + mfma32_row(r, hi);
+                if (key >= N) s0[r] = A3_NEG;
+                if (key + 32 >= N) s1[r] = A3_NEG;
+            }
+        }
+
+        // ---- online softmax for this lane's query column (scores are in the exp2 domain) ----
+        float mt = s0[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s0[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s1[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+            ps += s0[r] + s1[r];
+        }
+        if (__any(m_new > m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+        l_run += ps;
+        m_run = m_new;
+
+        // ---- O^T += V^T P^T (reads Vs only): k-step (kb, t) covers keys 32 kb + 16 t + 4 hi + (j&3) + 8 (j>>2), j = fragment
+        //      element — the key order in which accumulator registers 8t .. 8t+7 of S^T hold P ----
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float pv[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pv[j] = kb ? s1[8 * t + j] : s0[8 * t + j];
+                u32x4 P[3];
+                split8(pv, P[0], P[1], P[2]);
+                bf16x8 pf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) pf[p] = __builtin_bit_cast(bf16x8, P[p]);
+                const int key0 = 32 * kb + 16 * t + 4 * hi + v_q;     // this lane's ADDRESS row of the first 4-key block
+                const int sw = ((key0 >> 1) & 1) << 2;                // same for key0 + 8
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    const int chunk = 4 * db + 2 * cb + (v_p >> 1);
+                    bf16x8 vf[3];
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)AVD_LDS_PTR(
+                            Vs + key0 * ROWB + p * 128 + ((chunk ^ sw) << 4) + 8 * (v_p & 1)));
+                        const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)AVD_LDS_PTR(
+                            Vs + (key0 + 8) * ROWB + p * 128 + ((chunk ^ sw) << 4) + 8 * (v_p & 1)));
+                        const u32x2 a = __builtin_bit_cast(u32x2, lo), c2 = __builtin_bit_cast(u32x2, up);
+                        const u32x4 w = {a[0], a[1], c2[0], c2[1]};
+                        vf[p] = __builtin_bit_cast(bf16x8, w);
+                    }
+#pragma unroll
+                    for (int tt = 0; tt < 6; ++tt) {
+                        if (db == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PA[tt]], pf[PB[tt]], o0, 0, 0, 0);
+                        else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PA[tt]], pf[PB[tt]], o1, 0, 0, 0);
+                    }
+                }
+            }
+        // V is free once every wave is here; K(kt+1) has landed after the wait
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+        if (more) dma(Vb, Vs, kt + 1);
+    }
+    if (!active) return;      // no barriers below
+
+    // ---- normalise and store: lane (q, hi) holds O[q][8 g + 4 hi + (0..3)] in regs 4g..4g+3 of o0 (d < 32) / o1 ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    const int d = H * A3_DH;
+    if constexpr (SPLIT_OUT) {
+        float ch[8][4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ch[g4][e] = o0[4 * g4 + e] * inv;
+                ch[4 + g4][e] = o1[4 * g4 + e] * inv;
+            }
+        unsigned char* o3 = reinterpret_cast<unsigned char*>(out);
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) {     // the low half-lane ends up with even 8-d chunks, the high half-lane with odd ones
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float send = hi ? ch[c][e] : ch[c + 1][e];
+                const float recv = __shfl_xor(send, 32, 64);
+                v[e] = hi ? recv : ch[c][e];
+                v[4 + e] = hi ? ch[c + 1][e] : recv;
+            }
+            if (q_row < n_query) store_split8(o3, (int64_t)b * N + q_row, h * A3_DH + 8 * (c + hi), d, v);
+        }
+    } else if (q_row < n_query) {
+        float* dst = out + ((int64_t)b * N + q_row) * d + h * A3_DH + 4 * hi;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 a = {o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv};
+            f32x4 c = {o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv};
+            *reinterpret_cast<f32x4*>(dst + 8 * g4) = a;
+            *reinterpret_cast<f32x4*>(dst + 32 + 8 * g4) = c;
+        }
+    }
+}
+
+int64_t qkv3_bytes(int B, int N, int H) { return (int64_t)3 * B * H * qkv3_npad(N) * QKV3_ROWB; }
+
+// out3 != null: split3 image of the [B*N, H*64] result; otherwise fp32 out [B, N, H*64]
+int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, hipStream_t st) {
+    AVD_REQUIRE(qkv3 && (out || out3), AVD_EINVAL, "attn_bf16x3: null pointer");
+    AVD_REQUIRE(B > 0 && N > 0 && H > 0, AVD_EINVAL, "attn_bf16x3: bad dims B=%d N=%d H=%d", B, N, H);
+    AVD_REQUIRE(n_query >= 0 && n_query <= N, AVD_EINVAL, "attn_bf16x3: n_query=%d outside [0,%d]", n_query, N);
+    AVD_REQUIRE(aligned16(qkv3) && aligned16(out) && aligned16(out3), AVD_EUNSUPPORTED, "attn_bf16x3: pointers must be 16-byte aligned");
+    AVD_REQUIRE(!out3 || (H * A3_DH) % 16 == 0, AVD_EUNSUPPORTED, "attn_bf16x3: split3 output needs d %% 16 == 0");
+    if (n_query == 0) return AVD_OK;
+    const int nqb = (n_query + 32 * A3_NW - 1) / (32 * A3_NW);
+    AVD_REQUIRE((int64_t)B * H * nqb < (1ll << 31), AVD_EUNSUPPORTED, "attn_bf16x3: grid too large");
+    static const int tag = prof_tag_id("attn_bf16x3_kernel");
+    ProfScope prof(tag, 4.0 * (double)B * H * (double)n_query * N * A3_DH, st);
+    const int Npad = qkv3_npad(N);
+    const auto* img = static_cast<const unsigned char*>(qkv3);
+    if (out3)
+        hipLaunchKernelGGL(attn_bf16x3_kernel<true>, dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, static_cast<float*>(out3), B, N, Npad, H,
+                           n_query, nqb);
+    else
+        hipLaunchKernelGGL(attn_bf16x3_kernel<false>, dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, out, B, N, Npad, H, n_query, nqb);
+    AVD_CHECK_LAUNCH("attn_bf16x3");
+    return AVD_OK;
+}
+
+}  // namespace avd
+
+extern "C" int64_t avd_qkv3_bytes(int B, int N, int H) {
+    if (B <= 0 || N <= 0 || H <= 0) return -1;
+    return avd::qkv3_bytes(B, N, H);
+}
+extern "C" int avd_attn_fwd_qkv3_f32(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, avd_stream_t stream) {
+    return avd::attn_bf16x3(qkv3, out, out3, B, N, H, n_query, static_cast<hipStream_t>(stream));
+}

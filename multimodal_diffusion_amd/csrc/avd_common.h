@@ -120,6 +120,15 @@ __device__ __forceinline__ void store_split8(unsigned char* img, int64_t r, int 
     *reinterpret_cast<u32x4*>(dst + 2 * S3_PLANE) = Lo;
 }
 
+// ---- qkv3 image of the bf16x3 attention (attn_bf16x3.hip): for part in {q,k,v}, sample b, head h, rows n in [0,Npad) of
+// 384 B = [plane h | m | l][64 d bf16]; the 16-byte chunk c (8 d) of a row sits at slot c ^ qkv3_swizzle(part, n) ----
+constexpr int QKV3_ROWB = 384;
+__host__ __device__ __forceinline__ int qkv3_npad(int n) { return (n + 63) / 64 * 64; }
+__host__ __device__ __forceinline__ int qkv3_swizzle(int part, int n) {
+    // q: read straight from global; k: ds_read_b128 of 32 key rows; v: ds_read_b64_tr_b16 of 4-key x 16-d blocks
+    return part == 0 ? 0 : part == 1 ? (n >> 1) & 7 : ((n >> 1) & 1) << 2;
+}
+
 // measurement hooks (see avd_prof_enable): RAII bracket around one launch
 extern bool g_prof_on;
 void prof_mark(int tag, double work, hipStream_t st, bool begin);
@@ -146,6 +155,10 @@ int split3_f32(const float* x, int64_t ld, void* out, int64_t rows, int K, hipSt
 int rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t rows, int d, float eps, hipStream_t st);
 bool gemm_bf16x3_supported(int64_t M, int N, int K);
 int attn_f32_split3(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st);
+int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* img, int64_t M, int tokens, int heads, int K, float qscale,
+                     hipStream_t st);
+int64_t qkv3_bytes(int B, int N, int H);
+int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, hipStream_t st);
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
                 int act, hipStream_t st);
 

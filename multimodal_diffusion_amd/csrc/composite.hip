@@ -91,12 +91,19 @@ static bool core_use_split(const avd_core_weights* w, int64_t M) {
     return true;
 }
 
-static int64_t core_ws_bytes(const avd_core_weights* w, int64_t M) {
+// the wide scratch of the bf16x3 path holds the qkv3 image, then the fc1 image
+static int64_t core_split_wide_bytes(const avd_core_weights* w, int B, int N) {
+    const int64_t qkv3 = qkv3_bytes(B, N, w->n_heads), fc1 = split3_bytes((int64_t)B * N, w->mlp_hidden);
+    return qkv3 > fc1 ? qkv3 : fc1;
+}
+
+static int64_t core_ws_bytes(const avd_core_weights* w, int B, int N) {
+    const int64_t M = (int64_t)B * N;
     const int wide = 3 * w->d > w->mlp_hidden ? 3 * w->d : w->mlp_hidden;
     int64_t fp32_path = align_up(M * w->d * 4) + align_up(M * wide * 4);
     if (!core_use_split(w, M)) return fp32_path;
     // + split3 image of the norm / attention output, and the wide buffer must also hold the split3 image of the MLP hidden
-    const int64_t wide_b = M * 3 * w->d * 4 > split3_bytes(M, w->mlp_hidden) ? M * 3 * w->d * 4 : split3_bytes(M, w->mlp_hidden);
+    const int64_t wide_b = core_split_wide_bytes(w, B, N);
     const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d));
     return split_path > fp32_path ? split_path : fp32_path;
 }
@@ -116,8 +123,8 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
     AVD_REQUIRE(x && y && B > 0 && N > 0, AVD_EINVAL, "core: bad input");
     AVD_REQUIRE(out_row0 >= 0 && n_out_rows > 0 && out_row0 + n_out_rows <= N, AVD_EINVAL, "core: bad output row window");
     const int64_t M = (int64_t)B * N;
-    AVD_REQUIRE(ws && ws_bytes >= core_ws_bytes(w, M), AVD_EWORKSPACE, "core: workspace %lld < %lld bytes",
-                (long long)ws_bytes, (long long)core_ws_bytes(w, M));
+    AVD_REQUIRE(ws && ws_bytes >= core_ws_bytes(w, B, N), AVD_EWORKSPACE, "core: workspace %lld < %lld bytes",
+                (long long)ws_bytes, (long long)core_ws_bytes(w, B, N));
     const int d = w->d, hid = w->mlp_hidden, H = w->n_heads;
     Carver cv{static_cast<char*>(ws), 0, ws_bytes};
     float* hbuf = cv.take(M * d);                                   // norm output, then attention output
@@ -128,7 +135,7 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
     if (core_use_split(w, M)) {
         // same op sequence with the four projections on the bf16 matrix pipe (gemm_bf16x3.hip); hs / wide3 are split3 images
         Carver cs{static_cast<char*>(ws), 0, ws_bytes};
-        const int64_t wide_b = M * 3 * d * 4 > split3_bytes(M, hid) ? M * 3 * d * 4 : split3_bytes(M, hid);
+        const int64_t wide_b = core_split_wide_bytes(w, B, N);
         float* qkv = cs.take((wide_b + 3) / 4);
         void* wide3 = qkv;
         void* hs = cs.take((split3_bytes(M, d) + 3) / 4);
@@ -137,8 +144,8 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
             const bool last = l == w->n_layers - 1;
             const int nq = (last && out_row0 == 0) ? n_out_rows : N;
             if (int rc = rmsnorm_split3_f32(cur, b.norm1_scale, hs, M, d, w->norm_eps, st)) return rc;
-            if (int rc = gemm_bf16x3(hs, b.in_proj_weight3, b.in_proj_bias, nullptr, qkv, nullptr, M, 3 * d, d, AVD_ACT_NONE, st)) return rc;
-            if (int rc = attn_f32_split3(qkv, hs, B, N, H, d / H, scale, nq, st)) return rc;
+            if (int rc = gemm_bf16x3_qkv3(hs, b.in_proj_weight3, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, st)) return rc;
+            if (int rc = attn_bf16x3(qkv, nullptr, hs, B, N, H, nq, st)) return rc;
             if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, nullptr, M, d, d, AVD_ACT_NONE, st)) return rc;
             cur = y;
             if (int rc = rmsnorm_split3_f32(y, b.norm2_scale, hs, M, d, w->norm_eps, st)) return rc;
@@ -277,7 +284,7 @@ static int plan_step(const avd_step_desc* s, StepPlan& p) {
     p.x2 = align_up((int64_t)2 * e.B * p.N * e.d * 4);
     p.tok = align_up(embed_ws_floats(&e) * 4);
     // one slice per CFG half (they may run on two streams), or the stacked 2B batch in one piece, whichever is larger
-    const int64_t halves = 2 * core_ws_bytes(s->core, (int64_t)e.B * p.N), whole = core_ws_bytes(s->core, 2 * (int64_t)e.B * p.N);
+    const int64_t halves = 2 * core_ws_bytes(s->core, e.B, p.N), whole = core_ws_bytes(s->core, 2 * e.B, p.N);
     p.core = halves > whole ? halves : whole;
     p.head = 2 * head_ws_bytes(s->head, p.rows / 2);
     p.eps = align_up(p.rows * p.D * 4);
@@ -304,7 +311,7 @@ extern "C" int avd_device_arch(char* buf, int buflen) {
 
 extern "C" int64_t avd_core_workspace_bytes(const avd_core_weights* w, int B, int N) {
     if (!w || B <= 0 || N <= 0) return -1;
-    return core_ws_bytes(w, (int64_t)B * N);
+    return core_ws_bytes(w, B, N);
 }
 extern "C" int avd_core_forward_f32(const avd_core_weights* w, const float* x, float* y, int B, int N, int out_row0,
                                     int n_out_rows, void* workspace, int64_t workspace_bytes, avd_stream_t stream) {

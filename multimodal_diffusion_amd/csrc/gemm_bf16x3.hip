@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void rmsnorm_split3_kernel(const float* __rest
 // ---------------------------------------------------------------------------------------------------------
 // GEMM
 // ---------------------------------------------------------------------------------------------------------
-enum { S3_EPI_BIAS = 0, S3_EPI_RES = 2, S3_EPI_GELU_SPLIT = 3 };
+enum { S3_EPI_BIAS = 0, S3_EPI_RES = 2, S3_EPI_GELU_SPLIT = 3, S3_EPI_QKV3 = 4 };
 
 struct S3Args {
     const unsigned char* A;   // split3 image of [M][K]
@@ -95,6 +95,8 @@ struct S3Args {
     unsigned char* C3;        // split3 image of [M][N] (EPI_GELU_SPLIT)
     int64_t M;
     int N, K, nbn, sm, sn;
+    int tokN, tokNpad, heads;   // EPI_QKV3: tokens per sample, padded tokens per sample, heads (N == 3 * heads * 64)
+    float qscale;               // EPI_QKV3: factor folded into q before it is split (softmax scale * log2 e)
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() {
@@ -219,7 +221,37 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) slab[(i * 32 + mfma32_row(r, hi)) * CLD + j * 32 + l31] = acc[ps * 2 + i][j][r];
         const int64_t m0 = (int64_t)bm * BM + wm * WM + ps * 64;
-        if constexpr (EPI == S3_EPI_GELU_SPLIT) {
+        if constexpr (EPI == S3_EPI_QKV3) {
+            // packed in_proj output -> the qkv3 image attn_bf16x3.hip reads: a wave's 64 columns are one (part, head)
+            const int cr = lane >> 3, c = lane & 7;
+            const int n = nbase + c * 8;
+            const int dmodel = g.heads * 64;
+            const int part = nbase / dmodel, head = (nbase % dmodel) >> 6;
+            const int Bt = (int)(g.M / g.tokN);
+            float bv[8];
+            *reinterpret_cast<f32x4*>(bv) = *reinterpret_cast<const f32x4*>(g.bias + n);
+            *reinterpret_cast<f32x4*>(bv + 4) = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
+            const float mul = part == 0 ? g.qscale : 1.0f;
+            unsigned char* pbase = g.C3 + (((int64_t)part * Bt) * g.heads + head) * (int64_t)g.tokNpad * QKV3_ROWB;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int64_t m = m0 + cr + it * 8;
+                float v[8];
+                *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + c * 8);
+                *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + c * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * mul;
+                if (m < g.M) {
+                    const int b = (int)(m / g.tokN), tok = (int)(m - (int64_t)b * g.tokN);
+                    u32x4 Hh, Mi, Lo;
+                    split8(v, Hh, Mi, Lo);
+                    unsigned char* dst = pbase + ((int64_t)b * g.heads * g.tokNpad + tok) * QKV3_ROWB + ((c ^ qkv3_swizzle(part, tok)) << 4);
+                    *reinterpret_cast<u32x4*>(dst) = Hh;
+                    *reinterpret_cast<u32x4*>(dst + 128) = Mi;
+                    *reinterpret_cast<u32x4*>(dst + 256) = Lo;
+                }
+            }
+        } else if constexpr (EPI == S3_EPI_GELU_SPLIT) {
             // 8 lanes per row (8 columns each), 8 rows per wave instruction
             const int cr = lane >> 3, cc = (lane & 7) * 8;
             const int n = nbase + cc;
@@ -343,7 +375,7 @@ int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* 
     AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(C) && aligned16(C3) && aligned16(bias) && aligned16(R), AVD_EUNSUPPORTED,
                 "gemm_bf16x3: pointers must be 16-byte aligned");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, R, C,
-             static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0};
+             static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0, 0, 0, 0, 0.f};
     if (C3) {
         AVD_REQUIRE(act == AVD_ACT_GELU && !R && bias, AVD_EUNSUPPORTED, "gemm_bf16x3: split3 output implies bias + GELU, no residual");
         return launch_s3<S3_EPI_GELU_SPLIT>(a, st);
@@ -351,6 +383,20 @@ int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* 
     AVD_REQUIRE(act == AVD_ACT_NONE, AVD_EUNSUPPORTED, "gemm_bf16x3: fp32 output supports act NONE only");
     if (R) return launch_s3<S3_EPI_RES>(a, st);
     return launch_s3<S3_EPI_BIAS>(a, st);
+}
+
+// in_proj for the bf16x3 attention: qkv = A W^T + bias written as the qkv3 image (q pre-multiplied by qscale)
+int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* img, int64_t M, int tokens, int heads, int K, float qscale,
+                     hipStream_t st) {
+    AVD_REQUIRE(A3 && W3 && bias && img, AVD_EINVAL, "gemm_bf16x3_qkv3: null pointer");
+    const int N = 3 * heads * 64;
+    AVD_REQUIRE(tokens > 0 && heads > 0 && M > 0 && M % tokens == 0, AVD_EINVAL, "gemm_bf16x3_qkv3: rows %lld not a multiple of tokens %d",
+                (long long)M, tokens);
+    AVD_REQUIRE(gemm_bf16x3_supported(M, N, K), AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: need 3*heads*64 %% 256 == 0 and K %% 16 == 0");
+    AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(bias) && aligned16(img), AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: alignment");
+    S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, nullptr, nullptr,
+             static_cast<unsigned char*>(img), M, N, K, 0, 0, 0, tokens, qkv3_npad(tokens), heads, qscale};
+    return launch_s3<S3_EPI_QKV3>(a, st);
 }
 
 }  // namespace avd
@@ -371,4 +417,8 @@ extern "C" int avd_rmsnorm_split3_f32(const float* x, const float* scale, void* 
 extern "C" int avd_gemm_bf16x3_f32(const void* A3, const void* W3, const float* bias, const float* residual, float* C, void* C3,
                                    int64_t M, int N, int K, int act, avd_stream_t stream) {
     return gemm_bf16x3(A3, W3, bias, residual, C, C3, M, N, K, act, static_cast<hipStream_t>(stream));
+}
+extern "C" int avd_gemm_bf16x3_qkv3_f32(const void* A3, const void* W3, const float* bias, void* qkv3, int64_t M, int tokens, int heads,
+                                        int K, float qscale, avd_stream_t stream) {
+    return gemm_bf16x3_qkv3(A3, W3, bias, qkv3, M, tokens, heads, K, qscale, static_cast<hipStream_t>(stream));
 }

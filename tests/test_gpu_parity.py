@@ -737,3 +737,34 @@ def test_attention_split3_output(dev):
     L.check(L.lib().avd_attn_fwd_split3_f32(qkv.data_ptr(), img.data_ptr(), B, N, H, 64, 0.125, N, L.stream_ptr(dev)))
     got = _split3_decode(img.cpu().numpy(), B * N, H * 64).astype(np.float64).sum(0)
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 133, 4), (1, 421, 4), (3, 64, 8), (2, 37, 4)])
+def test_attention_bf16x3(dev, B, N, H):
+    """in_proj epilogue -> qkv3 image -> bf16x3 attention, against softmax(q k^T / 8) v in fp64 and against the fp32-MFMA kernel."""
+    from multimodal_diffusion_amd import functional as Fn, _lib as L
+    d = H * 64
+    g = torch.Generator().manual_seed(B * 1000 + N + H)
+    qkv = torch.randn(B * N, 3 * d, generator=g) * 1.5
+    bias = torch.randn(3 * d, generator=g) * 0.1
+    lib = L.lib()
+    img = torch.empty(lib.avd_qkv3_bytes(B, N, H), dtype=torch.uint8, device=dev)
+    x3, w3 = Fn.split3(qkv.to(dev)), Fn.split3(torch.eye(3 * d).to(dev))      # identity in_proj: the image holds qkv + bias exactly
+    bd = bias.to(dev)
+    L.check(lib.avd_gemm_bf16x3_qkv3_f32(x3.data_ptr(), w3.data_ptr(), bd.data_ptr(), img.data_ptr(), B * N, N, H, 3 * d,
+                                         0.125 * 1.4426950408889634, L.stream_ptr(dev)))
+    out = torch.empty(B, N, d, device=dev)
+    L.check(lib.avd_attn_fwd_qkv3_f32(img.data_ptr(), out.data_ptr(), None, B, N, H, N, L.stream_ptr(dev)))
+    full = (qkv + bias).double().view(B, N, 3, H, 64)
+    q, k, v = (full[:, :, i].transpose(1, 2) for i in range(3))                  # [B,H,N,64]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v).transpose(1, 2).reshape(B, N, d)
+    e3 = rel_err(out.cpu(), ref)
+    e32 = rel_err(Fn.attention((qkv + bias).view(B, N, 3 * d).to(dev), H).cpu(), ref)
+    assert e3 < 2e-6 and e3 < 2.0 * e32 + 2e-7, (e3, e32)
+    # split3-image output == fp32 output; n_query leaves later rows untouched
+    o3 = torch.zeros(lib.avd_split3_bytes(B * N, d), dtype=torch.uint8, device=dev)
+    nq = max(1, N - 5)
+    L.check(lib.avd_attn_fwd_qkv3_f32(img.data_ptr(), None, o3.data_ptr(), B, N, H, nq, L.stream_ptr(dev)))
+    got = _split3_decode(o3.cpu().numpy(), B * N, d).astype(np.float64).sum(0).reshape(B, N, d)
+    assert np.array_equal(got[:, :nq], out.cpu().double().numpy()[:, :nq])
+    assert not got[:, nq:].any()
