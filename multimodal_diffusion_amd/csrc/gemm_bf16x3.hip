@@ -22,6 +22,8 @@
 // (the chip holds ~1.6-1.9 GHz on random data), which caps the achievable rate near 280 fp32-equivalent TFLOP/s.
 #include "avd_common.h"
 
+#include <stdlib.h>
+
 namespace avd {
 
 #define AVD_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -102,6 +104,99 @@ struct S3Args {
 template <int N> __device__ __forceinline__ void wait_vm() {
     static_assert(N >= 0 && N < 64, "vmcnt range");
     __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14));
+}
+
+// epilogue shared by both tile configurations: the wave's 128 x 64 accumulator tile goes through a private LDS slab in two
+// 64-row passes and is streamed out as whole 16-byte segments (mwave0 = first output row of the wave, nbase = first column)
+template <int EPI>
+__device__ __forceinline__ void s3_epilogue(const S3Args& g, f32x16 (&acc)[4][2], float* slab, int64_t mwave0, int nbase, int lane) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    // epilogue: two 64-row passes per wave through a private LDS slab, streamed out as whole 16-byte segments
+    constexpr int CLD = 64 + 4, TN = 2;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[(i * 32 + mfma32_row(r, hi)) * CLD + j * 32 + l31] = acc[ps * 2 + i][j][r];
+        const int64_t m0 = mwave0 + ps * 64;
+        if constexpr (EPI == S3_EPI_QKV3) {
+            // packed in_proj output -> the qkv3 image attn_bf16x3.hip reads: a wave's 64 columns are one (part, head)
+            const int cr = lane >> 3, c = lane & 7;
+            const int n = nbase + c * 8;
+            const int dmodel = g.heads * 64;
+            const int part = nbase / dmodel, head = (nbase % dmodel) >> 6;
+            const int Bt = (int)(g.M / g.tokN);
+            float bv[8];
+            *reinterpret_cast<f32x4*>(bv) = *reinterpret_cast<const f32x4*>(g.bias + n);
+            *reinterpret_cast<f32x4*>(bv + 4) = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
+            const float mul = part == 0 ? g.qscale : 1.0f;
+            unsigned char* pbase = g.C3 + (((int64_t)part * Bt) * g.heads + head) * (int64_t)g.tokNpad * QKV3_ROWB;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int64_t m = m0 + cr + it * 8;
+                float v[8];
+                *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + c * 8);
+                *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + c * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * mul;
+                if (m < g.M) {
+                    const int b = (int)(m / g.tokN), tok = (int)(m - (int64_t)b * g.tokN);
+                    u32x4 Hh, Mi, Lo;
+                    split8(v, Hh, Mi, Lo);
+                    unsigned char* dst = pbase + ((int64_t)b * g.heads * g.tokNpad + tok) * QKV3_ROWB + ((c ^ qkv3_swizzle(part, tok)) << 4);
+                    *reinterpret_cast<u32x4*>(dst) = Hh;
+                    *reinterpret_cast<u32x4*>(dst + 128) = Mi;
+                    *reinterpret_cast<u32x4*>(dst + 256) = Lo;
+                }
+            }
+        } else if constexpr (EPI == S3_EPI_GELU_SPLIT) {
+            // 8 lanes per row (8 columns each), 8 rows per wave instruction
+            const int cr = lane >> 3, cc = (lane & 7) * 8;
+            const int n = nbase + cc;
+            float bv[8];
+            *reinterpret_cast<f32x4*>(bv) = *reinterpret_cast<const f32x4*>(g.bias + n);
+            *reinterpret_cast<f32x4*>(bv + 4) = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int64_t m = m0 + cr + it * 8;
+                float v[8];
+                *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + cc);
+                *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + cc + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e] + bv[e]);
+                if (m < g.M) store_split8(g.C3, m, n, g.N, v);
+            }
+        } else {
+            // 16 lanes per row (4 columns each), 4 rows per wave instruction
+            const int cr = lane >> 4, cc = (lane & 15) * 4;
+            const int n = nbase + cc;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+            float* cptr = g.C + (m0 + cr) * g.N + n;
+            const float* rptr = EPI == S3_EPI_RES ? g.R + (m0 + cr) * g.N + n : nullptr;
+#pragma unroll
+            for (int c0 = 0; c0 < 16; c0 += 8) {
+                f32x4 rv[8];
+                if constexpr (EPI == S3_EPI_RES) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        rv[u] = m0 + cr + (c0 + u) * 4 < g.M ? *reinterpret_cast<const f32x4*>(rptr + (int64_t)(c0 + u) * 4 * g.N)
+                                                            : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int it = c0 + u;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(slab + (cr + it * 4) * CLD + cc);
+                    v += bv;
+                    if constexpr (EPI == S3_EPI_RES) v += rv[u];
+                    if (m0 + cr + it * 4 < g.M) *reinterpret_cast<f32x4*>(cptr + (int64_t)it * 4 * g.N) = v;
+                }
+            }
+        }
+    }
 }
 
 constexpr int S3_BM = 256, S3_BN = 256, S3_NST = 3;
@@ -208,94 +303,135 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
     }
     __syncthreads();
 
-    // epilogue: two 64-row passes per wave through a private LDS slab, streamed out as whole 16-byte segments
     constexpr int CLD = WN + 4;
-    float* slab = reinterpret_cast<float*>(smem3) + wave * 64 * CLD;
-    const int nbase = bn * BN + wn * WN;
+    s3_epilogue<EPI>(g, acc, reinterpret_cast<float*>(smem3) + wave * 64 * CLD, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane);
+}
+
+// Second tile configuration: 256 x 128 block, 4 waves (same 128 x 64 wave tile), TWO blocks per CU so that one block's
+// epilogue (the split3 / qkv3 epilogues move 1.5x the bytes of an fp32 one) overlaps the other's main loop.  Two 36 KiB LDS
+// stages; the fragments are kept one K-tile ahead in registers: while the 48 MFMAs of tile kt run, the 18 fragment reads of
+// tile kt+1 are spread between them and the DMA of tile kt+2 is in flight.  The term order is chosen so that every operand
+// plane is dead before its successor is read into the same registers.
+constexpr int S3B_BM = 256, S3B_BN = 128;
+constexpr int S3B_STAGE = (S3B_BM + S3B_BN) * 96;        // 36 KiB
+constexpr int S3B_LDS = 2 * S3B_STAGE;                    // 72 KiB (4 epilogue slabs of 64 x 68 floats fit inside)
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
+    constexpr int BM = S3B_BM, BN = S3B_BN, WM = 128, WN = 64;
+    constexpr int TM = 4, TN = 2, STAGE = S3B_STAGE;
+    constexpr int PPW = 9;                                // 36 one-KiB pieces per stage / 4 waves
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+
+    int wg;
+    {
+        const int b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    const int per_row = g.sm * g.nbn, per_st = g.sm * g.sn;
+    const int srow = wg / per_row, rem = wg % per_row;
+    const int sc = rem / per_st, rem2 = rem % per_st;
+    const int bm = srow * g.sm + rem2 / g.sn;
+    const int bn = sc * g.sn + rem2 % g.sn;
+    if ((int64_t)bm * BM >= g.M) return;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ng = g.K >> 4;
+    const int nrtA = (int)((g.M + 127) >> 7);
+
+    // stage image [A row-tile 0 | A row-tile 1 | W row-tile], 12 one-KiB pieces each
+    const unsigned char* src[PPW];
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) slab[(i * 32 + mfma32_row(r, hi)) * CLD + j * 32 + l31] = acc[ps * 2 + i][j][r];
-        const int64_t m0 = (int64_t)bm * BM + wm * WM + ps * 64;
-        if constexpr (EPI == S3_EPI_QKV3) {
-            // packed in_proj output -> the qkv3 image attn_bf16x3.hip reads: a wave's 64 columns are one (part, head)
-            const int cr = lane >> 3, c = lane & 7;
-            const int n = nbase + c * 8;
-            const int dmodel = g.heads * 64;
-            const int part = nbase / dmodel, head = (nbase % dmodel) >> 6;
-            const int Bt = (int)(g.M / g.tokN);
-            float bv[8];
-            *reinterpret_cast<f32x4*>(bv) = *reinterpret_cast<const f32x4*>(g.bias + n);
-            *reinterpret_cast<f32x4*>(bv + 4) = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
-            const float mul = part == 0 ? g.qscale : 1.0f;
-            unsigned char* pbase = g.C3 + (((int64_t)part * Bt) * g.heads + head) * (int64_t)g.tokNpad * QKV3_ROWB;
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int64_t m = m0 + cr + it * 8;
-                float v[8];
-                *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + c * 8);
-                *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + c * 8 + 4);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * mul;
-                if (m < g.M) {
-                    const int b = (int)(m / g.tokN), tok = (int)(m - (int64_t)b * g.tokN);
-                    u32x4 Hh, Mi, Lo;
-                    split8(v, Hh, Mi, Lo);
-                    unsigned char* dst = pbase + ((int64_t)b * g.heads * g.tokNpad + tok) * QKV3_ROWB + ((c ^ qkv3_swizzle(part, tok)) << 4);
-                    *reinterpret_cast<u32x4*>(dst) = Hh;
-                    *reinterpret_cast<u32x4*>(dst + 128) = Mi;
-                    *reinterpret_cast<u32x4*>(dst + 256) = Lo;
-                }
-            }
-        } else if constexpr (EPI == S3_EPI_GELU_SPLIT) {
-            // 8 lanes per row (8 columns each), 8 rows per wave instruction
-            const int cr = lane >> 3, cc = (lane & 7) * 8;
-            const int n = nbase + cc;
-            float bv[8];
-            *reinterpret_cast<f32x4*>(bv) = *reinterpret_cast<const f32x4*>(g.bias + n);
-            *reinterpret_cast<f32x4*>(bv + 4) = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int64_t m = m0 + cr + it * 8;
-                float v[8];
-                *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + cc);
-                *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + cc + 4);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e] + bv[e]);
-                if (m < g.M) store_split8(g.C3, m, n, g.N, v);
-            }
+    for (int i = 0; i < PPW; ++i) {
+        const int q = wave * PPW + i;
+        const int region = q / 12, within = (q % 12) * 1024 + lane * 16;
+        if (region < 2) {
+            int rt = bm * 2 + region;
+            rt = rt < nrtA ? rt : nrtA - 1;
+            src[i] = g.A + (int64_t)rt * ng * S3_CHUNK + within;
         } else {
-            // 16 lanes per row (4 columns each), 4 rows per wave instruction
-            const int cr = lane >> 4, cc = (lane & 15) * 4;
-            const int n = nbase + cc;
-            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
-            float* cptr = g.C + (m0 + cr) * g.N + n;
-            const float* rptr = EPI == S3_EPI_RES ? g.R + (m0 + cr) * g.N + n : nullptr;
-#pragma unroll
-            for (int c0 = 0; c0 < 16; c0 += 8) {
-                f32x4 rv[8];
-                if constexpr (EPI == S3_EPI_RES) {
-#pragma unroll
-                    for (int u = 0; u < 8; ++u)
-                        rv[u] = m0 + cr + (c0 + u) * 4 < g.M ? *reinterpret_cast<const f32x4*>(rptr + (int64_t)(c0 + u) * 4 * g.N)
-                                                            : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int it = c0 + u;
-                    f32x4 v = *reinterpret_cast<const f32x4*>(slab + (cr + it * 4) * CLD + cc);
-                    v += bv;
-                    if constexpr (EPI == S3_EPI_RES) v += rv[u];
-                    if (m0 + cr + it * 4 < g.M) *reinterpret_cast<f32x4*>(cptr + (int64_t)it * 4 * g.N) = v;
-                }
-            }
+            src[i] = g.W + (int64_t)bn * ng * S3_CHUNK + within;
         }
     }
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(src[i] + (int64_t)kt * S3_CHUNK),
+                                             AVD_LDS_PTR(smem3 + buf * STAGE + (wave * PPW + i) * 1024), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int a_off[TM], b_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * WM + i * 32 + l31;
+        a_off[i] = (r >> 7) * S3_CHUNK + (r & 127) * 32 + ((hi ^ ((r >> 3) & 1)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int r = BM + wn * WN + j * 32 + l31;
+        b_off[j] = (r >> 7) * S3_CHUNK + (r & 127) * 32 + ((hi ^ ((r >> 3) & 1)) << 4);
+    }
+#define S3_LDA(dst, st, p) _Pragma("unroll") for (int i = 0; i < TM; ++i) dst[i] = *reinterpret_cast<const bf16x8*>((st) + a_off[i] + S3_PLANE * (p))
+#define S3_LDB(dst, st, p) _Pragma("unroll") for (int j = 0; j < TN; ++j) dst[j] = *reinterpret_cast<const bf16x8*>((st) + b_off[j] + S3_PLANE * (p))
+#define S3_MM(A_, B_) _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][j], 0, 0, 0)
+
+    const int nk = ng;
+    issue(0, 0);
+    wait_vm<0>();
+    asm volatile("s_barrier" ::: "memory");
+    if (nk > 1) issue(1, 1);
+    bf16x8 ah[TM], am[TM], al[TM], bh[TN], bmm[TN], bl[TN];
+    S3_LDA(ah, smem3, 0); S3_LDA(am, smem3, 1); S3_LDA(al, smem3, 2);
+    S3_LDB(bh, smem3, 0); S3_LDB(bmm, smem3, 1); S3_LDB(bl, smem3, 2);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt+1 has landed in stage (kt+1)&1; stage kt&1 (whose fragments are in registers) is free for tile kt+2
+        wait_vm<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 2 < nk) issue(kt + 2, kt & 1);
+        const unsigned char* nx = smem3 + ((kt + 1) & 1) * STAGE;
+        bf16x8 ah_n[TM], bl_n[TN];
+        __builtin_amdgcn_sched_barrier(0);
+        S3_MM(am, bmm);                    // (m,m)
+        S3_LDA(ah_n, nx, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        S3_MM(am, bh);                     // (m,h)  -> am dead
+        S3_LDA(am, nx, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        S3_MM(al, bh);                     // (l,h)  -> al dead
+        S3_LDA(al, nx, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        S3_MM(ah, bh);                     // (h,h)  -> bh dead
+        S3_LDB(bh, nx, 0);
+        S3_LDB(bl_n, nx, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        S3_MM(ah, bmm);                    // (h,m)  -> bmm dead
+        S3_LDB(bmm, nx, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        S3_MM(ah, bl);                     // (h,l)  -> ah, bl dead
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ah[i] = ah_n[i];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bl[j] = bl_n[j];
+    }
+#undef S3_LDA
+#undef S3_LDB
+#undef S3_MM
+    __syncthreads();
+    constexpr int CLD = WN + 4;
+    s3_epilogue<EPI>(g, acc, reinterpret_cast<float*>(smem3) + wave * 64 * CLD, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -340,27 +476,40 @@ int rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t ro
 
 bool gemm_bf16x3_supported(int64_t M, int N, int K) { return M > 0 && N > 0 && N % 256 == 0 && K > 0 && K % 16 == 0; }
 
+// tile configuration: 0 = 256x256, 8 waves, one block per CU; 1 = 256x128, 4 waves, two blocks per CU.
+// AVD_S3_TILE=0|1 forces one (measurement aid); default: per epilogue, what measured faster in the C3 pipeline.
+static int s3_tile_for(int epi) {
+    static const int forced = [] { const char* e = getenv("AVD_S3_TILE"); return e ? atoi(e) : -1; }();
+    if (forced == 0 || forced == 1) return forced;
+    // C3 pipeline, ms per step over 8 launches: fc1+GELU->split3 2.75 (one block/CU) vs 2.48 (two); in_proj->qkv3 1.98 vs 1.94;
+    // out_proj/fc2 + residual (16 launches) 3.07 vs 3.27
+    return (epi == S3_EPI_GELU_SPLIT || epi == S3_EPI_QKV3) ? 1 : 0;
+}
+
 template <int EPI>
 static int launch_s3(const S3Args& a, hipStream_t st) {
-    static bool attr = false;
-    auto kern = gemm_bf16x3_kernel<EPI>;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, S3_LDS);
+    const int tile = s3_tile_for(EPI);
+    const int BMt = tile ? S3B_BM : S3_BM, BNt = tile ? S3B_BN : S3_BN, lds = tile ? S3B_LDS : S3_LDS;
+    static bool attr[2] = {false, false};
+    const void* kern = tile ? reinterpret_cast<const void*>(gemm_bf16x3_b_kernel<EPI>) : reinterpret_cast<const void*>(gemm_bf16x3_kernel<EPI>);
+    if (!attr[tile]) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return set_error(AVD_ELAUNCH, "gemm_bf16x3 attr: %s", hipGetErrorString(e));
-        attr = true;
+        attr[tile] = true;
     }
     S3Args g = a;
-    g.nbn = a.N / S3_BN;
+    g.nbn = a.N / BNt;
     int sn = 8;
     while (g.nbn % sn) sn >>= 1;
     g.sn = sn;
-    g.sm = 16 / sn;
-    const int64_t nbm = (a.M + S3_BM - 1) / S3_BM;
+    g.sm = (tile ? 32 : 16) / sn;
+    const int64_t nbm = (a.M + BMt - 1) / BMt;
     const int64_t nwg = (nbm + g.sm - 1) / g.sm * g.sm * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
-    static const int tag = prof_tag_id("gemm_bf16x3_kernel<%d>", EPI);
-    ProfScope prof(tag, 2.0 * (double)a.M * a.N * a.K, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(512), S3_LDS, st, g);
+    static const int tag0 = prof_tag_id("gemm_bf16x3_kernel<%d>", EPI), tag1 = prof_tag_id("gemm_bf16x3_b_kernel<%d>", EPI);
+    ProfScope prof(tile ? tag1 : tag0, 2.0 * (double)a.M * a.N * a.K, st);
+    if (tile) hipLaunchKernelGGL(gemm_bf16x3_b_kernel<EPI>, dim3((unsigned)nwg), dim3(256), lds, st, g);
+    else hipLaunchKernelGGL(gemm_bf16x3_kernel<EPI>, dim3((unsigned)nwg), dim3(512), lds, st, g);
     AVD_CHECK_LAUNCH("gemm_bf16x3");
     return AVD_OK;
 }
