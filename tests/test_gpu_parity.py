@@ -768,3 +768,31 @@ def test_attention_bf16x3(dev, B, N, H):
     got = _split3_decode(o3.cpu().numpy(), B * N, d).astype(np.float64).sum(0).reshape(B, N, d)
     assert np.array_equal(got[:, :nq], out.cpu().double().numpy()[:, :nq])
     assert not got[:, nq:].any()
+
+
+def test_chain_bf16x3_tracks_f32(dev, full):
+    """A 10-step DDIM + CFG trajectory at the C3 shape (B=20): the bf16x3 matmul mode stays within the chained tolerance of
+    the fp32-MFMA mode (rel L2 <= 1e-3) — eager and as a replayed HIP graph."""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd import schedule_utils as su
+    ws, _ = full
+    B = 20
+    g = torch.Generator().manual_seed(99)
+    z = torch.randn(B, 8, 12, 32, 32, generator=g).to(dev)
+    za = torch.randn(B, 8, 150, generator=g).to(dev)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    sched = su.make_sampling_schedule(1000, 10)
+    outs = {}
+    for mode in ("f32", "bf16x3"):
+        core, head, av, aa = _full_modules(dev, ws)
+        eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video",
+                              latent_shape=tuple(z.shape), prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=mode)
+        eng.set_prompt(za)
+        outs[mode] = eng.run(z, sched)
+        if mode == "bf16x3":
+            outs["bf16x3_graph"] = eng.run(z, sched, graph=True)
+    ref = outs["f32"].double()
+    for k in ("bf16x3", "bf16x3_graph"):
+        l2 = float((outs[k].double() - ref).norm() / ref.norm())
+        assert l2 < 1e-3, (k, l2)
+    assert torch.equal(outs["bf16x3"], outs["bf16x3_graph"])
