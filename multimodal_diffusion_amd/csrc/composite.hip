@@ -3,6 +3,8 @@
 // order, on the caller's stream — one FFI call per module / per step, hipGraph-capturable.
 #include "avd_common.h"
 
+#include <stdlib.h>
+
 #include <string.h>
 #include <string>
 #include <vector>
@@ -79,8 +81,12 @@ struct Carver {
 // ---------------------------------------------------------------- MMDiT.forward
 // bf16x3 matmul path: taken when every block carries split3 weight images and the batch fills the 256x256-tile kernel
 constexpr int64_t kSplitMinRows = 16384;
+static int64_t split_min_rows() {      // AVD_S3_MIN_ROWS: measurement aid
+    static const int64_t v = [] { const char* e = getenv("AVD_S3_MIN_ROWS"); return e ? (int64_t)atoll(e) : kSplitMinRows; }();
+    return v;
+}
 static bool core_use_split(const avd_core_weights* w, int64_t M) {
-    if (M < kSplitMinRows) return false;
+    if (M < split_min_rows()) return false;
     if (!gemm_bf16x3_supported(M, 3 * w->d, w->d) || !gemm_bf16x3_supported(M, w->d, w->d) ||
         !gemm_bf16x3_supported(M, w->mlp_hidden, w->d) || !gemm_bf16x3_supported(M, w->d, w->mlp_hidden))
         return false;

@@ -171,7 +171,7 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 1) void sgemm2_kernel(S
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + NST - 1 <= nk) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>();
         asm volatile("s_barrier" ::: "memory");
-        if (MODE != 1 && kt + NST - 1 < nk) issue(kt + NST - 1, nxt);
+        if (MODE != 1 && MODE != 3 && kt + NST - 1 < nk) issue(kt + NST - 1, nxt);
         const unsigned char* st = smem + cur * STAGE;
         cur = cur + 1 == NST ? 0 : cur + 1;
         nxt = nxt + 1 == NST ? 0 : nxt + 1;
@@ -193,6 +193,16 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 1) void sgemm2_kernel(S
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
+                    if (MODE == 3) {
+                        // shape experiment: the same flops as two v_mfma_f32_16x16x32_bf16 on the same operand registers
+                        f32x4 q0 = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        f32x4 q1 = {acc[i][j][4 + 4 * (t & 1)], acc[i][j][5 + 4 * (t & 1)], acc[i][j][6 + 4 * (t & 1)], acc[i][j][7 + 4 * (t & 1)]};
+                        q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][PA[t]], bf[j][PB[t]], q0, 0, 0, 0);
+                        q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][PA[t]], bf[j][PB[t]], q1, 0, 0, 0);
+                        acc[i][j][0] = q0[0]; acc[i][j][1] = q0[1]; acc[i][j][2] = q0[2]; acc[i][j][3] = q0[3];
+                        acc[i][j][4 + 4 * (t & 1)] = q1[0]; acc[i][j][5 + 4 * (t & 1)] = q1[1];
+                        acc[i][j][6 + 4 * (t & 1)] = q1[2]; acc[i][j][7 + 4 * (t & 1)] = q1[3];
+                    } else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
@@ -548,6 +558,7 @@ int main(int argc, char** argv) {
             RUN("s3 super16", (run_gemm<256, 256, 128, 64, 3, 6>(a, it, 16)));
             RUN("noDMA", (run_gemm<256, 256, 128, 64, 3, 6, 1>(a, it, 16)));
             RUN("DMAonly", (run_gemm<256, 256, 128, 64, 3, 6, 2>(a, it, 16)));
+            RUN("noDMA 16x16x32", (run_gemm<256, 256, 128, 64, 3, 6, 3>(a, it, 16)));
             printf("\n    256x128:");
             RUN("s3", (run_gemm<256, 128, 64, 64, 3, 6>(a, it)));
             RUN("s4 super32", (run_gemm<256, 128, 64, 64, 4, 6>(a, it, 32)));
