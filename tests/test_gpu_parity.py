@@ -796,3 +796,24 @@ def test_chain_bf16x3_tracks_f32(dev, full):
         l2 = float((outs[k].double() - ref).norm() / ref.norm())
         assert l2 < 1e-3, (k, l2)
     assert torch.equal(outs["bf16x3"], outs["bf16x3_graph"])
+
+
+def test_full_step_bf16x3_512(dev, full):
+    """BASELINE C5 geometry (512x512: 1536+37 tokens, ragged 1573 -> 1600 padded keys), B=6 -> 18,876 rows on the bf16x3 path."""
+    import multimodal_diffusion_amd as A
+    ws, _ = full
+    core, head, av, aa = _full_modules(dev, ws)
+    B = 6
+    g = torch.Generator().manual_seed(512)
+    z_v = torch.randn(B, 8, 12, 64, 64, generator=g)
+    z_a = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn = torch.tensor([982, 500, 16, 999, 700, 300])
+    tp = torch.tensor([966, 480, -1, 979, 680, 280])
+    ref = R.denoise_step_a2v(z_v[:1], z_a[:1], tn[:1], tp[:1], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"],
+                             core=ws["core"], head=ws["head"], n_layers=8, n_heads=8, guidance=3.5)
+    eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video",
+                          latent_shape=tuple(z_v.shape), prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul="bf16x3")
+    eng.set_prompt(z_a.to(dev))
+    out = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev))
+    assert rel_err(out[:1].cpu(), ref) < TOL
