@@ -160,6 +160,11 @@ typedef struct {                       /* avdiff/models/mmdt.py:88-99 (Block) st
     const float* fc2_bias;             /* blocks.{i}.mlp.fc2.bias             [d]      */
     /* optional split3 images of the four weights above (avd_split3_f32); all four non-NULL in every block selects
      * the bf16x3 matmul path of avd_core_forward_f32 for large batches (see "bf16x3" below), NULL keeps fp32 MFMA */
+    /* optional: in_proj_weight * norm1.scale[None,:] and fc1_weight * norm2.scale[None,:] (fp32, same shapes).  Both non-NULL
+     * lets the fp32 path fold each RMSNorm into its neighbours: the preceding residual epilogue emits the rows' sums of
+     * squares, the following Linear runs on the un-normalised stream with these weights and scales its rows by 1/rms. */
+    const float* in_proj_weight_n;
+    const float* fc1_weight_n;
     const void* in_proj_weight3;
     const void* out_proj_weight3;
     const void* fc1_weight3;

@@ -35,6 +35,7 @@ class BlockWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in (
         "norm1_scale", "in_proj_weight", "in_proj_bias", "out_proj_weight", "out_proj_bias",
         "norm2_scale", "fc1_weight", "fc1_bias", "fc2_weight", "fc2_bias",
+        "in_proj_weight_n", "fc1_weight_n",
         "in_proj_weight3", "out_proj_weight3", "fc1_weight3", "fc2_weight3")]
 
 

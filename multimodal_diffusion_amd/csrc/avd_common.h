@@ -143,6 +143,12 @@ struct ProfScope {
 int gemm_f32(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm,
              float* C, RowMap cm, int64_t M, int N, int K, int act, hipStream_t st);
 
+bool gemm_f32_fold_supported(int N, int K);
+int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm, float* C, RowMap cm,
+                  int64_t M, int N, int K, int act, const float* ss_in, int ss_in_cols, float sqrt_d, float eps, float* ss_out,
+                  hipStream_t st);
+int rowss_f32(const float* x, float* ss, int64_t rows, int d, hipStream_t st);
+
 int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st);
 int rmsnorm_f32(const float* x, RowMap xm, const float* scale, float* y, RowMap ym, int64_t rows, int d, float eps,
                 hipStream_t st);

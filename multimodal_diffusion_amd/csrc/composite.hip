@@ -97,6 +97,18 @@ static bool core_use_split(const avd_core_weights* w, int64_t M) {
     return true;
 }
 
+// fp32 path with RMSNorm folded into the neighbouring GEMM epilogues: needs the scale-carrying weights and LDS-DMA-able shapes
+static bool core_use_fold(const avd_core_weights* w) {
+    static const bool off = getenv("AVD_NO_FOLD") != nullptr;      // measurement aid
+    if (off) return false;
+    if (!gemm_f32_fold_supported(3 * w->d, w->d) || !gemm_f32_fold_supported(w->d, w->d) ||
+        !gemm_f32_fold_supported(w->mlp_hidden, w->d) || !gemm_f32_fold_supported(w->d, w->mlp_hidden))
+        return false;
+    for (int l = 0; l < w->n_layers; ++l)
+        if (!w->blocks[l].in_proj_weight_n || !w->blocks[l].fc1_weight_n) return false;
+    return true;
+}
+
 // the wide scratch of the bf16x3 path holds the qkv3 image, then the fc1 image
 static int64_t core_split_wide_bytes(const avd_core_weights* w, int B, int N) {
     const int64_t qkv3 = qkv3_bytes(B, N, w->n_heads), fc1 = split3_bytes((int64_t)B * N, w->mlp_hidden);
@@ -106,7 +118,7 @@ static int64_t core_split_wide_bytes(const avd_core_weights* w, int B, int N) {
 static int64_t core_ws_bytes(const avd_core_weights* w, int B, int N) {
     const int64_t M = (int64_t)B * N;
     const int wide = 3 * w->d > w->mlp_hidden ? 3 * w->d : w->mlp_hidden;
-    int64_t fp32_path = align_up(M * w->d * 4) + align_up(M * wide * 4);
+    int64_t fp32_path = align_up(M * w->d * 4) + align_up(M * wide * 4) + 2 * align_up(M * (w->d / 32 + 1) * 4);
     if (!core_use_split(w, M)) return fp32_path;
     // + split3 image of the norm / attention output, and the wide buffer must also hold the split3 image of the MLP hidden
     const int64_t wide_b = core_split_wide_bytes(w, B, N);
@@ -157,6 +169,32 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
             if (int rc = rmsnorm_split3_f32(y, b.norm2_scale, hs, M, d, w->norm_eps, st)) return rc;
             if (int rc = gemm_bf16x3(hs, b.fc1_weight3, b.fc1_bias, nullptr, nullptr, wide3, M, hid, d, AVD_ACT_GELU, st)) return rc;
             if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, nullptr, M, d, hid, AVD_ACT_NONE, st)) return rc;
+        }
+        return rmsnorm_f32(y, rd, w->final_norm_scale, y, rd, M, d, w->norm_eps, st);
+    }
+    if (core_use_fold(w)) {
+        // RMSNorm folded into its neighbours (GemmArgs in gemm_f32.hip): the residual epilogues emit per-row sums of squares, the
+        // in_proj / fc1 GEMMs run on the un-normalised stream with scale-carrying weights and multiply their rows by 1/rms
+        float* ssA = cv.take(M * (d / 32 + 1));     // sums of squares of the stream entering norm1
+        float* ssB = cv.take(M * (d / 32 + 1));     // ... entering norm2
+        const float sqrt_d = (float)sqrt((double)d);
+        if (int rc = rowss_f32(cur, ssA, M, d, st)) return rc;
+        int colsA = 1;
+        for (int l = 0; l < w->n_layers; ++l) {
+            const avd_block_weights& b = w->blocks[l];
+            const bool last = l == w->n_layers - 1;
+            const int nq = (last && out_row0 == 0) ? n_out_rows : N;
+            if (int rc = gemm_f32_fold(cur, rd, b.in_proj_weight_n, b.in_proj_bias, nullptr, rd, wide, r3, M, 3 * d, d, AVD_ACT_NONE, ssA,
+                                       colsA, sqrt_d, w->norm_eps, nullptr, st)) return rc;
+            if (int rc = attn_f32(wide, hbuf, B, N, H, d / H, scale, nq, st)) return rc;
+            if (int rc = gemm_f32_fold(hbuf, rd, b.out_proj_weight, b.out_proj_bias, cur, rd, y, rd, M, d, d, AVD_ACT_NONE, nullptr, 0,
+                                       1.f, 0.f, ssB, st)) return rc;
+            cur = y;
+            if (int rc = gemm_f32_fold(y, rd, b.fc1_weight_n, b.fc1_bias, nullptr, rd, wide, rh, M, hid, d, AVD_ACT_GELU, ssB, d / 32,
+                                       sqrt_d, w->norm_eps, nullptr, st)) return rc;
+            if (int rc = gemm_f32_fold(wide, rh, b.fc2_weight, b.fc2_bias, y, rd, y, rd, M, d, hid, AVD_ACT_NONE, nullptr, 0, 1.f, 0.f,
+                                       ssA, st)) return rc;
+            colsA = d / 32;
         }
         return rmsnorm_f32(y, rd, w->final_norm_scale, y, rd, M, d, w->norm_eps, st);
     }

@@ -47,6 +47,13 @@ struct GemmArgs {
     int N, K;
     int act;
     int nbn;
+    // RMSNorm folding (dma kernels only): ss_in -> every output row is multiplied by 1 / (sqrt(sum_j ss_in[row][j]) / sqrt_d + eps)
+    // before the bias (A is then the UN-normalised input and W carries the norm's scale); ss_out -> the epilogue also writes
+    // the sum of squares of its final values per (row, 32-column chunk), the partials the next folded GEMM reads
+    const float* ss_in;
+    int ss_in_cols;
+    float ss_sqrt_d, ss_eps;
+    float* ss_out;
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
@@ -176,10 +183,29 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
     constexpr int NIT = WM / RPI;
     const int cr = lane / LPR, cc = (lane % LPR) * 4;
     const int n = bn * BN + wn * WN + cc;
-    if (n >= g.N) return;           // N % 4 == 0: a float4 is wholly in or out
+    // folded RMSNorm: lane l of the wave computes the factor of the wave's row l; the store loop fetches it by shuffle
+    float inv_r = 1.0f;
+    if (g.ss_in) {
+        const int64_t mr = (int64_t)bm * BM + wm * WM + lane;
+        if (lane < WM && mr < g.M) {
+            const float* sp = g.ss_in + mr * g.ss_in_cols;
+            float ss = 0.f;
+            if (g.ss_in_cols == 16) {            // d = 512: four independent 16-byte loads, fixed summation order
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(sp), p1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                const f32x4 p2 = *reinterpret_cast<const f32x4*>(sp + 8), p3 = *reinterpret_cast<const f32x4*>(sp + 12);
+                const f32x4 t = (p0 + p1) + (p2 + p3);
+                ss = (t[0] + t[1]) + (t[2] + t[3]);
+            } else {
+                for (int j = 0; j < g.ss_in_cols; ++j) ss += sp[j];
+            }
+            inv_r = 1.0f / (sqrtf(ss) / g.ss_sqrt_d + g.ss_eps);
+        }
+    }
+    if (n >= g.N) return;           // N % 4 == 0: a float4 is wholly in or out (never taken when folding: N % BN == 0 there)
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
     const int64_t mbase = (int64_t)bm * BM + wm * WM + cr;
+    const int ss_cols = g.N >> 5;
     float* cptr = g.C + mbase * g.cm.ld + n;
     const float* rptr = EPI == EPI_RES ? g.R + mbase * g.rm.ld + n : nullptr;
     constexpr int CHUNK = NIT < 8 ? NIT : 8;
@@ -197,13 +223,22 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
         for (int u = 0; u < CHUNK; ++u) {
             const int it = c0 + u;
             f32x4 v = *reinterpret_cast<const f32x4*>(slab + (cr + it * RPI) * CLD + cc);
+            if (g.ss_in) v *= __shfl(inv_r, cr + it * RPI, 64);
             v += bv;
             if (EPI == EPI_GELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
             }
             if (EPI == EPI_RES) v += rv[u];
-            if (mbase + (int64_t)it * RPI < g.M) *reinterpret_cast<f32x4*>(cptr + (int64_t)it * RPI * g.cm.ld) = v;
+            const bool row_ok = mbase + (int64_t)it * RPI < g.M;
+            if (row_ok) *reinterpret_cast<f32x4*>(cptr + (int64_t)it * RPI * g.cm.ld) = v;
+            if (g.ss_out) {     // 8 consecutive lanes hold one row's 32 columns
+                float sq = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+                sq += __shfl_xor(sq, 1, 64);
+                sq += __shfl_xor(sq, 2, 64);
+                sq += __shfl_xor(sq, 4, 64);
+                if (row_ok && (lane & 7) == 0) g.ss_out[(mbase + (int64_t)it * RPI) * ss_cols + (n >> 5)] = sq;
+            }
         }
     }
 }
@@ -405,8 +440,17 @@ static int launch_reg_k(const GemmArgs& a, hipStream_t st) {
     return (a.K % GEMM_BK) ? launch_reg<BM, BN, WM, WN, true>(a, st) : launch_reg<BM, BN, WM, WN, false>(a, st);
 }
 
+bool gemm_f32_fold_supported(int N, int K) { return K % GEMM_BK == 0 && N % 128 == 0; }
+
 int gemm_f32(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm,
              float* C, RowMap cm, int64_t M, int N, int K, int act, hipStream_t st) {
+    return gemm_f32_fold(A, am, W, bias, R, rm, C, cm, M, N, K, act, nullptr, 0, 1.f, 0.f, nullptr, st);
+}
+
+// gemm_f32 with RMSNorm folding (see GemmArgs); ss_in / ss_out may each be null.  ss_out must hold M * (N / 32) floats.
+int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm,
+                  float* C, RowMap cm, int64_t M, int N, int K, int act, const float* ss_in, int ss_in_cols, float sqrt_d, float eps,
+                  float* ss_out, hipStream_t st) {
     AVD_REQUIRE(A && W && C, AVD_EINVAL, "gemm: null pointer");
     AVD_REQUIRE(M >= 0 && N > 0 && K > 0, AVD_EINVAL, "gemm: bad dims M=%lld N=%d K=%d", (long long)M, N, K);
     AVD_REQUIRE(K % 4 == 0, AVD_EUNSUPPORTED, "gemm: K=%d must be a multiple of 4", K);
@@ -415,13 +459,15 @@ int gemm_f32(const float* A, RowMap am, const float* W, const float* bias, const
     AVD_REQUIRE(aligned16(A) && aligned16(W), AVD_EUNSUPPORTED, "gemm: A/W must be 16-byte aligned");
     AVD_REQUIRE(act == AVD_ACT_NONE || act == AVD_ACT_GELU || act == AVD_ACT_SILU, AVD_EINVAL, "gemm: bad act %d", act);
     if (M == 0) return AVD_OK;
-    GemmArgs g{A, am, W, bias, R, rm, C, cm, M, N, K, act, 0};
+    GemmArgs g{A, am, W, bias, R, rm, C, cm, M, N, K, act, 0, ss_in, ss_in_cols, sqrt_d, eps, ss_out};
 
     static const int force = getenv("AVD_GEMM_TILE") ? atoi(getenv("AVD_GEMM_TILE")) : -1;   // tuning/debug only
     const bool dma_ok = K % GEMM_BK == 0 && N % 4 == 0 && N > 32 && cm.seg <= 0 && cm.ld % 4 == 0 && aligned16(C) &&
                         (R == nullptr || (rm.seg <= 0 && rm.ld % 4 == 0 && aligned16(R))) &&
                         (bias == nullptr || aligned16(bias)) && (act == AVD_ACT_NONE || act == AVD_ACT_GELU) &&
                         !(R != nullptr && act != AVD_ACT_NONE) && force < 10;
+    AVD_REQUIRE(!(ss_in || ss_out) || (dma_ok && gemm_f32_fold_supported(N, K) && (!ss_in || ss_in_cols > 0)), AVD_EUNSUPPORTED,
+                "gemm: RMSNorm folding needs the LDS-DMA path (K %% 32 == 0, N %% 128 == 0)");
     const int64_t mb128 = (M + 127) / 128;
     if (dma_ok) {
         // 128x128 when it still gives >= 3 full rounds of 512 resident blocks; 128x64 (3 blocks/CU) for the

@@ -121,6 +121,30 @@ int rmsnorm_f32(const float* x, RowMap xm, const float* scale, float* y, RowMap 
     return AVD_OK;
 }
 
+// sum of squares of every row: ss[row] (the one-column partial table a folded GEMM reads for the first block's norm1)
+__global__ __launch_bounds__(256) void rowss_kernel(const float* __restrict__ x, float* __restrict__ ss, int64_t rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * d;
+    float s = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    s = wave_sum(s);
+    if (lane == 0) ss[row] = s;
+}
+
+int rowss_f32(const float* x, float* ss, int64_t rows, int d, hipStream_t st) {
+    AVD_REQUIRE(x && ss && rows > 0 && d > 0 && d % 4 == 0 && aligned16(x), AVD_EINVAL, "rowss: bad arguments");
+    static const int tag = prof_tag_id("rowss_kernel");
+    ProfScope prof(tag, 4.0 * (double)rows * d, st);
+    hipLaunchKernelGGL(rowss_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, ss, rows, d);
+    AVD_CHECK_LAUNCH("rowss");
+    return AVD_OK;
+}
+
 int layernorm_act_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int d, float eps,
                       int act, hipStream_t st) {
     AVD_REQUIRE(x && gamma && beta && y, AVD_EINVAL, "layernorm: null pointer");

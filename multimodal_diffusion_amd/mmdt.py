@@ -150,7 +150,17 @@ class MMDiT(nn.Module):
         # "f32": fp32 MFMA everywhere.  "bf16x3": the four projections of every block run on the bf16 matrix pipe with
         # exactly split operands (fp32-level error, csrc/gemm_bf16x3.hip) whenever the batch is large enough.
         self.matmul = "f32"
+        self.fold_norms = True        # fp32 path: fold norm1 / norm2 into the neighbouring Linear epilogues (same math, one pass less)
         self._split3: dict = {}
+        self._folded: dict = {}
+
+    def _folded_weight(self, name: str, w: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+        key = (w.data_ptr(), w._version, scale.data_ptr(), scale._version)
+        hit = self._folded.get(name)
+        if hit is None or hit[0] != key:
+            hit = (key, (w.detach() * scale.detach()[None, :]).contiguous())
+            self._folded[name] = hit
+        return hit[1]
 
     def _split3_image(self, name: str, p: torch.Tensor) -> torch.Tensor:
         key = (p.data_ptr(), p._version, tuple(p.shape))
@@ -178,6 +188,11 @@ class MMDiT(nn.Module):
                     raise L.AvdError("all MMDiT parameters must live on one device")
                 keep.append(t)
                 setattr(arr[i], k, t.data_ptr())
+            if self.fold_norms and self.matmul == "f32":
+                for k, sc in (("in_proj_weight", "norm1_scale"), ("fc1_weight", "norm2_scale")):
+                    t = self._folded_weight(f"{i}.{k}", L.dev_f32(ps[k].detach(), k), L.dev_f32(ps[sc].detach(), sc))
+                    keep.append(t)
+                    setattr(arr[i], k + "_n", t.data_ptr())
             if self.matmul == "bf16x3":
                 for k in ("in_proj_weight", "out_proj_weight", "fc1_weight", "fc2_weight"):
                     img = self._split3_image(f"{i}.{k}", ps[k])
