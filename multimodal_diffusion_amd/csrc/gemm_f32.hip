@@ -475,7 +475,10 @@ int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, 
         int tile = (N >= 128 && mb128 * ((N + 127) / 128) >= 1536) ? 0 : (mb128 * ((N + 63) / 64) >= 512) ? 1 : 2;
         if (force >= 0 && force <= 2) tile = force;
         if (tile == 0) return launch_dma_epi<128, 128, 64, 64, 2>(g, st);
-        if (tile == 1) return launch_dma_epi<128, 64, 64, 32, 2>(g, st);
+        if (tile == 1) {
+            static const bool three = getenv("AVD_GEMM_WPS3") != nullptr;      // measurement aid: three resident blocks per CU
+            return three ? launch_dma_epi<128, 64, 64, 32, 3>(g, st) : launch_dma_epi<128, 64, 64, 32, 2>(g, st);
+        }
         return launch_dma_epi<64, 64, 32, 32, 4>(g, st);
     }
     if (N <= 32) return launch_reg_k<128, 32, 32, 32>(g, st);

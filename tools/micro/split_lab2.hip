@@ -167,10 +167,37 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 1) void sgemm2_kernel(S
     for (int s = 0; s < NST - 1; ++s)
         if (s < nk) issue(s, s);
 
+    // MODE 4 / 5: software L2 prefetch — every wave touches one dword per 128-byte line of the stage image D K-tiles ahead
+    constexpr int PFD = MODE == 4 ? 4 : MODE == 5 ? 6 : 0;
+    const unsigned char* pf_base = nullptr;
+    if (PFD) {
+        int line = wave * 64 + lane;
+        line = line < PIECES * 8 ? line : PIECES * 8 - 1;
+        const int region = line / 96, within = (line % 96) * 128;
+        if (region < RA) {
+            int rt = bm * RA + region;
+            rt = rt < nrtA ? rt : nrtA - 1;
+            pf_base = g.A + (int64_t)rt * ng * CHUNK + within;
+        } else {
+            pf_base = g.W + (int64_t)(bn * RB + region - RA) * ng * CHUNK + within;
+        }
+    }
     int cur = 0, nxt = NST - 1;
     for (int kt = 0; kt < nk; ++kt) {
-        if (kt + NST - 1 <= nk) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>();
+        if (PFD) {
+            if (kt == 0) wait_vm<(NST - 2) * PPW>();
+            else if (kt + NST - 1 <= nk) wait_vm<(NST - 2) * (PPW + 1)>();
+            else wait_vm<0>();
+        } else {
+            if (kt + NST - 1 <= nk) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>();
+        }
         asm volatile("s_barrier" ::: "memory");
+        if (PFD) {
+            const int kp = kt + PFD < nk ? kt + PFD : nk - 1;
+            // a 4-byte-per-lane LDS-DMA into a scratch area: touches the line without a destination VGPR (an asynchronous load into
+            // a register the compiler considers free would clobber whatever it allocates there next)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(pf_base + (int64_t)kp * CHUNK), LDS_PTR(smem + NST * STAGE + wave * 256), 4, 0, 0);
+        }
         if (MODE != 1 && MODE != 3 && kt + NST - 1 < nk) issue(kt + NST - 1, nxt);
         const unsigned char* st = smem + cur * STAGE;
         cur = cur + 1 == NST ? 0 : cur + 1;
@@ -241,7 +268,7 @@ static float run_gemm(const SArgs& a0, int iters, int super = 0) {
     constexpr int NW = (BM / WM) * (BN / WN);
     constexpr int SUBM = WM < 64 ? WM : 64;
     constexpr int stage_lds = NST * (BM + BN) * 96, epi_lds = NW * SUBM * (WN + 4) * 4;
-    constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
+    constexpr int lds = (stage_lds > epi_lds ? stage_lds : epi_lds) + ((MODE == 4 || MODE == 5) ? 2048 : 0);
     static_assert(lds <= 160 * 1024, "LDS");
     auto kern = sgemm2_kernel<BM, BN, WM, WN, NST, TERMS, MODE>;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -498,7 +525,7 @@ static int check(int M, int N, int K, float scaleA) {
         else if (cfg == 0) run_gemm<256, 256, 128, 64, 3, 6>(a, 1);
         else if (cfg == 1) run_gemm<256, 128, 64, 64, 3, 6>(a, 1, 32);
         else if (cfg == 2) run_gemm<128, 128, 64, 64, 3, 6>(a, 1, 64);
-        else run_gemm<256, 256, 128, 64, 3, 6>(a, 1, 16);
+        else run_gemm<256, 256, 128, 64, 3, 6, 4>(a, 1, 16);
         CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
         double max_err = 0;
         for (size_t i = 0; i < hC.size(); ++i) {
@@ -559,6 +586,8 @@ int main(int argc, char** argv) {
             RUN("noDMA", (run_gemm<256, 256, 128, 64, 3, 6, 1>(a, it, 16)));
             RUN("DMAonly", (run_gemm<256, 256, 128, 64, 3, 6, 2>(a, it, 16)));
             RUN("noDMA 16x16x32", (run_gemm<256, 256, 128, 64, 3, 6, 3>(a, it, 16)));
+            RUN("PF4", (run_gemm<256, 256, 128, 64, 3, 6, 4>(a, it, 16)));
+            RUN("PF6", (run_gemm<256, 256, 128, 64, 3, 6, 5>(a, it, 16)));
             printf("\n    256x128:");
             RUN("s3", (run_gemm<256, 128, 64, 64, 3, 6>(a, it)));
             RUN("s4 super32", (run_gemm<256, 128, 64, 64, 4, 6>(a, it, 32)));
