@@ -478,17 +478,20 @@ bool gemm_bf16x3_supported(int64_t M, int N, int K) { return M > 0 && N > 0 && N
 
 // tile configuration: 0 = 256x256, 8 waves, one block per CU; 1 = 256x128, 4 waves, two blocks per CU.
 // AVD_S3_TILE=0|1 forces one (measurement aid); default: per epilogue, what measured faster in the C3 pipeline.
-static int s3_tile_for(int epi) {
+static int s3_tile_for(int epi, int64_t M, int N) {
     static const int forced = [] { const char* e = getenv("AVD_S3_TILE"); return e ? atoi(e) : -1; }();
     if (forced == 0 || forced == 1) return forced;
     // C3 pipeline, ms per step over 8 launches: fc1+GELU->split3 2.75 (one block/CU) vs 2.48 (two); in_proj->qkv3 1.98 vs 1.94;
     // out_proj/fc2 + residual (16 launches) 3.07 vs 3.27
-    return (epi == S3_EPI_GELU_SPLIT || epi == S3_EPI_QKV3) ? 1 : 0;
+    if (epi == S3_EPI_GELU_SPLIT || epi == S3_EPI_QKV3) return 1;
+    // 256x256 tiles only when they occupy most of the 256 CUs (C3: 106 x 2 = 212 blocks); at the 128x128 geometry
+    // (8,512 rows) the 256x128 tiles run the whole step in 3.75 ms against 4.78
+    return (M + 255) / 256 * (N / 256) >= 192 ? 0 : 1;
 }
 
 template <int EPI>
 static int launch_s3(const S3Args& a, hipStream_t st) {
-    const int tile = s3_tile_for(EPI);
+    const int tile = s3_tile_for(EPI, a.M, a.N);
     const int BMt = tile ? S3B_BM : S3_BM, BNt = tile ? S3B_BN : S3_BN, lds = tile ? S3B_LDS : S3_LDS;
     static bool attr[2] = {false, false};
     const void* kern = tile ? reinterpret_cast<const void*>(gemm_bf16x3_b_kernel<EPI>) : reinterpret_cast<const void*>(gemm_bf16x3_kernel<EPI>);

@@ -684,7 +684,7 @@ def test_rmsnorm_split3(dev):
 
 
 def test_core_bf16x3_vs_oracle_and_f32(dev, full):
-    """MMDiT.forward at a batch large enough for the bf16x3 path (rows >= 16384): same tolerance as the fp32 path, and
+    """MMDiT.forward at a batch large enough for the bf16x3 path (rows >= 6144): same tolerance as the fp32 path, and
     no further from the fp64 oracle than the fp32 MFMA path is."""
     ws, _ = full
     core3, _, _, _ = _full_modules(dev, ws)
