@@ -36,6 +36,16 @@ def test_error_channel_without_gpu():
         L.check(L.EINVAL)
     with pytest.raises(L.AvdError):
         L.check(L.EUNSUPPORTED)
+    # bf16x3 entry points: size helpers and shape guards
+    assert lib.avd_split3_bytes(300, 512) == 512 * 512 * 6            # rows padded to 256, six bytes per element
+    assert lib.avd_split3_bytes(300, 24) == -1                         # K must be a multiple of 16
+    assert lib.avd_qkv3_bytes(2, 421, 8) == 3 * 2 * 8 * 448 * 384      # tokens padded to 64, 384-byte rows
+    assert lib.avd_qkv3_bytes(0, 421, 8) == -1
+    assert lib.avd_gemm_bf16x3_f32(16, 16, None, None, 16, None, 100, 200, 512, 0, None) == L.EUNSUPPORTED   # N % 256 != 0
+    assert b"N % 256" in lib.avd_last_error()
+    assert lib.avd_gemm_bf16x3_f32(None, 16, None, None, 16, None, 100, 256, 512, 0, None) == L.EINVAL
+    assert lib.avd_gemm_bf16x3_qkv3_f32(16, 16, 16, 16, 1000, 421, 8, 512, 0.1, None) == L.EINVAL          # rows not a multiple of tokens
+    assert lib.avd_attn_fwd_qkv3_f32(16, 16, None, 2, 421, 8, 500, None) == L.EINVAL                       # n_query > N
 
 
 def test_schedule_tables_bit_exact_vs_reference():
