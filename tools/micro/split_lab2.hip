@@ -81,6 +81,7 @@ struct SArgs {
     float* C;
     int64_t M;
     int N, K, nbn, sm, sn;
+    unsigned long long* dbg;   // MODE 6: per (block, wave) phase cycle sums
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() {
@@ -183,7 +184,10 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 1) void sgemm2_kernel(S
         }
     }
     int cur = 0, nxt = NST - 1;
+    unsigned long long ph[5] = {0, 0, 0, 0, 0};
     for (int kt = 0; kt < nk; ++kt) {
+        unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
+        if (MODE == 6) tA = __builtin_amdgcn_s_memtime();
         if (PFD) {
             if (kt == 0) wait_vm<(NST - 2) * PPW>();
             else if (kt + NST - 1 <= nk) wait_vm<(NST - 2) * (PPW + 1)>();
@@ -191,7 +195,9 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 1) void sgemm2_kernel(S
         } else {
             if (kt + NST - 1 <= nk) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>();
         }
+        if (MODE == 6) { tB = __builtin_amdgcn_s_memtime(); }
         asm volatile("s_barrier" ::: "memory");
+        if (MODE == 6) { tC = __builtin_amdgcn_s_memtime(); ph[0] += tB - tA; ph[1] += tC - tB; }
         if (PFD) {
             const int kp = kt + PFD < nk ? kt + PFD : nk - 1;
             // a 4-byte-per-lane LDS-DMA into a scratch area: touches the line without a destination VGPR (an asynchronous load into
@@ -212,6 +218,11 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 1) void sgemm2_kernel(S
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + 32 * p);
+        if (MODE == 6) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            tD = __builtin_amdgcn_s_memtime();
+            ph[2] += tD - tC;
+        }
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
         constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
@@ -231,7 +242,17 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 1) void sgemm2_kernel(S
                         acc[i][j][6 + 4 * (t & 1)] = q1[2]; acc[i][j][7 + 4 * (t & 1)] = q1[3];
                     } else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+        if (MODE == 6) { const unsigned long long tE = __builtin_amdgcn_s_memtime(); ph[3] += tE - tD; }
     }
+    if (MODE == 6) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        __syncthreads();
+        ph[4] = __builtin_amdgcn_s_memtime() - t0;
+        if (lane == 0 && g.dbg) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) g.dbg[((int64_t)blockIdx.x * NW + wave) * 5 + i] = ph[i];
+        }
+    } else
     __syncthreads();
 
     // epilogue: per wave, 64-row passes through a private LDS slab, streamed out as 16-byte row segments (+bias)
@@ -501,7 +522,7 @@ static int check(int M, int N, int K, float scaleA) {
     CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(db, hb.data(), N * 4, hipMemcpyHostToDevice));
     do_split(dA, dAs, M, K); do_split(dW, dWs, N, K);
-    SArgs a{dAs, dWs, db, dC, M, N, K, 0, 0, 0};
+    SArgs a{dAs, dWs, db, dC, M, N, K, 0, 0, 0, nullptr};
     std::vector<double> ref((size_t)M * N);
     double max_ref = 0, max_f32 = 0;
     for (int m = 0; m < M; ++m)
@@ -564,7 +585,7 @@ int main(int argc, char** argv) {
     struct Shape { const char* name; int N, K; } shapes[] = {{"qkv", 1536, 512}, {"out_proj", 512, 512}, {"fc1", 2048, 512}, {"fc2", 512, 2048}};
     {
         do_split(dA, dAs, M, 512); do_split(dW, dWs, 2048, 512);
-        SArgs a{dAs, dWs, db, dC, M, 2048, 512, 0, 0, 0};
+        SArgs a{dAs, dWs, db, dC, M, 2048, 512, 0, 0, 0, nullptr};
         run_gemm<256, 256, 128, 64, 3, 6>(a, 300);
     }
     for (int rep = 0; rep < 2; ++rep)
@@ -575,7 +596,7 @@ int main(int argc, char** argv) {
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float sms; CK(hipEventElapsedTime(&sms, e0, e1));
             do_split(dW, dWs, s.N, s.K);
-            SArgs a{dAs, dWs, db, dC, M, s.N, s.K, 0, 0, 0};
+            SArgs a{dAs, dWs, db, dC, M, s.N, s.K, 0, 0, 0, nullptr};
             const double fl = 2.0 * (double)M * s.N * s.K;
             const int it = 100;
             float t;
@@ -588,6 +609,25 @@ int main(int argc, char** argv) {
             RUN("noDMA 16x16x32", (run_gemm<256, 256, 128, 64, 3, 6, 3>(a, it, 16)));
             RUN("PF4", (run_gemm<256, 256, 128, 64, 3, 6, 4>(a, it, 16)));
             RUN("PF6", (run_gemm<256, 256, 128, 64, 3, 6, 5>(a, it, 16)));
+            {
+                unsigned long long* dbg; const int nblk = 1024;
+                CK(hipMalloc(&dbg, (size_t)nblk * 8 * 5 * 8)); CK(hipMemset(dbg, 0, (size_t)nblk * 8 * 5 * 8));
+                SArgs ad = a; ad.dbg = dbg;
+                run_gemm<256, 256, 128, 64, 3, 6, 6>(ad, 3, 16);
+                std::vector<unsigned long long> h((size_t)nblk * 8 * 5);
+                CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
+                double sum[5] = {0, 0, 0, 0, 0}; int cnt = 0;
+                for (int b = 0; b < nblk; ++b) for (int w = 0; w < 8; ++w) {
+                    const unsigned long long* p = &h[((size_t)b * 8 + w) * 5];
+                    if (p[3] == 0) continue;
+                    for (int i = 0; i < 5; ++i) sum[i] += (double)p[i];
+                    ++cnt;
+                }
+                const double steps = s.K / 16.0;
+                printf("\n    phases (memtime ticks per K-step, mean over %d waves): wait_vm %.0f | barrier %.0f | dma-issue+frag-reads %.0f | mfma %.0f | final-sync %.0f (per block)",
+                       cnt, sum[0] / cnt / steps, sum[1] / cnt / steps, sum[2] / cnt / steps, sum[3] / cnt / steps, sum[4] / cnt);
+                CK(hipFree(dbg));
+            }
             printf("\n    256x128:");
             RUN("s3", (run_gemm<256, 128, 64, 64, 3, 6>(a, it)));
             RUN("s4 super32", (run_gemm<256, 128, 64, 64, 4, 6>(a, it, 32)));
