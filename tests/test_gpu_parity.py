@@ -817,3 +817,39 @@ def test_full_step_bf16x3_512(dev, full):
     eng.set_prompt(z_a.to(dev))
     out = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev))
     assert rel_err(out[:1].cpu(), ref) < TOL
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 256, 16), (255, 256, 64), (256, 512, 4096), (257, 256, 512), (513, 768, 48)])
+def test_gemm_bf16x3_edge_shapes(dev, M, N, K):
+    """Row counts around the 128/256-row tile edges, the smallest and a large K."""
+    from multimodal_diffusion_amd import functional as Fn
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    ref = R.linear(x.double(), w.double(), b.double()) + r.double()
+    y = Fn.linear_bf16x3(Fn.split3(x.to(dev)), M, Fn.split3(w.to(dev)), N, K, bias=b.to(dev), residual=r.to(dev)).cpu()
+    assert rel_err(y, ref) < 2e-6
+
+
+@pytest.mark.parametrize("B,N,H,nq", [(1, 5, 4, 5), (2, 64, 4, 64), (1, 200, 4, 1), (1, 129, 8, 128), (1, 1573, 4, 1536)])
+def test_attention_bf16x3_edge_shapes(dev, B, N, H, nq):
+    """Sequences shorter than a key tile, exactly one tile, ragged long (the 512x512 geometry) and tiny / ragged query counts."""
+    from multimodal_diffusion_amd import functional as Fn, _lib as L
+    d = H * 64
+    g = torch.Generator().manual_seed(N + H)
+    qkv = torch.randn(B * N, 3 * d, generator=g)
+    lib = L.lib()
+    img = torch.empty(lib.avd_qkv3_bytes(B, N, H), dtype=torch.uint8, device=dev)
+    x3, w3 = Fn.split3(qkv.to(dev)), Fn.split3(torch.eye(3 * d).to(dev))
+    zb = torch.zeros(3 * d, device=dev)
+    L.check(lib.avd_gemm_bf16x3_qkv3_f32(x3.data_ptr(), w3.data_ptr(), zb.data_ptr(), img.data_ptr(), B * N, N, H, 3 * d,
+                                         0.125 * 1.4426950408889634, L.stream_ptr(dev)))
+    out = torch.full((B, N, d), 7.0, device=dev)
+    L.check(lib.avd_attn_fwd_qkv3_f32(img.data_ptr(), out.data_ptr(), None, B, N, H, nq, L.stream_ptr(dev)))
+    full = qkv.double().view(B, N, 3, H, 64)
+    q, k, v = (full[:, :, i].transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v).transpose(1, 2).reshape(B, N, d)
+    assert rel_err(out.cpu()[:, :nq], ref[:, :nq]) < 2e-6
+    assert torch.all(out[:, nq:] == 7.0)
