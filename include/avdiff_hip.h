@@ -274,7 +274,12 @@ typedef struct {
     const float* const* gn_b;          /* dec_net.{i}.2.bias   [base] */
     const float* to_img_w;             /* to_img.weight [out_ch,base] */
     const float* to_img_b;             /* to_img.bias   [out_ch] */
+    const void* const* conv_w3;        /* optional HOST array [n_blocks] of avd_conv3_weight_f32 images: the convolutions then run
+                                        * on the bf16 matrix pipe with exactly split operands (fp32-level error, see "bf16x3"); NULL = fp32 MFMA */
 } avd_vae_decode_desc;
+/* weight image of one 3x3x3 64->64 convolution for the bf16x3 decoder: w_tap_major is [out][kt][kh][kw][in] fp32 */
+int64_t avd_conv3_weight_bytes(void);
+int avd_conv3_weight_f32(const float* w_tap_major, void* img, avd_stream_t stream);
 int64_t avd_vae_decode_workspace_bytes(const avd_vae_decode_desc* d);
 int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, float* out, void* workspace,
                        int64_t workspace_bytes, avd_stream_t stream);

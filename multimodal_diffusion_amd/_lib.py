@@ -67,7 +67,8 @@ class VaeDecodeDesc(C.Structure):
                 ("from_lat_w", C.c_void_p), ("from_lat_b", C.c_void_p),
                 ("conv_w", C.POINTER(C.c_void_p)), ("conv_b", C.POINTER(C.c_void_p)),
                 ("gn_w", C.POINTER(C.c_void_p)), ("gn_b", C.POINTER(C.c_void_p)),
-                ("to_img_w", C.c_void_p), ("to_img_b", C.c_void_p)]
+                ("to_img_w", C.c_void_p), ("to_img_b", C.c_void_p),
+                ("conv_w3", C.POINTER(C.c_void_p))]
 
 
 class VaeEncodeDesc(C.Structure):
@@ -116,6 +117,8 @@ SIGNATURES = {
     "avd_gemm_bf16x3_qkv3_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
     "avd_attn_fwd_qkv3_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "avd_gemm_bf16x3_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "avd_conv3_weight_bytes": (_L, []),
+    "avd_conv3_weight_f32": (_I, [_P, _P, _P]),
     "avd_vae_decode_workspace_bytes": (_L, [C.POINTER(VaeDecodeDesc)]),
     "avd_vae_decode_f32": (_I, [C.POINTER(VaeDecodeDesc), _P, _P, _P, _L, _P]),
     "avd_vae_encode_workspace_bytes": (_L, [C.POINTER(VaeEncodeDesc)]),

@@ -390,6 +390,247 @@ __global__ __launch_bounds__(256) void gn_pool_tolat_kernel(const float* __restr
     }
 }
 
+// =========================================================================================================
+// bf16x3 decoder path: the two 3x3x3 convolutions on the bf16 matrix pipe with exactly split operands (x = h + m + l, six
+// product terms, fp32 accumulation — rationale and error analysis in gemm_bf16x3.hip).  The zero-haloed activation buffer
+// then holds, per voxel, 384 B = [plane h | m | l][64 channels bf16] ("act3"); the producers (trilinear upsample, GroupNorm
+// apply) write it directly, so no fp32 copy of the conv inputs exists.  Weights become a per-(tap, half-tap) image
+// [54][3 planes][64 out][32 ch] with its 16-byte chunks pre-swizzled for the LDS reads.
+// =========================================================================================================
+constexpr int A3_ROWB = 384;                   // bytes per voxel of the act3 buffer
+constexpr int W3_STAGE = 3 * 64 * 64;          // weight bytes per (tap, half-tap) stage
+constexpr int W3_BYTES = 54 * W3_STAGE;
+
+struct Conv3Args {
+    const unsigned char* X3;   // act3, padded [B, T+2, H+2, W+2] voxels x 384 B
+    const unsigned char* W3;   // weight image
+    const float* bias;
+    float* Y;                  // NDHWC fp32 [B, T, H, W, 64]
+    float* part;
+    int T, H, W, tiles;
+};
+
+// Wt [64 out][27 taps][64 in] fp32 -> weight image: stage kt = 2*tap + half holds [plane][out][4 chunks of 8 in-channels],
+// chunk c of row `out` at slot c ^ ((out>>2)&3)
+__global__ __launch_bounds__(256) void conv3_weight_kernel(const float* __restrict__ Wt, unsigned char* __restrict__ img) {
+    const int i = blockIdx.x * 256 + threadIdx.x;          // one thread = 8 in-channels of one (stage, out)
+    if (i >= 54 * 64 * 4) return;
+    const int c = i & 3, out = (i >> 2) & 63, kt = i >> 8;
+    const int tap = kt >> 1, half = kt & 1;
+    float v[8];
+    const float* src = Wt + ((int64_t)out * 27 + tap) * VC + half * 32 + c * 8;
+    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(src);
+    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(src + 4);
+    u32x4 Hh, Mi, Lo;
+    split8(v, Hh, Mi, Lo);
+    unsigned char* dst = img + (int64_t)kt * W3_STAGE + out * 64 + ((c ^ ((out >> 2) & 3)) << 4);
+    *reinterpret_cast<u32x4*>(dst) = Hh;
+    *reinterpret_cast<u32x4*>(dst + 4096) = Mi;
+    *reinterpret_cast<u32x4*>(dst + 8192) = Lo;
+}
+
+__device__ __forceinline__ void store_act3(unsigned char* X3, int64_t pv, int c8, const float* v) {
+    u32x4 Hh, Mi, Lo;
+    split8(v, Hh, Mi, Lo);
+    unsigned char* dst = X3 + pv * A3_ROWB + c8 * 16;
+    *reinterpret_cast<u32x4*>(dst) = Hh;
+    *reinterpret_cast<u32x4*>(dst + 128) = Mi;
+    *reinterpret_cast<u32x4*>(dst + 256) = Lo;
+}
+
+// trilinear upsample into the interior of the act3 buffer (same arithmetic as upsample_pad_kernel, 8 channels per thread)
+__global__ __launch_bounds__(256) void upsample_pad3_kernel(const float* __restrict__ hlow, unsigned char* __restrict__ X3,
+                                                            int Tp, int Hp_, int Wp_, int T, int H, int W, float st,
+                                                            float sh, float sw, int64_t total8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total8) return;
+    const int c8 = (int)(i & 7);
+    const int64_t vox = i >> 3;
+    const int THW = T * H * W;
+    const int smp = (int)(vox / THW), v = (int)(vox % THW);
+    const int w = v % W, h = (v / W) % H, t = v / (W * H);
+    int t0, t1, h0, h1, w0, w1;
+    float tl0, tl1, hl0, hl1, wl0, wl1;
+    tri_src(t, st, Tp, t0, t1, tl0, tl1);
+    tri_src(h, sh, Hp_, h0, h1, hl0, hl1);
+    tri_src(w, sw, Wp_, w0, w1, wl0, wl1);
+    float o[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float* base = hlow + (int64_t)smp * Tp * Hp_ * Wp_ * VC + c8 * 8 + q * 4;
+        auto at = [&](int tt, int hh, int ww) {
+            return *reinterpret_cast<const f32x4*>(base + ((int64_t)(tt * Hp_ + hh) * Wp_ + ww) * VC);
+        };
+        const f32x4 r = tl0 * (hl0 * (wl0 * at(t0, h0, w0) + wl1 * at(t0, h0, w1)) + hl1 * (wl0 * at(t0, h1, w0) + wl1 * at(t0, h1, w1))) +
+                        tl1 * (hl0 * (wl0 * at(t1, h0, w0) + wl1 * at(t1, h0, w1)) + hl1 * (wl0 * at(t1, h1, w0) + wl1 * at(t1, h1, w1)));
+        o[4 * q] = r[0]; o[4 * q + 1] = r[1]; o[4 * q + 2] = r[2]; o[4 * q + 3] = r[3];
+    }
+    const int64_t pv = (((int64_t)smp * (T + 2) + t + 1) * (H + 2) + h + 1) * (W + 2) + w + 1;
+    store_act3(X3, pv, c8, o);
+}
+
+// GroupNorm apply: Y (NDHWC fp32) -> interior of the act3 buffer feeding the next conv (a chunk of 8 channels = one group)
+__global__ __launch_bounds__(256) void gn_apply_pad3_kernel(const float* __restrict__ Y, const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            unsigned char* __restrict__ X3, int T, int H, int W, int64_t total8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total8) return;
+    const int c8 = (int)(i & 7);
+    const int64_t vox = i >> 3;
+    const int THW = T * H * W;
+    const int smp = (int)(vox / THW), v = (int)(vox % THW);
+    const int w = v % W, h = (v / W) % H, t = v / (W * H);
+    const float mean = stats[(smp * VG + c8) * 2], rstd = stats[(smp * VG + c8) * 2 + 1];
+    float y[8], gm[8], bt[8], o[8];
+    *reinterpret_cast<f32x4*>(y) = *reinterpret_cast<const f32x4*>(Y + vox * VC + c8 * 8);
+    *reinterpret_cast<f32x4*>(y + 4) = *reinterpret_cast<const f32x4*>(Y + vox * VC + c8 * 8 + 4);
+    *reinterpret_cast<f32x4*>(gm) = *reinterpret_cast<const f32x4*>(gamma + c8 * 8);
+    *reinterpret_cast<f32x4*>(gm + 4) = *reinterpret_cast<const f32x4*>(gamma + c8 * 8 + 4);
+    *reinterpret_cast<f32x4*>(bt) = *reinterpret_cast<const f32x4*>(beta + c8 * 8);
+    *reinterpret_cast<f32x4*>(bt + 4) = *reinterpret_cast<const f32x4*>(beta + c8 * 8 + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (y[e] - mean) * rstd * gm[e] + bt[e];
+    const int64_t pv = (((int64_t)smp * (T + 2) + t + 1) * (H + 2) + h + 1) * (W + 2) + w + 1;
+    store_act3(X3, pv, c8, o);
+}
+
+// conv 3x3x3 64 -> 64 + bias + GELU + GroupNorm partial statistics, bf16x3.  128 voxels x 64 out per block, 4 waves (64 x 32 each),
+// K-stage = half a tap (32 channels = two MFMA k-steps), two 36 KiB LDS stages, two blocks per CU.
+// LDS image of a stage: A [plane][128 voxels][64 B], W [plane][64 out][64 B]; 16-byte chunk c of row r at slot c ^ ((r>>2)&3).
+__global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
+    constexpr int BM = VBM, WM = 64, WN = 32, TM = 2;
+    constexpr int A_ST = 3 * BM * 64, STAGE = A_ST + W3_STAGE;       // 24 KiB + 12 KiB
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+
+    const int nwg = gridDim.x;
+    int wg;
+    {
+        const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    }
+    const int smp = wg / g.tiles, tile = wg % g.tiles;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int THW = g.T * g.H * g.W;
+    const int Hp = g.H + 2, Wp = g.W + 2;
+
+    // DMA A: piece q = plane*8 + rowset (16 voxel rows x 64 B of one plane); wave w takes q = w + 4 i, i.e. row sets w and w + 4 of
+    // every plane.  Lane -> voxel row 16*rowset + lane/4, physical chunk lane%4.
+    const int r16 = lane >> 2, pc = lane & 3;
+    const unsigned char* a_src[2];
+#pragma unroll
+    for (int rs = 0; rs < 2; ++rs) {
+        const int trow = (wave + 4 * rs) * 16 + r16;
+        int v = tile * BM + trow;
+        v = v < THW ? v : THW - 1;
+        const int w = v % g.W, h = (v / g.W) % g.H, t = v / (g.W * g.H);
+        const int64_t pv = (((int64_t)smp * (g.T + 2) + t) * Hp + h) * Wp + w;      // tap (0,0,0) of this voxel
+        a_src[rs] = g.X3 + pv * A3_ROWB + ((pc ^ ((trow >> 2) & 3)) << 4);
+    }
+    auto stage = [&](int kt, int buf) {
+        unsigned char* as = smem3 + buf * STAGE;
+        const int tap = kt >> 1, half = kt & 1;
+        const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+        const int64_t offA = (int64_t)((dt * Hp + dh) * Wp + dw) * A3_ROWB + half * 64;   // same shift for every voxel of the tile
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int plane = i >> 1, rs = i & 1;
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(a_src[rs] + offA + plane * 128),
+                                             AVD_LDS_PTR(as + plane * (BM * 64) + (wave + 4 * rs) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int r = wave + 4 * j;
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(g.W3 + (int64_t)kt * W3_STAGE + r * 1024 + lane * 16),
+                                             AVD_LDS_PTR(as + A_ST + r * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    constexpr int nk = 54;
+    stage(0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __syncthreads();
+
+    int a_row[TM], a_sw[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * WM + i * 32 + l31;
+        a_row[i] = r * 64;
+        a_sw[i] = (r >> 2) & 3;
+    }
+    const int br = wn * WN + l31;
+    const int b_row = A_ST + br * 64, b_sw = (br >> 2) & 3;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
+        const unsigned char* st = smem3 + cur * STAGE;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 af[TM][3], bf[3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    af[i][p] = *reinterpret_cast<const bf16x8*>(st + p * (BM * 64) + a_row[i] + (((2 * s + hi) ^ a_sw[i]) << 4));
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(st + p * 4096 + b_row + (((2 * s + hi) ^ b_sw) << 4));
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[PB[t]], acc[i], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+    }
+
+    // ---- epilogue (as conv3d_k3_gelu_stats_kernel): slab -> bias + GELU -> NDHWC store + GroupNorm partial statistics ----
+    constexpr int CLD = WN + 4;
+    float* slab = reinterpret_cast<float*>(smem3) + wave * WM * CLD;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) slab[(i * 32 + mfma32_row(r, hi)) * CLD + l31] = acc[i][r];
+    __syncthreads();
+
+    constexpr int LPR = WN / 4, RPI = 64 / LPR, NIT = WM / RPI;
+    const int cr = lane / LPR, cc = (lane % LPR) * 4;
+    const int n = wn * WN + cc;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int v = tile * BM + wm * WM + cr + it * RPI;
+        f32x4 y = *reinterpret_cast<const f32x4*>(slab + (cr + it * RPI) * CLD + cc);
+        y += bv;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) y[e] = gelu_erf(y[e]);
+        if (v < THW) {
+            *reinterpret_cast<f32x4*>(g.Y + ((int64_t)smp * THW + v) * VC + n) = y;
+            s1 += (y[0] + y[1]) + (y[2] + y[3]);
+            s2 += (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+        }
+    }
+    s1 += __shfl_xor(s1, 1, 64);  s2 += __shfl_xor(s2, 1, 64);
+    s1 += __shfl_xor(s1, 8, 64);  s2 += __shfl_xor(s2, 8, 64);
+    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    if ((lane & 0x39) == 0) {
+        float* p = g.part + ((((int64_t)smp * g.tiles + tile) * 2 + wm) * VG + wn * 4 + (lane >> 1)) * 2;
+        p[0] = s1;
+        p[1] = s2;
+    }
+}
+
 static inline int64_t a256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 struct VaePlan {
@@ -409,7 +650,7 @@ static int vae_plan(const avd_vae_decode_desc* d, VaePlan& p) {
     AVD_REQUIRE(p.THW * VC < (1ll << 31) && (int64_t)(d->T + 2) * (d->H + 2) * (d->W + 2) * VC < (1ll << 31), AVD_EUNSUPPORTED,
                 "vae_decode: one sample's activation exceeds 2^31 elements");
     p.tiles = (int)((p.THW + VBM - 1) / VBM);
-    p.pad_b = a256((int64_t)d->B * (d->T + 2) * (d->H + 2) * (d->W + 2) * VC * 4);
+    p.pad_b = a256((int64_t)d->B * (d->T + 2) * (d->H + 2) * (d->W + 2) * (d->conv_w3 ? A3_ROWB : VC * 4));
     p.y_b = a256((int64_t)d->B * p.THW * VC * 4);
     p.hlow_b = a256((int64_t)d->B * d->Tp * d->Hp * d->Wp * VC * 4);
     p.part_b = a256((int64_t)d->B * p.tiles * 2 * VG * 2 * 4);
@@ -421,6 +662,15 @@ static int vae_plan(const avd_vae_decode_desc* d, VaePlan& p) {
 }  // namespace avd
 
 using namespace avd;
+
+extern "C" int64_t avd_conv3_weight_bytes(void) { return W3_BYTES; }
+extern "C" int avd_conv3_weight_f32(const float* w_tap_major, void* img, avd_stream_t stream) {
+    AVD_REQUIRE(w_tap_major && img && aligned16(w_tap_major) && aligned16(img), AVD_EINVAL, "conv3_weight: bad pointer");
+    hipLaunchKernelGGL(conv3_weight_kernel, dim3(54), dim3(256), 0, static_cast<hipStream_t>(stream), w_tap_major,
+                       static_cast<unsigned char*>(img));
+    AVD_CHECK_LAUNCH("conv3_weight");
+    return AVD_OK;
+}
 
 extern "C" int64_t avd_vae_decode_workspace_bytes(const avd_vae_decode_desc* d) {
     VaePlan p;
@@ -445,9 +695,13 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
     float* stats = reinterpret_cast<float*>(w + p.pad_b + p.y_b + p.hlow_b + p.part_b);
     const int B = d->B;
 
+    const bool s3 = d->conv_w3 != nullptr;                  // bf16x3 convolutions: Xp is the act3 buffer (384 B per voxel)
+    unsigned char* X3 = reinterpret_cast<unsigned char*>(w);
+    if (s3)
+        for (int blk = 0; blk < d->n_blocks; ++blk) AVD_REQUIRE(d->conv_w3[blk], AVD_EINVAL, "vae_decode: null conv_w3[%d]", blk);
     // zero halo (whole padded buffer; interiors are overwritten below, the halo stays zero for every conv)
     {
-        hipError_t e = hipMemsetAsync(Xp, 0, (size_t)B * (p.T + 2) * (p.H + 2) * (p.W + 2) * VC * 4, st);
+        hipError_t e = hipMemsetAsync(Xp, 0, (size_t)B * (p.T + 2) * (p.H + 2) * (p.W + 2) * (s3 ? A3_ROWB : VC * 4), st);
         if (e != hipSuccess) return set_error(AVD_ELAUNCH, "vae_decode memset: %s", hipGetErrorString(e));
     }
     {   // from_lat on the latent grid, then trilinear upsample into the padded conv input
@@ -459,7 +713,14 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
                            d->from_lat_b, hlow, d->Cv, vol, total);
         AVD_CHECK_LAUNCH("fromlat");
     }
-    {
+    if (s3) {
+        const int64_t total8 = (int64_t)B * p.THW * 8;
+        static const int tag = prof_tag_id("upsample_pad3_kernel");
+        ProfScope prof(tag, 6.0 * (double)B * p.THW * VC, st);
+        hipLaunchKernelGGL(upsample_pad3_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, hlow, X3, d->Tp, d->Hp, d->Wp,
+                           p.T, p.H, p.W, (float)d->Tp / (float)p.T, (float)d->Hp / (float)p.H, (float)d->Wp / (float)p.W, total8);
+        AVD_CHECK_LAUNCH("upsample_pad3");
+    } else {
         const int64_t total4 = (int64_t)B * p.THW * (VC / 4);
         static const int tag = prof_tag_id("upsample_pad_kernel");
         ProfScope prof(tag, 4.0 * (double)B * p.THW * VC, st);
@@ -470,9 +731,22 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
     }
     constexpr int stage_lds = 2 * (VBM + VC) * VBK * 4, epi_lds = 4 * 64 * 36 * 4;
     constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
+    constexpr int lds3 = 2 * (3 * VBM * 64 + W3_STAGE);
+    static bool attr3 = false;
+    if (s3 && !attr3) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+        if (e != hipSuccess) return set_error(AVD_ELAUNCH, "vae_decode attr: %s", hipGetErrorString(e));
+        attr3 = true;
+    }
     for (int blk = 0; blk < d->n_blocks; ++blk) {
         ConvArgs a{Xp, d->conv_w[blk], d->conv_b[blk], Y, part, p.T, p.H, p.W, p.tiles};
-        {
+        if (s3) {
+            Conv3Args a3{X3, static_cast<const unsigned char*>(d->conv_w3[blk]), d->conv_b[blk], Y, part, p.T, p.H, p.W, p.tiles};
+            static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel");
+            ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st);
+            hipLaunchKernelGGL(conv3d_k3_bf16x3_kernel, dim3((unsigned)(B * p.tiles)), dim3(256), lds3, st, a3);
+            AVD_CHECK_LAUNCH("conv3d_bf16x3");
+        } else {
             static const int tag = prof_tag_id("conv3d_k3_gelu_stats_kernel<64>");
             ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st);
             hipLaunchKernelGGL(conv3d_k3_gelu_stats_kernel<64>, dim3((unsigned)(B * p.tiles)), dim3(256), lds, st, a);
@@ -481,7 +755,14 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
         hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * VG), dim3(256), 0, st, part, stats, p.tiles,
                            (double)p.THW * (VC / VG), d->gn_eps);
         AVD_CHECK_LAUNCH("gn_finalize");
-        if (blk + 1 < d->n_blocks) {
+        if (blk + 1 < d->n_blocks && s3) {
+            const int64_t total8 = (int64_t)B * p.THW * 8;
+            static const int tag = prof_tag_id("gn_apply_pad3_kernel");
+            ProfScope prof(tag, 10.0 * (double)B * p.THW * VC, st);
+            hipLaunchKernelGGL(gn_apply_pad3_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
+                               d->gn_b[blk], X3, p.T, p.H, p.W, total8);
+            AVD_CHECK_LAUNCH("gn_apply_pad3");
+        } else if (blk + 1 < d->n_blocks) {
             const int64_t total4 = (int64_t)B * p.THW * (VC / 4);
             static const int tag = prof_tag_id("gn_apply_pad_kernel");
             ProfScope prof(tag, 8.0 * (double)B * p.THW * VC, st);

@@ -72,6 +72,9 @@ class VideoVAE(nn.Module):
         self.to_img = nn.Conv3d(D, cfg.in_ch, kernel_size=1)
         self._ws: Optional[torch.Tensor] = None
         self._relaid = {}
+        self._conv3 = {}
+        # "f32": convolutions on fp32 MFMA; "bf16x3": decoder convolutions on the bf16 matrix pipe with exactly split operands
+        self.matmul = "f32"
 
     @classmethod
     def from_config(cls, d: Dict) -> "VideoVAE":
@@ -161,6 +164,17 @@ class VideoVAE(nn.Module):
         return getattr(self, "_kld", None)
 
     # conv weight [out,in,kt,kh,kw] -> [out][kt][kh][kw][in] (K = tap-major, channel-minor), cached per parameter version
+    def _conv3_image(self, i: int) -> torch.Tensor:
+        """bf16x3 weight image of decoder conv i (csrc/vae3d_f32.hip), rebuilt when the parameter changes."""
+        w = self.dec_net[i][0].weight
+        key = (i, w.data_ptr(), w._version, str(w.device))
+        hit = self._conv3.get(i)
+        if hit is None or hit[0] != key:
+            img = torch.empty(L.lib().avd_conv3_weight_bytes(), dtype=torch.uint8, device=w.device)
+            L.check(L.lib().avd_conv3_weight_f32(self._tap_major(i).data_ptr(), img.data_ptr(), L.stream_ptr(w.device)))
+            self._conv3[i] = (key, img)
+        return self._conv3[i][1]
+
     def _tap_major(self, i: int) -> torch.Tensor:
         w = self.dec_net[i][0].weight
         key = (i, w.data_ptr(), w._version, str(w.device))
@@ -204,6 +218,14 @@ class VideoVAE(nn.Module):
         d.conv_w, d.conv_b = C.cast(cw, C.POINTER(C.c_void_p)), C.cast(cb, C.POINTER(C.c_void_p))
         d.gn_w, d.gn_b = C.cast(gw, C.POINTER(C.c_void_p)), C.cast(gb, C.POINTER(C.c_void_p))
         d.to_img_w, d.to_img_b = tiw.data_ptr(), L.dev_f32(self.to_img.bias.detach()).data_ptr()
+        if self.matmul == "bf16x3":
+            imgs = [self._conv3_image(i) for i in range(nb)]
+            keep.extend(imgs)
+            c3 = (C.c_void_p * nb)(*[t.data_ptr() for t in imgs])
+            keep.append(c3)
+            d.conv_w3 = C.cast(c3, C.POINTER(C.c_void_p))
+        elif self.matmul != "f32":
+            raise ValueError(f"matmul must be 'f32' or 'bf16x3', got {self.matmul!r}")
         # chunk the batch so the NDHWC activations (2 x 0.85 GB per 48x256x256 sample) stay inside the budget
         d.B = 1
         per = L.lib().avd_vae_decode_workspace_bytes(C.byref(d))

@@ -853,3 +853,26 @@ def test_attention_bf16x3_edge_shapes(dev, B, N, H, nq):
     ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v).transpose(1, 2).reshape(B, N, d)
     assert rel_err(out.cpu()[:, :nq], ref[:, :nq]) < 2e-6
     assert torch.all(out[:, nq:] == 7.0)
+
+
+def test_vae_decode_bf16x3(dev):
+    """Decoder convolutions on the bf16 matrix pipe with split operands: golden fixture, ragged tiles, and the fp64 oracle at
+    128x128 — same tolerance as the fp32-MFMA decoder, and no further from fp64 than that decoder is."""
+    import multimodal_diffusion_amd as A
+    g = load_golden("g11_vae_decode.npz")
+    vae = _vae_from(split_weights(g)["w"], dev)
+    vae.matmul = "bf16x3"
+    x = vae.decode(G(g["z"], dev)).cpu()
+    assert rel_err(x, g["x"]) < TOL
+    assert rel_err(vae.decode(G(g["z"][:1], dev), out_size=(6, 24, 40)).cpu(), g["x_odd"]) < TOL
+    assert torch.equal(vae.decode(G(g["z"], dev), max_workspace_bytes=1).cpu(), x)
+    W = R.synth_vae_decoder(seed=3, n_blocks=3)
+    z = torch.randn(1, 8, 3, 16, 16, generator=torch.Generator().manual_seed(4))
+    ref = R.vae_decode(z.double(), {k: v.double() for k, v in W.items()}, n_blocks=3, out_act="tanh")
+    errs = {}
+    for mode in ("f32", "bf16x3"):
+        v = A.VideoVAE(A.VideoVAEConfig(dec_blocks=3, out_activation="tanh")).eval()
+        v.load_state_dict(W, strict=False)
+        v.matmul = mode
+        errs[mode] = rel_err(v.to(dev).decode(z.to(dev)).cpu(), ref)
+    assert errs["bf16x3"] < TOL and errs["bf16x3"] < 2.0 * errs["f32"] + 1e-7, errs
