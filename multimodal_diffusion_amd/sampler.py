@@ -54,10 +54,16 @@ def build_components(cfg: Dict, device: torch.device, vid_vae: Optional[nn.Modul
 
     The codec / VAE are built from ``cfg["video"]`` / ``cfg["audio"]`` like the reference unless the caller passes
     its own modules (anything with ``encode`` / ``decode``); they sit outside the per-step path.
+    Extension over the reference config: ``cfg["runtime"]["matmul"]`` in {"f32", "bf16x3"} selects the matrix-pipe mode of the
+    MMDiT core and the VAE decoder (default "f32"; same fp32-level error either way).
     """
+    matmul = str(cfg.get("runtime", {}).get("matmul", "f32"))
+    if matmul not in ("f32", "bf16x3"):
+        raise ValueError(f"runtime.matmul must be 'f32' or 'bf16x3', got {matmul!r}")
     if vid_vae is None and "video" in cfg:
         from .vae_video3d import VideoVAE
         vid_vae = VideoVAE.from_config(cfg["video"]).to(device).eval()
+        vid_vae.matmul = matmul
     if aud_codec is None and "audio" in cfg:
         from .audio_codec import AudioCodec
         aud_codec = AudioCodec.from_config(cfg["audio"]).to(device).eval()
@@ -68,6 +74,7 @@ def build_components(cfg: Dict, device: torch.device, vid_vae: Optional[nn.Modul
     adapt_v = LinearAdapter(out_v, d - tstep_dim).to(device)
     adapt_a = LinearAdapter(out_a, d - tstep_dim).to(device)
     core = MMDiT(**cfg["model"]["core"]).to(device).eval()
+    core.matmul = matmul
     head = MultiModalNoiseHead(
         input_dims={"video": d, "audio": d}, output_dims={"video": out_v, "audio": out_a},
         hidden_dim=int(cfg["model"]["heads"]["video"]["hidden_dim"]), num_shared_layers=2,
