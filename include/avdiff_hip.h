@@ -300,6 +300,8 @@ typedef struct {
     const float* const* gn_b;
     const float* to_lat_w;             /* to_lat.weight (or to_mu.weight) [lat_ch,64] */
     const float* to_lat_b;
+    const void* const* conv_w3;        /* optional HOST array [n_blocks] (entry 0 unused): avd_conv3_weight_f32 images of the 64->64
+                                        * convolutions, which then run on the bf16 matrix pipe (as in avd_vae_decode_desc); NULL = fp32 */
 } avd_vae_encode_desc;
 int64_t avd_vae_encode_workspace_bytes(const avd_vae_encode_desc* d);
 int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, float* z, void* workspace,

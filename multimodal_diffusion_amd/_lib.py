@@ -77,7 +77,8 @@ class VaeEncodeDesc(C.Structure):
                 ("base", C.c_int), ("n_blocks", C.c_int), ("lat_ch", C.c_int), ("gn_eps", C.c_float),
                 ("conv_w", C.POINTER(C.c_void_p)), ("conv_b", C.POINTER(C.c_void_p)),
                 ("gn_w", C.POINTER(C.c_void_p)), ("gn_b", C.POINTER(C.c_void_p)),
-                ("to_lat_w", C.c_void_p), ("to_lat_b", C.c_void_p)]
+                ("to_lat_w", C.c_void_p), ("to_lat_b", C.c_void_p),
+                ("conv_w3", C.POINTER(C.c_void_p))]
 
 
 ABI_VERSION = 2

@@ -805,7 +805,7 @@ static int vae_enc_plan(const avd_vae_encode_desc* d, VaeEncPlan& p) {
     p.tiles = (int)((p.THW + VBM - 1) / VBM);
     const int64_t padvox = (int64_t)d->B * (d->T + 2) * (d->H + 2) * (d->W + 2);
     p.pad4_b = a256(padvox * 4 * 4);
-    p.pad_b = d->n_blocks > 1 ? a256(padvox * VC * 4) : 0;
+    p.pad_b = d->n_blocks > 1 ? a256(padvox * (d->conv_w3 ? A3_ROWB : VC * 4)) : 0;
     p.y_b = a256((int64_t)d->B * p.THW * VC * 4);
     p.part_b = a256((int64_t)d->B * p.tiles * 2 * VG * 2 * 4);
     p.stats_b = a256((int64_t)d->B * VG * 2 * 4);
@@ -838,8 +838,12 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
     const int B = d->B, T = d->T, H = d->H, W = d->W;
     const int64_t padvox = (int64_t)B * (T + 2) * (H + 2) * (W + 2);
 
+    const bool s3 = d->conv_w3 != nullptr && d->n_blocks > 1;     // bf16x3 for the 64 -> 64 convolutions (block 0 is 4 -> 64, fp32)
+    unsigned char* X3 = reinterpret_cast<unsigned char*>(Xp);
+    if (s3)
+        for (int blk = 1; blk < d->n_blocks; ++blk) AVD_REQUIRE(d->conv_w3[blk], AVD_EINVAL, "vae_encode: null conv_w3[%d]", blk);
     hipError_t e = hipMemsetAsync(Xp4, 0, (size_t)padvox * 16, st);
-    if (e == hipSuccess && d->n_blocks > 1) e = hipMemsetAsync(Xp, 0, (size_t)padvox * VC * 4, st);
+    if (e == hipSuccess && d->n_blocks > 1) e = hipMemsetAsync(Xp, 0, (size_t)padvox * (s3 ? A3_ROWB : VC * 4), st);
     if (e != hipSuccess) return set_error(AVD_ELAUNCH, "vae_encode memset: %s", hipGetErrorString(e));
     {
         const int64_t nvox = (int64_t)B * p.THW;
@@ -849,9 +853,21 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
     }
     constexpr int stage_lds = 2 * (VBM + VC) * VBK * 4, epi_lds = 4 * 64 * 36 * 4;
     constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
+    constexpr int lds3 = 2 * (3 * VBM * 64 + W3_STAGE);
+    static bool attr3 = false;
+    if (s3 && !attr3) {
+        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+        if (ea != hipSuccess) return set_error(AVD_ELAUNCH, "vae_encode attr: %s", hipGetErrorString(ea));
+        attr3 = true;
+    }
     for (int blk = 0; blk < d->n_blocks; ++blk) {
         ConvArgs a{blk == 0 ? Xp4 : Xp, d->conv_w[blk], d->conv_b[blk], Y, part, T, H, W, p.tiles};
-        if (blk == 0) {
+        if (blk > 0 && s3) {
+            Conv3Args a3{X3, static_cast<const unsigned char*>(d->conv_w3[blk]), d->conv_b[blk], Y, part, T, H, W, p.tiles};
+            static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel");
+            ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st);
+            hipLaunchKernelGGL(conv3d_k3_bf16x3_kernel, dim3((unsigned)(B * p.tiles)), dim3(256), lds3, st, a3);
+        } else if (blk == 0) {
             static const int tag = prof_tag_id("conv3d_k3_gelu_stats_kernel<4>");
             ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * d->in_ch, st);
             hipLaunchKernelGGL(conv3d_k3_gelu_stats_kernel<4>, dim3((unsigned)(B * p.tiles)), dim3(256), lds, st, a);
@@ -864,7 +880,14 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
         hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * VG), dim3(256), 0, st, part, stats, p.tiles,
                            (double)p.THW * (VC / VG), d->gn_eps);
         AVD_CHECK_LAUNCH("gn_finalize");
-        if (blk + 1 < d->n_blocks) {
+        if (blk + 1 < d->n_blocks && s3) {
+            const int64_t total8 = (int64_t)B * p.THW * 8;
+            static const int tag = prof_tag_id("gn_apply_pad3_kernel");
+            ProfScope prof(tag, 10.0 * (double)B * p.THW * VC, st);
+            hipLaunchKernelGGL(gn_apply_pad3_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
+                               d->gn_b[blk], X3, T, H, W, total8);
+            AVD_CHECK_LAUNCH("gn_apply_pad3");
+        } else if (blk + 1 < d->n_blocks) {
             const int64_t total4 = (int64_t)B * p.THW * (VC / 4);
             static const int tag = prof_tag_id("gn_apply_pad_kernel");
             ProfScope prof(tag, 8.0 * (double)B * p.THW * VC, st);

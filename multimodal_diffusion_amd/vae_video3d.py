@@ -141,6 +141,12 @@ class VideoVAE(nn.Module):
         d.conv_w, d.conv_b = C.cast(cw, C.POINTER(C.c_void_p)), C.cast(cb, C.POINTER(C.c_void_p))
         d.gn_w, d.gn_b = C.cast(gw, C.POINTER(C.c_void_p)), C.cast(gb, C.POINTER(C.c_void_p))
         d.to_lat_w, d.to_lat_b = tlw.data_ptr(), L.dev_f32(self.to_lat.bias.detach()).data_ptr()
+        if self.matmul == "bf16x3" and nb > 1:
+            imgs = [self._conv3_image(i, enc=True) for i in range(1, nb)]
+            keep.extend(imgs)
+            c3 = (C.c_void_p * nb)(None, *[t.data_ptr() for t in imgs])
+            keep.append(c3)
+            d.conv_w3 = C.cast(c3, C.POINTER(C.c_void_p))
         d.B = 1
         per = L.lib().avd_vae_encode_workspace_bytes(C.byref(d))
         if per < 0:
@@ -164,16 +170,17 @@ class VideoVAE(nn.Module):
         return getattr(self, "_kld", None)
 
     # conv weight [out,in,kt,kh,kw] -> [out][kt][kh][kw][in] (K = tap-major, channel-minor), cached per parameter version
-    def _conv3_image(self, i: int) -> torch.Tensor:
-        """bf16x3 weight image of decoder conv i (csrc/vae3d_f32.hip), rebuilt when the parameter changes."""
-        w = self.dec_net[i][0].weight
-        key = (i, w.data_ptr(), w._version, str(w.device))
-        hit = self._conv3.get(i)
+    def _conv3_image(self, i: int, enc: bool = False) -> torch.Tensor:
+        """bf16x3 weight image of decoder (or encoder) conv i (csrc/vae3d_f32.hip), rebuilt when the parameter changes."""
+        w = (self.enc_net if enc else self.dec_net)[i][0].weight
+        key = (enc, i, w.data_ptr(), w._version, str(w.device))
+        hit = self._conv3.get((enc, i))
         if hit is None or hit[0] != key:
             img = torch.empty(L.lib().avd_conv3_weight_bytes(), dtype=torch.uint8, device=w.device)
-            L.check(L.lib().avd_conv3_weight_f32(self._tap_major(i).data_ptr(), img.data_ptr(), L.stream_ptr(w.device)))
-            self._conv3[i] = (key, img)
-        return self._conv3[i][1]
+            src = self._enc_weight(i) if enc else self._tap_major(i)
+            L.check(L.lib().avd_conv3_weight_f32(src.data_ptr(), img.data_ptr(), L.stream_ptr(w.device)))
+            self._conv3[(enc, i)] = (key, img)
+        return self._conv3[(enc, i)][1]
 
     def _tap_major(self, i: int) -> torch.Tensor:
         w = self.dec_net[i][0].weight

@@ -876,3 +876,21 @@ def test_vae_decode_bf16x3(dev):
         v.matmul = mode
         errs[mode] = rel_err(v.to(dev).decode(z.to(dev)).cpu(), ref)
     assert errs["bf16x3"] < TOL and errs["bf16x3"] < 2.0 * errs["f32"] + 1e-7, errs
+
+
+def test_vae_encode_bf16x3(dev):
+    """Encoder with its 64 -> 64 convolution(s) on the bf16x3 path: golden fixture at the fp32 encoder's tolerance."""
+    import warnings
+    import multimodal_diffusion_amd as A
+    g = load_golden("g12_vae_encode.npz")
+    vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval()
+    vae.load_state_dict(split_weights(g)["w"], strict=False)
+    vae = vae.to(dev)
+    z32 = vae.encode(G(g["x"], dev)).cpu()
+    vae.matmul = "bf16x3"
+    z3 = vae.encode(G(g["x"], dev)).cpu()
+    assert rel_err(z3, g["z"]) < TOL and rel_err(z3, z32) < 2e-5
+    assert not torch.equal(z3, z32) or len(vae.enc_net) == 1, "bf16x3 encoder path did not run"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert rel_err(vae.encode(G(g["x_crop"], dev)).cpu(), g["z_crop"]) < TOL
