@@ -11,15 +11,18 @@
 //
 // Operand image ("split3"): X[rows][K] fp32 -> T[ceil(rows/128)][K/16][3 planes][128 rows][32 B]; inside a 12 KiB chunk
 // the 16 bytes of (plane p, row r, half = (k%16)/8) sit at p*4096 + r*32 + (half ^ ((r>>3)&1))*16.  One block's K-tile of
-// an operand is then one contiguous, already bank-swizzled chunk, and a producer's store of one plane for consecutive
-// rows is contiguous too: the global->LDS DMA is a linear copy of whole cache lines
-// and the ds_read_b128 of fragment rows is conflict free.  Producers (RMSNorm, the fc1+GELU epilogue, the split pass
-// after attention) write this image directly, so no fp32 copy of those activations exists in this mode.
+// an operand is then one contiguous, already bank-swizzled chunk — the global->LDS DMA is a linear copy of whole cache lines,
+// the ds_read_b128 of fragment rows is conflict free — and a producer's store of one plane for consecutive rows is
+// contiguous too.  Producers write the image directly (rmsnorm_split3_kernel here, the attention epilogue in
+// attn_bf16x3.hip, the fc1 bias+GELU epilogue below), so no fp32 copy of those activations exists in this mode; the in_proj
+// epilogue writes the "qkv3" image the attention kernel reads (layout in avd_common.h).
 //
-// Kernel: 256x256 block tile, 8 waves (wave tile 128x64 = 4x2 accumulators), K-tile 16, three 48 KiB LDS stages filled by
-// LDS-DMA with a counted vmcnt (two tiles in flight), one s_barrier per K-tile, XCD-contiguous super-tiles of 16 blocks
-// so co-resident blocks share A and W panels in their XCD's L2.  The matrix pipe under this load is power-limited
-// (the chip holds ~1.6-1.9 GHz on random data), which caps the achievable rate near 280 fp32-equivalent TFLOP/s.
+// Kernels (wave tile 128x64 = 4x2 accumulators, 18 ds_read_b128 per 48 MFMAs, K-tile 16, XCD-contiguous super-tiles):
+//   gemm_bf16x3_kernel    256x256, 8 waves, one block per CU, three 48 KiB LDS stages, counted vmcnt (two tiles in flight);
+//   gemm_bf16x3_b_kernel  256x128, 4 waves, two blocks per CU, two 36 KiB stages, fragments one K-tile ahead in registers —
+//                         for the heavy epilogues (split3 / qkv3 outputs) and for batches that do not fill 256-row tiles.
+// The main loop is MFMA-paced (3,180 cycles per K-step against 3,072 of pure MFMA issue); what caps the rate near 190-200
+// fp32-equivalent TFLOP/s is power: the chip holds ~1.7 GHz under this load.
 #include "avd_common.h"
 
 #include <stdlib.h>
