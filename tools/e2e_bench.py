@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""End-to-end audio->video generation for one batch on one GPU (GPU box): 50 DDIM + CFG steps at 256x256 (the bench.py
+workload) followed by VideoVAE.decode of the whole batch — the part of sample_one_direction (sample_clip.py:220-394) that runs
+on the device.  Prints the sampler / decode split for both matrix-pipe modes."""
+import argparse
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import multimodal_diffusion_amd as A                                   # noqa: E402
+from multimodal_diffusion_amd import schedule_utils as su              # noqa: E402
+import bench                                                           # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--size", type=int, default=256)
+ap.add_argument("--sampler-steps", type=int, default=50)
+args = ap.parse_args()
+dev = torch.device("cuda:0")
+B, S, size = args.batch, args.sampler_steps, args.size
+mods, tdim = bench.build_modules(dev)
+av, aa, core, head = mods
+torch.manual_seed(0)
+vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval().to(dev)
+abar = su.alphas_cumprod_from_betas(su.make_beta_schedule(1000, "cosine", 1e-4, 0.02))[1]
+sched = su.make_sampling_schedule(1000, S)
+z0 = torch.randn(B, 8, 12, size // 8, size // 8, generator=torch.Generator().manual_seed(1)).to(dev)
+za = torch.randn(B, 8, 150, generator=torch.Generator().manual_seed(2)).to(dev)
+for mode in ("f32", "bf16x3"):
+    vae.matmul = mode
+    eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=tdim, target="video", latent_shape=tuple(z0.shape),
+                          prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=mode)
+    eng.set_prompt(za)
+    z = eng.run(z0, sched[:3])                      # warm-up
+    x = vae.decode(z[:2])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    z = eng.run(z0, sched)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    # the random-weight trajectory explodes numerically (|z| ~ 1e5); decode a unit-scale latent of the same shape
+    x = vae.decode(torch.randn_like(z))
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f"[{mode:6s}] B={B} {size}x{size}: sampler {S} steps {1e3 * (t1 - t0):7.1f} ms ({1e3 * (t1 - t0) / S:.2f} ms/step)  "
+          f"VAE decode {1e3 * (t2 - t1):7.1f} ms ({1e3 * (t2 - t1) / B:.2f} ms/sample)  total {1e3 * (t2 - t0):7.1f} ms  "
+          f"= {B / (t2 - t0):.1f} clips/s   out {tuple(x.shape)}", flush=True)
