@@ -507,8 +507,18 @@ static int launch_s3(const S3Args& a, hipStream_t st) {
     g.nbn = a.N / BNt;
     int sn = 8;
     while (g.nbn % sn) sn >>= 1;
+    // 256x128 tiles: whole block rows per super-tile, so the 12-16 column blocks that share an A panel run together and the panel
+    // is fetched into the XCD's L2 once (in_proj at C3: 2.02 -> 1.84 ms per step)
+    if (tile && g.nbn <= 16) sn = g.nbn;
+    int total = tile ? 32 : 16;
+    {   // AVD_S3_SN / AVD_S3_SUPER: measurement aids (super-tile width in blocks / blocks per super-tile)
+        static const int e_sn = getenv("AVD_S3_SN") ? atoi(getenv("AVD_S3_SN")) : 0;
+        static const int e_tot = getenv("AVD_S3_SUPER") ? atoi(getenv("AVD_S3_SUPER")) : 0;
+        if (e_sn > 0) { sn = e_sn < g.nbn ? e_sn : g.nbn; while (g.nbn % sn) --sn; }
+        if (e_tot > 0) total = e_tot;
+    }
     g.sn = sn;
-    g.sm = (tile ? 32 : 16) / sn;
+    g.sm = total / sn > 0 ? total / sn : 1;
     const int64_t nbm = (a.M + BMt - 1) / BMt;
     const int64_t nwg = (nbm + g.sm - 1) / g.sm * g.sm * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
