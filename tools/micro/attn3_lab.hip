@@ -274,6 +274,192 @@ __global__ __launch_bounds__(NW * 64, 2) void attn3_kernel(const unsigned char* 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// ring variant: 32-key tiles, three LDS stages (K + V of a tile = 24 KiB), DMA two tiles ahead behind a counted vmcnt,
+// one barrier per tile
+// ---------------------------------------------------------------------------------------------------------
+template <int N_> __device__ __forceinline__ void wait_vm() { __builtin_amdgcn_s_waitcnt(0x0f70 | (N_ & 15) | ((N_ >> 4) << 14)); }
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn3r_kernel(const unsigned char* __restrict__ img, float* __restrict__ out, int Bt, int N,
+                                                            int Npad, int H, int n_query, int nqb) {
+    constexpr int KT2 = 32, NST = 3;
+    constexpr int TILEB = KT2 * ROWB;                 // 12 KiB per operand
+    constexpr int STAGE = 2 * TILEB;                  // K then V
+    constexpr int PPW = 24 / NW;                      // 24 one-KiB pieces per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+
+    int qb, h, b;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = id & 7;
+        const int w = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+        qb = w % nqb;
+        h = (w / nqb) % H;
+        b = w / (nqb * H);
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int64_t hstride = (int64_t)Npad * ROWB;
+    const unsigned char* Qb = img + (((int64_t)0 * Bt + b) * H + h) * hstride;
+    const unsigned char* Kb = img + (((int64_t)1 * Bt + b) * H + h) * hstride;
+    const unsigned char* Vb = img + (((int64_t)2 * Bt + b) * H + h) * hstride;
+
+    const int q_row = qb * (NW * 32) + wave * 32 + l31;
+    bf16x8 qf[4][3];
+    {
+        const unsigned char* src = Qb + (int64_t)(q_row < N ? q_row : N - 1) * ROWB + hi * 16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) qf[s][p] = *reinterpret_cast<const bf16x8*>(src + p * 128 + s * 32);
+    }
+    auto dma = [&](int kt, int buf) {
+        const int last_row = N - 1 - kt * KT2;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + NW * i;                       // 0..11 K, 12..23 V
+            const int pp = p < 12 ? p : p - 12;
+            const int off = pp * 1024 + lane * 16;
+            int row = off / ROWB;
+            const int within = off - row * ROWB;
+            row = row < last_row ? row : last_row;
+            const unsigned char* g = (p < 12 ? Kb : Vb) + ((int64_t)kt * KT2 + row) * ROWB + within;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(sm + buf * STAGE + p * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = NEG, l_run = 0.f;
+    const int nkt = (N + KT2 - 1) / KT2;
+    dma(0, 0);
+    if (nkt > 1) dma(1, 1);
+
+    const int ksw = (l31 >> 1) & 7;
+    const int k_rd = l31 * ROWB;
+    const int i16 = lane & 15, cb = (lane >> 4) & 1;
+    const int v_q = i16 >> 2, v_p = i16 & 3;
+    const bool active = qb * (NW * 32) + wave * 32 < n_query;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+
+    int cur = 0, nxt = 2;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) wait_vm<PPW>(); else wait_vm<0>();
+        asm volatile("s_barrier" ::: "memory");
+        if (kt + 2 < nkt) dma(kt + 2, nxt);
+        const unsigned char* Ks = sm + cur * STAGE;
+        const unsigned char* Vs = Ks + TILEB;
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt = nxt == 2 ? 0 : nxt + 1;
+        if (!active) continue;
+
+        f32x16 s0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 ka[3];
+            const int ch = ((2 * s + hi) ^ ksw) << 4;
+#pragma unroll
+            for (int p = 0; p < 3; ++p) ka[p] = *reinterpret_cast<const bf16x8*>(Ks + k_rd + p * 128 + ch);
+#pragma unroll
+            for (int t = 0; t < 6; ++t) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[PA[t]], qf[s][PB[t]], s0, 0, 0, 0);
+        }
+        if (kt == nkt - 1 && (N & (KT2 - 1))) {
+            const int kbase = kt * KT2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kbase + mfma32_row(r, hi) >= N) s0[r] = NEG;
+        }
+        float mt = s0[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, s0[r]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        float ps = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+            ps += s0[r];
+        }
+        if (__any(m_new > m_run)) {
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+        l_run += ps;
+        m_run = m_new;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float pv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] = s0[8 * t + j];
+            u32x4 P[3];
+            split8(pv, P[0], P[1], P[2]);
+            bf16x8 pf[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) pf[p] = __builtin_bit_cast(bf16x8, P[p]);
+            const int key0 = 16 * t + 4 * hi + v_q;
+            const int sw = ((key0 >> 1) & 1) << 2;
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                const int chunk = 4 * db + 2 * cb + (v_p >> 1);
+                bf16x8 vf[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)LDS_PTR(Vs + key0 * ROWB + p * 128 + ((chunk ^ sw) << 4) + 8 * (v_p & 1)));
+                    const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (__attribute__((address_space(3))) s16x4*)LDS_PTR(Vs + (key0 + 8) * ROWB + p * 128 + ((chunk ^ sw) << 4) + 8 * (v_p & 1)));
+                    const u32x2 a = __builtin_bit_cast(u32x2, lo), c2 = __builtin_bit_cast(u32x2, up);
+                    const u32x4 w = {a[0], a[1], c2[0], c2[1]};
+                    vf[p] = __builtin_bit_cast(bf16x8, w);
+                }
+#pragma unroll
+                for (int tt = 0; tt < 6; ++tt) {
+                    if (db == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PA[tt]], pf[PB[tt]], o0, 0, 0, 0);
+                    else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PA[tt]], pf[PB[tt]], o1, 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (!active) return;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_row < n_query) {
+        const int d = H * DH;
+        float* dst = out + ((int64_t)b * N + q_row) * d + h * DH + 4 * hi;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 a = {o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv};
+            f32x4 c = {o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv};
+            *reinterpret_cast<f32x4*>(dst + 8 * g4) = a;
+            *reinterpret_cast<f32x4*>(dst + 32 + 8 * g4) = c;
+        }
+    }
+}
+
+template <int NW>
+static float run_ring(const unsigned char* img, float* dout, int Bt, int N, int H, int iters) {
+    const int Npad = (N + 63) / 64 * 64;
+    const int nqb = (N + 32 * NW - 1) / (32 * NW);
+    constexpr int lds = 3 * 2 * 32 * ROWB;
+    auto kern = attn3r_kernel<NW>;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(kern, dim3(nqb * H * Bt), dim3(64 * NW), lds, 0, img, dout, Bt, N, Npad, H, N, nqb);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(nqb * H * Bt), dim3(64 * NW), lds, 0, img, dout, Bt, N, Npad, H, N, nqb);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipGetLastError());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / iters;
+}
+
 static void fill(std::vector<float>& v, unsigned seed, float scale) {
     uint64_t s = seed * 6364136223846793005ull + 1442695040888963407ull;
     for (auto& x : v) {
@@ -318,6 +504,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dqkv, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     if (check) {
         if (argv[1][0] == '4') run<4>(dqkv, img, dout, Bt, N, H, 1, true); else run<2>(dqkv, img, dout, Bt, N, H, 1, true);
+        if (argv[1][0] == 'r') { CK(hipMemset(dout, 0xff, (size_t)Bt * N * d * 4)); run_ring<4>(img, dout, Bt, N, H, 1); }
         std::vector<float> o((size_t)Bt * N * d);
         CK(hipMemcpy(o.data(), dout, o.size() * 4, hipMemcpyDeviceToHost));
         double max_err = 0, max_ref = 0;
@@ -357,6 +544,9 @@ int main(int argc, char** argv) {
         const float t = run<2>(dqkv, img, dout, Bt, N, H, 100, false);
         const float tp = run<2>(dqkv, img, dout, Bt, N, H, 100, true);
         const float t4 = run<4>(dqkv, img, dout, Bt, N, H, 100, false);
+        const float tr = run_ring<4>(img, dout, Bt, N, H, 100);
+        const float tr2 = run_ring<2>(img, dout, Bt, N, H, 100);
+        printf("ring(KT=32, 3 stages): NW=4 %7.1f us %6.1f TF-eq | NW=2 %7.1f us %6.1f TF-eq\n", tr * 1e3, fl / tr / 1e9, tr2 * 1e3, fl / tr2 / 1e9);
         printf("attn3 B=%d N=%d H=%d: NW=2 %7.1f us  %6.1f TF-eq   (with prep kernel %7.1f us) | NW=4 %7.1f us %6.1f TF-eq\n", Bt, N, H, t * 1e3,
                fl / t / 1e9, tp * 1e3, t4 * 1e3, fl / t4 / 1e9);
     }
