@@ -894,3 +894,30 @@ def test_vae_encode_bf16x3(dev):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         assert rel_err(vae.encode(G(g["x_crop"], dev)).cpu(), g["z_crop"]) < TOL
+
+
+def test_full_step_v2a_bf16x3(dev, full):
+    """Video -> audio direction on the bf16x3 path: 37 target + 384 prompt tokens at 256x256 (the prompt is the long part, the
+    target rows come first, the audio head stays on fp32 MFMA), B=10 -> 8,420 rows; oracle on the first two samples."""
+    import multimodal_diffusion_amd as A
+    ws, _ = full
+    core, head, av, aa = _full_modules(dev, ws)
+    g = torch.Generator().manual_seed(78)
+    B = 10
+    z_v = torch.randn(B, 8, 12, 32, 32, generator=g)
+    z_a = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn = torch.tensor([982, 19] * 5)
+    tp = torch.tensor([966, -1] * 5)
+    ref = R.denoise_step_v2a(z_a[:2], z_v[:2], tn[:2], tp[:2], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"], core=ws["core"],
+                             head=ws["head"], n_layers=8, n_heads=8, guidance=3.0)
+    eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="audio",
+                          latent_shape=tuple(z_a.shape), prompt_tokens=384, alpha_bar=abar, guidance=3.0, matmul="bf16x3")
+    eng.set_prompt(z_v.to(dev))
+    out = eng.step(z_a.to(dev), tn.to(dev), tp.to(dev))
+    assert rel_err(out[:2].cpu(), ref) < TOL
+    f32 = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=_full_modules(dev, ws)[0], head=head, tstep_dim=256, target="audio",
+                          latent_shape=tuple(z_a.shape), prompt_tokens=384, alpha_bar=abar, guidance=3.0, matmul="f32")
+    f32.set_prompt(z_v.to(dev))
+    o32 = f32.step(z_a.to(dev), tn.to(dev), tp.to(dev))
+    assert not torch.equal(out, o32) and rel_err(out.cpu(), o32.cpu()) < 2e-5
