@@ -79,7 +79,8 @@ struct Carver {
 };
 
 // ---------------------------------------------------------------- MMDiT.forward
-// bf16x3 matmul path: taken when every block carries split3 weight images and the batch fills the 256x256-tile kernel
+// bf16x3 matmul path (gemm_bf16x3.hip, attn_bf16x3.hip): taken when every block carries split3 weight images and the batch has
+// enough rows for the 256-row tiles
 constexpr int64_t kSplitMinRows = 6144;    // 128x128 geometry at B=32 (8,512 rows) gains 1.34x; 64x64 (3,904 rows) does not fill the tiles
 static int64_t split_min_rows() {      // AVD_S3_MIN_ROWS: measurement aid
     static const int64_t v = [] { const char* e = getenv("AVD_S3_MIN_ROWS"); return e ? (int64_t)atoll(e) : kSplitMinRows; }();
