@@ -22,7 +22,7 @@
 //   gemm_bf16x3_b_kernel  256x128, 4 waves, two blocks per CU, two 36 KiB stages, fragments one K-tile ahead in registers —
 //                         for the heavy epilogues (split3 / qkv3 outputs) and for batches that do not fill 256-row tiles.
 // The main loop is MFMA-paced (3,180 cycles per K-step against 3,072 of pure MFMA issue); what caps the rate near 190-200
-// fp32-equivalent TFLOP/s is power: the chip holds ~1.7 GHz under this load.
+// fp32-equivalent TFLOP/s is power: the in-kernel clock is 2.07 GHz with every CU busy, 2.25 GHz with 212 of 256.
 #include "avd_common.h"
 
 #include <stdlib.h>

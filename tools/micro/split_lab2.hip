@@ -185,6 +185,8 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 1) void sgemm2_kernel(S
     }
     int cur = 0, nxt = NST - 1;
     unsigned long long ph[5] = {0, 0, 0, 0, 0};
+    unsigned long long c0 = 0, r0 = 0;
+    if (MODE == 6) { c0 = __builtin_amdgcn_s_memtime(); r0 = __builtin_amdgcn_s_memrealtime(); }
     for (int kt = 0; kt < nk; ++kt) {
         unsigned long long tA = 0, tB = 0, tC = 0, tD = 0;
         if (MODE == 6) tA = __builtin_amdgcn_s_memtime();
@@ -248,9 +250,14 @@ __global__ __launch_bounds__((BM / WM) * (BN / WN) * 64, 1) void sgemm2_kernel(S
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         __syncthreads();
         ph[4] = __builtin_amdgcn_s_memtime() - t0;
+        const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (lane == 0 && g.dbg) {
 #pragma unroll
             for (int i = 0; i < 5; ++i) g.dbg[((int64_t)blockIdx.x * NW + wave) * 5 + i] = ph[i];
+            if (wave == 0) {       // main-loop clock of this block: shader cycles per 100 MHz tick
+                g.dbg[(int64_t)gridDim.x * NW * 5 + blockIdx.x * 2] = c1 - c0;
+                g.dbg[(int64_t)gridDim.x * NW * 5 + blockIdx.x * 2 + 1] = r1 - r0;
+            }
         }
     } else
     __syncthreads();
@@ -611,10 +618,10 @@ int main(int argc, char** argv) {
             RUN("PF6", (run_gemm<256, 256, 128, 64, 3, 6, 5>(a, it, 16)));
             {
                 unsigned long long* dbg; const int nblk = 1024;
-                CK(hipMalloc(&dbg, (size_t)nblk * 8 * 5 * 8)); CK(hipMemset(dbg, 0, (size_t)nblk * 8 * 5 * 8));
+                CK(hipMalloc(&dbg, (size_t)nblk * 8 * 6 * 8)); CK(hipMemset(dbg, 0, (size_t)nblk * 8 * 6 * 8));
                 SArgs ad = a; ad.dbg = dbg;
-                run_gemm<256, 256, 128, 64, 3, 6, 6>(ad, 3, 16);
-                std::vector<unsigned long long> h((size_t)nblk * 8 * 5);
+                run_gemm<256, 256, 128, 64, 3, 6, 6>(ad, 200, 16);     // ~50 ms of back-to-back launches: the clock has settled
+                std::vector<unsigned long long> h((size_t)nblk * 8 * 6);
                 CK(hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost));
                 double sum[5] = {0, 0, 0, 0, 0}; int cnt = 0;
                 for (int b = 0; b < nblk; ++b) for (int w = 0; w < 8; ++w) {
@@ -626,6 +633,20 @@ int main(int argc, char** argv) {
                 const double steps = s.K / 16.0;
                 printf("\n    phases (memtime ticks per K-step, mean over %d waves): wait_vm %.0f | barrier %.0f | dma-issue+frag-reads %.0f | mfma %.0f | final-sync %.0f (per block)",
                        cnt, sum[0] / cnt / steps, sum[1] / cnt / steps, sum[2] / cnt / steps, sum[3] / cnt / steps, sum[4] / cnt);
+                {
+                    // grid size used by run_gemm with super = 16 (same formula)
+                    const int nbn_ = s.N / 256, nbm_ = (int)((M + 255) / 256);
+                    int sn_ = 8; while (nbn_ % sn_) sn_ >>= 1;
+                    const int sm_ = 16 / sn_;
+                    const int grid = (nbm_ + sm_ - 1) / sm_ * sm_ * nbn_;
+                    double cs = 0, rs = 0; int nb = 0;
+                    for (int b = 0; b < grid && b < nblk; ++b) {
+                        const unsigned long long c = h[(size_t)grid * 8 * 5 + b * 2], r = h[(size_t)grid * 8 * 5 + b * 2 + 1];
+                        if (r == 0) continue;
+                        cs += (double)c; rs += (double)r; ++nb;
+                    }
+                    if (nb) printf("\n    in-kernel clock over the main loop (s_memtime / s_memrealtime x 100 MHz, %d blocks): %.2f GHz", nb, cs / rs * 0.1);
+                }
                 CK(hipFree(dbg));
             }
             printf("\n    256x128:");
