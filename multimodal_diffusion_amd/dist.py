@@ -61,6 +61,23 @@ def local_conditioning(cond_global: torch.Tensor, rank: int, world: int) -> torc
     return cond_global[lo:hi].contiguous()
 
 
+def gather_batch(local: torch.Tensor, global_batch: int) -> torch.Tensor:
+    """Optional epilogue of the sharded loop: every rank returns the finished latents of the WHOLE batch,
+    [global_batch, ...], shards in rank order (one all-gather; shard sizes may differ by one sample)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world, rank = dist.get_world_size(), dist.get_rank()
+    sizes = [shard_range(global_batch, r, world) for r in range(world)]
+    if local.shape[0] != sizes[rank][1] - sizes[rank][0]:
+        raise ValueError("local shard does not match shard_range")
+    pad = max(hi - lo for lo, hi in sizes)
+    buf = local.new_zeros((pad,) + tuple(local.shape[1:]))
+    buf[:local.shape[0]] = local
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf.contiguous())
+    return torch.cat([p[:hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
+
+
 def max_over_ranks(value: float, device: torch.device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value

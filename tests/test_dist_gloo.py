@@ -32,6 +32,10 @@ def _worker(rank, world, port, out):
     expect = torch.randn(gshape, generator=torch.Generator().manual_seed(2))
     lo, hi = D.shard_range(B * world, rank, world)
     ok = torch.equal(full, expect) and torch.equal(mine, expect[lo:hi]) and mine.shape[0] == B
+    # ragged global batch (7 samples over 2 ranks): every rank gets the whole batch back in rank order
+    glo, ghi = D.shard_range(7, rank, world)
+    whole = torch.arange(7 * 5, dtype=torch.float32).view(7, 5)
+    ok = ok and torch.equal(D.gather_batch(whole[glo:ghi].clone(), 7), whole)
     slow = D.max_over_ranks(1.0 + rank, torch.device("cpu"))
     D.barrier()
     out.put((rank, bool(ok), slow))
