@@ -160,10 +160,15 @@ class DenoiseEngine:
         self.N = e.Nt + e.Np
         self.alpha_bar = alpha_bar.to(self.device, torch.float32).contiguous()
 
+        # matrix-pipe mode of this engine ("f32" | "bf16x3", default: the core's own setting); the core module keeps its setting
+        prev = core.matmul
         if matmul is not None:
-            core.matmul = matmul          # "f32" | "bf16x3" (mmdt.MMDiT.matmul)
+            core.matmul = matmul
         self.matmul = core.matmul
-        self._core_tab, self._keep_core = core.weight_table()
+        try:
+            self._core_tab, self._keep_core = core.weight_table()
+        finally:
+            core.matmul = prev
         self._head_tab, self._keep_head = head.weight_table(target)
         self._aw = L.dev_f32(self.adapt_t.proj.weight.detach(), "adapter weight")
         self._ab = L.dev_f32(self.adapt_t.proj.bias.detach(), "adapter bias")
