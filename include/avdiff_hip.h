@@ -44,6 +44,10 @@ int         avd_abi_version(void);
 const char* avd_last_error(void);
 /* gfx arch name of device 0 as seen by the library ("gfx950"); diagnostic only. */
 int         avd_device_arch(char* buf, int buflen);
+/* Measurement / test hooks, process-wide, never needed for correct results: "gemm_tile" (-1 auto, 0 = 128x128, 1 = 128x64,
+ * 2 = 64x64 LDS-DMA tile of avd_gemm_bias_act_f32), "s3_min_rows" (smallest 2B*N that takes the bf16x3 kernels),
+ * "no_fold" (1 = keep RMSNorm as separate kernels in avd_core_forward_f32). */
+int         avd_tune_set(const char* key, int64_t value);
 
 /* ---- a6: RMSNorm — avdiff/models/mmdt.py:33-42 (RMSNorm.forward)
  * y = scale * x / (||x||_2 / sqrt(d) + eps), eps OUTSIDE the sqrt. x,y: [rows,d]. */
@@ -59,6 +63,16 @@ int avd_rmsnorm_f32(const float* x, const float* scale, float* y, int64_t rows, 
 int avd_gemm_bias_act_f32(const float* A, int64_t lda, const float* W, const float* bias,
                           const float* residual, int64_t ldr, float* C, int64_t ldc,
                           int64_t M, int N, int K, int act, avd_stream_t stream);
+
+/* The same Linear with the neighbouring RMSNorms (mmdt.py:39-42) folded in, as avd_core_forward_f32 uses it (A [M,K], C [M,N]
+ * contiguous; K % 32 == 0, N % 128 == 0):
+ *   ss_in  != NULL: A is the UN-normalised stream and W carries the norm's scale (W * scale[None,:]); every output row is
+ *                   multiplied by 1 / (sqrt(sum_j ss_in[row][j]) / sqrt(K) + eps) before the bias.  ss_in: [M, ss_in_cols].
+ *   ss_out != NULL: the epilogue also writes the sum of squares of each final output row per 32-column chunk, [M, N/32]
+ *                   (fixed summation order: deterministic) — the table the next folded Linear reads as ss_in. */
+int avd_gemm_rmsfold_f32(const float* A, const float* W, const float* bias, const float* residual, float* C, int64_t M,
+                         int N, int K, int act, const float* ss_in, int ss_in_cols, float eps, float* ss_out,
+                         avd_stream_t stream);
 
 /* ---- a6: multi-head self-attention core — nn.MultiheadAttention(batch_first=True) at
  * avdiff/models/mmdt.py:51-61 between in_proj and out_proj: out = softmax(q k^T * scale) v per head,

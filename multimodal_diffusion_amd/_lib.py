@@ -91,6 +91,8 @@ SIGNATURES = {
     "avd_device_arch": (_I, [C.c_char_p, _I]),
     "avd_rmsnorm_f32": (_I, [_P, _P, _P, _L, _I, _F, _P]),
     "avd_gemm_bias_act_f32": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _L, _I, _I, _I, _P]),
+    "avd_gemm_rmsfold_f32": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _I, _F, _P, _P]),
+    "avd_tune_set": (_I, [C.c_char_p, _L]),
     "avd_attn_fwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "avd_layernorm_act_f32": (_I, [_P, _P, _P, _P, _L, _I, _F, _I, _P]),
     "avd_timestep_embedding_f32": (_I, [_P, _P, _P, _I, _I, _F, _P]),

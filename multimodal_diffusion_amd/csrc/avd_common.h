@@ -143,6 +143,7 @@ struct ProfScope {
 int gemm_f32(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm,
              float* C, RowMap cm, int64_t M, int N, int K, int act, hipStream_t st);
 
+extern int g_gemm_force_tile;     // -1 = automatic tile choice; 0 / 1 / 2 = 128x128 / 128x64 / 64x64 (avd_tune_set "gemm_tile")
 bool gemm_f32_fold_supported(int N, int K);
 int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm, float* C, RowMap cm,
                   int64_t M, int N, int K, int act, const float* ss_in, int ss_in_cols, float sqrt_d, float eps, float* ss_out,

@@ -82,10 +82,9 @@ struct Carver {
 // bf16x3 matmul path (gemm_bf16x3.hip, attn_bf16x3.hip): taken when every block carries split3 weight images and the batch has
 // enough rows for the 256-row tiles
 constexpr int64_t kSplitMinRows = 6144;    // 128x128 geometry at B=32 (8,512 rows) gains 1.34x; 64x64 (3,904 rows) does not fill the tiles
-static int64_t split_min_rows() {      // AVD_S3_MIN_ROWS: measurement aid
-    static const int64_t v = [] { const char* e = getenv("AVD_S3_MIN_ROWS"); return e ? (int64_t)atoll(e) : kSplitMinRows; }();
-    return v;
-}
+static int64_t g_s3_min_rows = [] { const char* e = getenv("AVD_S3_MIN_ROWS"); return e ? (int64_t)atoll(e) : kSplitMinRows; }();
+static bool g_no_fold = getenv("AVD_NO_FOLD") != nullptr;
+static int64_t split_min_rows() { return g_s3_min_rows; }      // avd_tune_set "s3_min_rows": measurement aid
 static bool core_use_split(const avd_core_weights* w, int64_t M) {
     if (M < split_min_rows()) return false;
     if (!gemm_bf16x3_supported(M, 3 * w->d, w->d) || !gemm_bf16x3_supported(M, w->d, w->d) ||
@@ -100,8 +99,7 @@ static bool core_use_split(const avd_core_weights* w, int64_t M) {
 
 // fp32 path with RMSNorm folded into the neighbouring GEMM epilogues: needs the scale-carrying weights and LDS-DMA-able shapes
 static bool core_use_fold(const avd_core_weights* w) {
-    static const bool off = getenv("AVD_NO_FOLD") != nullptr;      // measurement aid
-    if (off) return false;
+    if (g_no_fold) return false;                                   // avd_tune_set "no_fold": measurement aid
     if (!gemm_f32_fold_supported(3 * w->d, w->d) || !gemm_f32_fold_supported(w->d, w->d) ||
         !gemm_f32_fold_supported(w->mlp_hidden, w->d) || !gemm_f32_fold_supported(w->d, w->mlp_hidden))
         return false;
@@ -343,6 +341,14 @@ using namespace avd;
 
 extern "C" int avd_abi_version(void) { return AVD_ABI_VERSION; }
 extern "C" const char* avd_last_error(void) { return g_err; }
+
+extern "C" int avd_tune_set(const char* key, int64_t value) {
+    AVD_REQUIRE(key, AVD_EINVAL, "tune_set: null key");
+    if (!strcmp(key, "gemm_tile")) { g_gemm_force_tile = (int)value; return AVD_OK; }
+    if (!strcmp(key, "s3_min_rows")) { g_s3_min_rows = value; return AVD_OK; }
+    if (!strcmp(key, "no_fold")) { g_no_fold = value != 0; return AVD_OK; }
+    return set_error(AVD_EINVAL, "tune_set: unknown key '%s'", key);
+}
 
 extern "C" int avd_device_arch(char* buf, int buflen) {
     AVD_REQUIRE(buf && buflen > 0, AVD_EINVAL, "device_arch: bad buffer");

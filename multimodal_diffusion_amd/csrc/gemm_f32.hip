@@ -26,6 +26,7 @@
 #include "avd_common.h"
 
 #include <stdlib.h>
+#include <type_traits>
 
 namespace avd {
 
@@ -141,31 +142,74 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
         b_sw[j] = (r >> 1) & 7;
     }
 
-    for (int kt = 0; kt < nk; ++kt) {
+    // Main loop schedule (per wave, per K tile of 32 = four k-groups of 8):
+    //  * fragment reads run one k-group ahead of the MFMAs that consume them, across the K-tile boundary too, so a wave never
+    //    waits on an LDS read it has just issued: one wave alone keeps its SIMD's matrix pipe issuing back to back and the
+    //    co-resident block only has to cover the barrier.  hipcc waits lgkmcnt(0) (never a counted wait) while an LDS-DMA is
+    //    in flight, so inside a k-group the order is: first MFMA step on the current registers (its wait finds the reads
+    //    issued a whole group ago), THEN the reads for the next group, then the remaining steps.
+    //  * the next stage's DMA pieces are issued one at a time behind single MFMAs (an LDS-DMA costs the wave ~60 issue cycles,
+    //    one 64-cycle MFMA hides it) instead of as a block at the top of the tile.
+    //  * sched_barrier(0) pins all of this: left alone, hipcc sinks every read down to its consumer and waits on it there.
+    // Two named fragment register sets, static indexing throughout; the last K tile is a second instantiation without DMA.
+    constexpr int MPS = TM * TN;                    // MFMAs per k step
+    constexpr int NPIECE = A_PIECES + B_PIECES;     // DMA pieces per wave per stage
+    static_assert(NPIECE <= 11 * MPS, "DMA pieces must all be issued before the tile's last k-group");
+#define AVD_SB() __builtin_amdgcn_sched_barrier(0)
+    auto ld_frag = [&](const float* as, const float* bs, int kk, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + a_row[i] + (((2 * kk + hi) ^ a_sw[i]) << 2));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + b_row[j] + (((2 * kk + hi) ^ b_sw[j]) << 2));
+    };
+    f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
+    auto ktile = [&](int kt, auto dma_tag) {
+        constexpr bool DMA = decltype(dma_tag)::value;
         const int cur = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
         const float* as = smem + cur * STAGE;
         const float* bs = as + BM * BK;
+        float* nas = smem + (cur ^ 1) * STAGE;
+        float* nbs = nas + BM * BK;
+        const int k1 = (kt + 1) * BK;
+        // steps [s0, s1) of k-group g on the registers (af, bf); MFMA number m of the tile is followed by DMA piece m - MPS
+        auto mma = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], int g, int s0, int s1) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            f32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(as + a_row[i] + (((2 * kk + hi) ^ a_sw[i]) << 2));
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(bs + b_row[j] + (((2 * kk + hi) ^ b_sw[j]) << 2));
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
+            for (int s = s0; s < s1; ++s)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int j = 0; j < TN; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+                        const int pc = (g * 4 + s) * MPS + i * TN + j - MPS;
+                        if (DMA && pc >= 0 && pc < NPIECE) {
+                            AVD_SB();
+                            if (pc < A_PIECES)
+                                __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(a_src[pc < A_PIECES ? pc : 0] + k1),
+                                                                 AVD_LDS_PTR(nas + (wave + 4 * pc) * 8 * BK), 16, 0, 0);
+                            else
+                                __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(b_src[pc >= A_PIECES ? pc - A_PIECES : 0] + k1),
+                                                                 AVD_LDS_PTR(nbs + (wave + 4 * (pc - A_PIECES)) * 8 * BK), 16, 0, 0);
+                            AVD_SB();
+                        }
+                    }
+        };
+        AVD_SB(); mma(af0, bf0, 0, 0, 1); AVD_SB(); ld_frag(as, bs, 1, af1, bf1); AVD_SB(); mma(af0, bf0, 0, 1, 4);
+        AVD_SB(); mma(af1, bf1, 1, 0, 1); AVD_SB(); ld_frag(as, bs, 2, af0, bf0); AVD_SB(); mma(af1, bf1, 1, 1, 4);
+        AVD_SB(); mma(af0, bf0, 2, 0, 1); AVD_SB(); ld_frag(as, bs, 3, af1, bf1); AVD_SB(); mma(af0, bf0, 2, 1, 4);
+        AVD_SB(); mma(af1, bf1, 3, 0, 2); AVD_SB();
+        if constexpr (DMA) {
+            // every wave holds its last fragments of this stage in registers: wait for the next stage's DMA, swap
+            __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+            __builtin_amdgcn_s_barrier();
+            ld_frag(nas, nbs, 0, af0, bf0);
         }
-        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the next stage has landed
-        __syncthreads();
-    }
+        AVD_SB(); mma(af1, bf1, 3, 2, 4); AVD_SB();
+    };
+    ld_frag(smem, smem + BM * BK, 0, af0, bf0);
+    for (int kt = 0; kt + 1 < nk; ++kt) ktile(kt, std::true_type{});
+    ktile(nk - 1, std::false_type{});
+#undef AVD_SB
+    __syncthreads();    // the slabs below overlay the stages: every wave must be past its last fragment read
 
     // ---- epilogue: park the wave's WM x WN tile in its own LDS slab, stream it out as 16-byte row segments ----
     constexpr int CLD = WN + 4;
@@ -440,6 +484,8 @@ static int launch_reg_k(const GemmArgs& a, hipStream_t st) {
     return (a.K % GEMM_BK) ? launch_reg<BM, BN, WM, WN, true>(a, st) : launch_reg<BM, BN, WM, WN, false>(a, st);
 }
 
+int g_gemm_force_tile = getenv("AVD_GEMM_TILE") ? atoi(getenv("AVD_GEMM_TILE")) : -1;
+
 bool gemm_f32_fold_supported(int N, int K) { return K % GEMM_BK == 0 && N % 128 == 0; }
 
 int gemm_f32(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm,
@@ -461,7 +507,7 @@ int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, 
     if (M == 0) return AVD_OK;
     GemmArgs g{A, am, W, bias, R, rm, C, cm, M, N, K, act, 0, ss_in, ss_in_cols, sqrt_d, eps, ss_out};
 
-    static const int force = getenv("AVD_GEMM_TILE") ? atoi(getenv("AVD_GEMM_TILE")) : -1;   // tuning/debug only
+    const int force = g_gemm_force_tile;      // tuning / test hook (avd_tune_set "gemm_tile"; env AVD_GEMM_TILE)
     const bool dma_ok = K % GEMM_BK == 0 && N % 4 == 0 && N > 32 && cm.seg <= 0 && cm.ld % 4 == 0 && aligned16(C) &&
                         (R == nullptr || (rm.seg <= 0 && rm.ld % 4 == 0 && aligned16(R))) &&
                         (bias == nullptr || aligned16(bias)) && (act == AVD_ACT_NONE || act == AVD_ACT_GELU) &&
@@ -487,6 +533,15 @@ int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, 
 }
 
 }  // namespace avd
+
+extern "C" int avd_gemm_rmsfold_f32(const float* A, const float* W, const float* bias, const float* residual, float* C, int64_t M,
+                                    int N, int K, int act, const float* ss_in, int ss_in_cols, float eps, float* ss_out,
+                                    avd_stream_t stream) {
+    using namespace avd;
+    const RowMap ra{K, 0, 0}, rc{N, 0, 0};
+    return gemm_f32_fold(A, ra, W, bias, residual, rc, C, rc, M, N, K, act, ss_in, ss_in_cols, (float)sqrt((double)K), eps, ss_out,
+                         static_cast<hipStream_t>(stream));
+}
 
 extern "C" int avd_gemm_bias_act_f32(const float* A, int64_t lda, const float* W, const float* bias,
                                      const float* residual, int64_t ldr, float* C, int64_t ldc,

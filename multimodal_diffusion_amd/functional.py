@@ -50,6 +50,22 @@ def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor] = None, act: int = 
     return out
 
 
+def linear_rmsfold(x: Tensor, weight_n: Tensor, bias: Optional[Tensor] = None, act: int = L.ACT_NONE,
+                   residual: Optional[Tensor] = None, ss_in: Optional[Tensor] = None, eps: float = 1e-6, want_ss: bool = False):
+    """The folded-RMSNorm Linear of the MMDiT composite (avd_gemm_rmsfold_f32).  ``weight_n`` = weight * norm_scale[None, :]
+    when ``ss_in`` (the per-row sums of squares of x, [M, cols]) is given.  Returns (y, ss_out or None)."""
+    x = L.dev_f32(x, "x")
+    weight_n = L.dev_f32(weight_n, "weight")
+    n, k = weight_n.shape
+    m = x.numel() // k
+    y = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float32)
+    ss_out = torch.empty(m, n // 32, device=x.device, dtype=torch.float32) if want_ss else None
+    cols = 0 if ss_in is None else ss_in.shape[-1]
+    L.check(L.lib().avd_gemm_rmsfold_f32(x.data_ptr(), weight_n.data_ptr(), L.ptr(bias), L.ptr(residual), y.data_ptr(), m, n, k,
+                                         act, L.ptr(ss_in), cols, eps, L.ptr(ss_out), _st(x)))
+    return y, ss_out
+
+
 def attention(qkv: Tensor, n_heads: int, n_query: Optional[int] = None) -> Tensor:
     """softmax(q k^T / sqrt(Dh)) v over packed qkv [B,N,3d] -> [B,N,d] (head_dim must be 64)."""
     qkv = L.dev_f32(qkv, "qkv")
@@ -164,15 +180,17 @@ def ddim_step(x_t: Tensor, t_now: Tensor, t_prev: Tensor, eps_hat: Tensor, alpha
 
 
 # ---- "bf16x3": fp32-accurate Linear on the bf16 matrix pipe (csrc/gemm_bf16x3.hip) ----
-def split3(x: Tensor) -> Tensor:
-    """fp32 [rows, K] -> its split3 image (uint8; three bf16 planes, tiled).  K must be a multiple of 16."""
+def split3(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """fp32 [rows, K] -> its split3 image (uint8; three bf16 planes, tiled).  K must be a multiple of 16.
+    ``out``: an existing image of the same size to overwrite (keeps its address)."""
     x = L.dev_f32(x, "x")
     k = x.shape[-1]
     rows = x.numel() // k
     nbytes = L.lib().avd_split3_bytes(rows, k)
     if nbytes < 0:
         raise L.AvdError(f"split3: K={k} must be a multiple of 16")
-    out = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    if out is None or out.numel() != nbytes or out.device != x.device:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     L.check(L.lib().avd_split3_f32(x.data_ptr(), out.data_ptr(), rows, k, _st(x)))
     return out
 

@@ -158,7 +158,11 @@ class MMDiT(nn.Module):
         key = (w.data_ptr(), w._version, scale.data_ptr(), scale._version)
         hit = self._folded.get(name)
         if hit is None or hit[0] != key:
-            hit = (key, (w.detach() * scale.detach()[None, :]).contiguous())
+            new = (w.detach() * scale.detach()[None, :]).contiguous()
+            if hit is not None and hit[1].shape == new.shape and hit[1].device == new.device:
+                hit[1].copy_(new)          # refresh in place: pointer tables (and captured graphs) that hold it stay valid
+                new = hit[1]
+            hit = (key, new)
             self._folded[name] = hit
         return hit[1]
 
@@ -167,7 +171,8 @@ class MMDiT(nn.Module):
         hit = self._split3.get(name)
         if hit is None or hit[0] != key:
             from . import functional as Fn
-            hit = (key, Fn.split3(p.detach()))
+            old = hit[1] if hit is not None and hit[0][2] == key[2] and hit[1].device == p.device else None
+            hit = (key, Fn.split3(p.detach(), out=old))      # same storage when the shape is unchanged
             self._split3[name] = hit
         return hit[1]
 

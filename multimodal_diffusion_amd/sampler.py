@@ -161,35 +161,69 @@ class DenoiseEngine:
         self.alpha_bar = alpha_bar.to(self.device, torch.float32).contiguous()
 
         # matrix-pipe mode of this engine ("f32" | "bf16x3", default: the core's own setting); the core module keeps its setting
+        self.matmul = core.matmul if matmul is None else matmul
+        self._split_streams = bool(split_streams)
+        self._captured = False
+        self.workspace: Optional[torch.Tensor] = None
+        self._bind_weights()
+        self.Xp: Optional[torch.Tensor] = None
+        self._prompt_latent: Optional[torch.Tensor] = None
+
+    # ---- pointer tables.  They hold derived copies (norm-folded / split3 weights), so they are re-derived whenever a
+    # parameter's (address, version) changes: load_state_dict, EMA copy_to, an optimiser step or .to(device) after the
+    # engine was built all show up here, at the next step, instead of mixing old and new weights silently.
+    def _weights_key(self):
+        mods = (self.core, self.head, self.adapt_t, self.adapt_p)
+        return tuple((p.data_ptr(), p._version) for m in mods for p in m.parameters())
+
+    def _bind_weights(self) -> None:
+        core, head = self.core, self.head
         prev = core.matmul
-        if matmul is not None:
-            core.matmul = matmul
-        self.matmul = core.matmul
+        core.matmul = self.matmul
         try:
             self._core_tab, self._keep_core = core.weight_table()
         finally:
             core.matmul = prev
-        self._head_tab, self._keep_head = head.weight_table(target)
+        self._head_tab, self._keep_head = head.weight_table(self.target)
         self._aw = L.dev_f32(self.adapt_t.proj.weight.detach(), "adapter weight")
         self._ab = L.dev_f32(self.adapt_t.proj.bias.detach(), "adapter bias")
+        if self._aw.device != self.device:
+            raise L.AvdError("engine modules moved to another device after the engine was built")
         s = L.StepDesc()
-        s.embed = e
+        s.embed = self.embed
         s.core = C.pointer(self._core_tab)
         s.head = C.pointer(self._head_tab)
         s.adapt_w, s.adapt_b = self._aw.data_ptr(), self._ab.data_ptr()
         s.alpha_bar, s.T_train = self.alpha_bar.data_ptr(), self.alpha_bar.numel()
         s.guidance, s.eta = self.guidance, self.eta
-        s.split_streams = 1 if split_streams else 0
+        s.split_streams = 1 if self._split_streams else 0
         self.desc = s
         need = L.lib().avd_step_workspace_bytes(C.byref(s))
         if need < 0:
             raise ValueError(L.lib().avd_last_error().decode())
-        self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
-        self.Xp: Optional[torch.Tensor] = None
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._ptrs = self._table_ptrs()
+        self._wkey = self._weights_key()
+
+    def _table_ptrs(self):
+        return tuple(t.data_ptr() for t in self._keep_core[1]) + tuple(t.data_ptr() for t in self._keep_head[1]) + \
+            (self._aw.data_ptr(), self._ab.data_ptr())
+
+    def _sync_weights(self) -> None:
+        if self._weights_key() == self._wkey:
+            return
+        old = self._ptrs
+        self._bind_weights()             # derived copies are refreshed in place where shapes allow
+        if self._captured and self._ptrs != old:
+            raise L.AvdError("a parameter was re-allocated after a HIP graph of this engine was captured; capture again")
+        if self._prompt_latent is not None:
+            self.set_prompt(self._prompt_latent)     # the cached prompt rows depend on the prompt adapter
 
     # ---- prompt rows: adapter(tokens(prompt latent)) | temb(0); constant over the trajectory ----
     def set_prompt(self, prompt_latent: torch.Tensor) -> torch.Tensor:
         z = L.dev_f32(prompt_latent, "prompt latent")
+        self._prompt_latent = z
         B = self.embed.B
         if z.shape[0] != B:
             raise ValueError("prompt batch size must match the engine's")
@@ -225,6 +259,8 @@ class DenoiseEngine:
         if tuple(z.shape) != self.latent_shape:
             raise ValueError(f"latent shape {tuple(z.shape)} != engine shape {self.latent_shape}")
         tn, tp = L.dev_i64(t_now, self.device), L.dev_i64(t_prev, self.device)
+        if not torch.cuda.is_current_stream_capturing():
+            self._sync_weights()
         if self.eta > 0 and noise is None:
             noise = torch.randn_like(z)
         out = torch.empty_like(z) if out is None else out
@@ -264,10 +300,12 @@ class DenoiseEngine:
         """Capture two steps (za -> zb -> za) into one HIP graph; replaying it advances the trajectory by two."""
         if self.eta > 0:
             raise NotImplementedError("graph replay with eta > 0 would replay the same noise")
+        self._sync_weights()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self.advance(za, zb)
             self.advance(zb, za)
+        self._captured = True
         return g
 
     def run(self, z: torch.Tensor, sched: torch.Tensor, graph: bool = False) -> torch.Tensor:

@@ -921,3 +921,192 @@ def test_full_step_v2a_bf16x3(dev, full):
     f32.set_prompt(z_v.to(dev))
     o32 = f32.step(z_a.to(dev), tn.to(dev), tp.to(dev))
     assert not torch.equal(out, o32) and rel_err(out.cpu(), o32.cpu()) < 2e-5
+
+
+# ------------------------------------------------------------------------------------------------- round-2 coverage
+def _tune(key, value):
+    from multimodal_diffusion_amd import _lib as L
+    L.check(L.lib().avd_tune_set(key.encode(), value))
+
+
+def _sample_rows(M, g):
+    idx = torch.cat([torch.arange(0, min(M, 192)), torch.arange(max(0, M - 192), M),
+                     torch.randint(0, M, (384,), generator=g)]).unique()
+    return idx
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("M,N,K", [(16385, 512, 512), (26944, 1536, 512), (20011, 2048, 512), (16500, 512, 2048)])
+@pytest.mark.parametrize("mode", ["plain", "gelu", "res"])
+def test_gemm_dma_templates_direct(dev, tile, M, N, K, mode):
+    """Each LDS-DMA tile template (0: 128x128, 1: 128x64, 2: 64x64) forced in turn at full-batch row counts with ragged M,
+    every epilogue, against fp64 on a row sample that includes the first and the ragged last row blocks."""
+    from multimodal_diffusion_amd import functional as Fn, _lib as L
+    g = torch.Generator().manual_seed(M + N + K + tile)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    idx = _sample_rows(M, g)
+    ref = R.linear(x[idx].double(), w.double(), b.double())
+    if mode == "gelu":
+        ref = R.gelu_erf(ref)
+    if mode == "res":
+        ref = ref + r[idx].double()
+    _tune("gemm_tile", tile)
+    try:
+        y = Fn.linear(x.to(dev), w.to(dev), b.to(dev), act=L.ACT_GELU if mode == "gelu" else L.ACT_NONE,
+                      residual=r.to(dev) if mode == "res" else None)
+    finally:
+        _tune("gemm_tile", -1)
+    assert torch.isfinite(y).all()
+    assert rel_err(y.cpu()[idx], ref) < 2e-5
+
+
+@pytest.mark.parametrize("tile", [0, 1, 2])
+@pytest.mark.parametrize("M", [16385, 26944])
+def test_gemm_rmsfold_epilogue_direct(dev, tile, M):
+    """The folded-RMSNorm epilogues stand-alone: a residual GEMM that emits per-row sums of squares (ss_out), then the
+    scale-carrying GEMM that consumes them (ss_in) — against RMSNorm -> Linear in fp64 (mmdt.py:39-42, 77-83)."""
+    from multimodal_diffusion_amd import functional as Fn, _lib as L
+    d, hid = 512, 2048
+    g = torch.Generator().manual_seed(M + tile)
+    a = torch.randn(M, d, generator=g)
+    x0 = torch.randn(M, d, generator=g) * torch.exp(torch.randn(M, 1, generator=g))       # rows of very different norms
+    x0[7] = 0.0                                                                           # all-zero row: eps carries it
+    w0 = torch.randn(d, d, generator=g) / math.sqrt(d)
+    b0 = torch.randn(d, generator=g) * 0.1
+    scale = 1.0 + 0.1 * torch.randn(d, generator=g)
+    w1 = torch.randn(hid, d, generator=g) / math.sqrt(d)
+    b1 = torch.randn(hid, generator=g) * 0.1
+    idx = _sample_rows(M, g)
+    _tune("gemm_tile", tile)
+    try:
+        x1, ss = Fn.linear_rmsfold(a.to(dev), w0.to(dev), b0.to(dev), residual=x0.to(dev), want_ss=True)
+        y, _ = Fn.linear_rmsfold(x1, (w1 * scale[None, :]).to(dev), b1.to(dev), act=L.ACT_GELU, ss_in=ss, eps=1e-6)
+        # the one-column table form (first block: rowss kernel)
+        ss1 = (x1 * x1).sum(-1, keepdim=True).contiguous()
+        y1, _ = Fn.linear_rmsfold(x1, (w1 * scale[None, :]).to(dev), b1.to(dev), act=L.ACT_GELU, ss_in=ss1, eps=1e-6)
+    finally:
+        _tune("gemm_tile", -1)
+    x1_ref = x0[idx].double() + R.linear(a[idx].double(), w0.double(), b0.double())
+    assert rel_err(x1.cpu()[idx], x1_ref) < 2e-5
+    chunks = x1.cpu().double().view(M, d // 32, 32).pow(2).sum(-1)
+    assert rel_err(ss.cpu(), chunks) < 1e-5
+    # reference on the device's own x1 so only the folded GEMM is under test
+    h = R.rmsnorm(x1.cpu()[idx].double(), scale.double(), 1e-6)
+    ref = R.gelu_erf(R.linear(h, w1.double(), b1.double()))
+    assert rel_err(y.cpu()[idx], ref) < 2e-5
+    assert rel_err(y1.cpu()[idx], ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,N,H", [(1, 1573, 8), (2, 1600, 2), (1, 1537, 4)])
+def test_attention_long(dev, B, N, H):
+    """BASELINE C5 geometry (512x512: 1536 + 37 = 1573 tokens, 25 key tiles) on the default fp32 kernel."""
+    from multimodal_diffusion_amd import functional as Fn
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    d = 64 * H
+    qkv = torch.randn(B, N, 3 * d, generator=g) * 1.5
+    q, k, v = (qkv.double().view(B, N, 3, H, 64)[:, :, i].transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, -1) @ v).transpose(1, 2).reshape(B, N, d)
+    assert rel_err(Fn.attention(qkv.to(dev), H).cpu(), ref) < 2e-5
+    nq = N - 37
+    part = Fn.attention(qkv.to(dev), H, n_query=nq)
+    assert rel_err(part[:, :nq].cpu(), ref[:, :nq]) < 2e-5 and torch.count_nonzero(part[:, nq:]) == 0
+
+
+def _one_step(dev, mods, ws, size, B, n_ref, matmul="f32", seed=None):
+    import multimodal_diffusion_amd as A
+    core, head, av, aa = mods
+    g = torch.Generator().manual_seed(size if seed is None else seed)
+    z_v = torch.randn(B, 8, 12, size // 8, size // 8, generator=g)
+    z_a = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn = torch.tensor(([982, 500, 16, 999] * B)[:B])
+    tp = torch.tensor(([966, 480, -1, 979] * B)[:B])
+    ref = R.denoise_step_a2v(z_v[:n_ref], z_a[:n_ref], tn[:n_ref], tp[:n_ref], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"],
+                             core=ws["core"], head=ws["head"], n_layers=8, n_heads=8, guidance=3.5)
+    eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video",
+                          latent_shape=tuple(z_v.shape), prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=matmul)
+    eng.set_prompt(z_a.to(dev))
+    return eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)).cpu(), ref
+
+
+def test_full_step_f32_512(dev, full):
+    """BASELINE C5 geometry on the DEFAULT fp32 path: 512x512, N = 1573, B = 4 (2B*N = 12,584 rows: the 128-row tiles),
+    sample 0 against the CPU oracle."""
+    ws, mods = full
+    out, ref = _one_step(dev, mods, ws, 512, 4, 1)
+    assert rel_err(out[:1], ref) < TOL
+
+
+def test_full_step_c2_batch32(dev, full):
+    """BASELINE C2 shape at its real batch: 64x64, N = 61, B = 32 (3,904 rows -> the 64x64 tiles), fp32; first two samples."""
+    ws, mods = full
+    out, ref = _one_step(dev, mods, ws, 64, 32, 2)
+    assert rel_err(out[:2], ref) < TOL
+
+
+def test_vae_decode_256_vs_oracle(dev):
+    """Row a9 at the headline geometry: one sample [1,8,12,32,32] -> [1,3,48,256,256] against the fp32 CPU oracle."""
+    import multimodal_diffusion_amd as A
+    W = R.synth_vae_decoder(seed=5, n_blocks=2)
+    vae = A.VideoVAE(A.VideoVAEConfig()).eval()
+    vae.load_state_dict(W, strict=False)
+    z = torch.randn(1, 8, 12, 32, 32, generator=torch.Generator().manual_seed(6))
+    ref = R.vae_decode(z, W, n_blocks=2)
+    x = vae.to(dev).decode(z.to(dev)).cpu()
+    assert x.shape == (1, 3, 48, 256, 256)
+    assert rel_err(x, ref) < TOL
+
+
+def test_add_mode_step_golden(dev, small_model):
+    """next-4 pinned: trainer-style embedding (train/trainer.py:36-49) against the G15 fixture made by the reference's own
+    helper definitions."""
+    import multimodal_diffusion_amd as A
+    _, W, meta = small_model
+    core, head, _, _ = _small_modules(dev, W, meta)
+    g = load_golden("g15_add_mode_step.npz")
+    Wa = split_weights(g)
+    av, aa = A.LinearAdapter(256, meta["d"]), A.LinearAdapter(32, meta["d"])
+    av.load_state_dict(Wa["adapt_v"], strict=True)
+    aa.load_state_dict(Wa["adapt_a"], strict=True)
+    z_v = G(g["z_v"], dev)
+    eng = A.DenoiseEngine(adapt_v=av.to(dev), adapt_a=aa.to(dev), core=core, head=head, tstep_dim=meta["tdim"], target="video",
+                          latent_shape=tuple(z_v.shape), prompt_tokens=5, alpha_bar=T(g["abar"]), guidance=float(g["guidance"]),
+                          temb_mode="add")
+    eng.set_prompt(G(g["z_a"], dev))
+    zn = eng.step(z_v, G(g["t_now"], dev), G(g["t_prev"], dev))
+    e2 = eng.eps_tokens()
+    B = z_v.shape[0]
+    assert rel_err(e2[:B].cpu(), g["eps_cond"]) < TOL and rel_err(e2[B:].cpu(), g["eps_null"]) < TOL
+    assert rel_err(zn.cpu(), g["z_next"]) < TOL
+
+
+@pytest.mark.parametrize("matmul", ["f32", "bf16x3"])
+def test_engine_follows_weight_updates(dev, full, matmul):
+    """Weights loaded AFTER the engine was built (load_state_dict writes in place): the next step must use the new weights
+    everywhere, including the derived norm-folded / split3 copies — checked against the oracle with the new weights."""
+    import multimodal_diffusion_amd as A
+    ws, _ = full
+    core, head, av, aa = _full_modules(dev, ws)
+    B = 16 if matmul == "bf16x3" else 2           # 2B*N = 13,472 rows takes the bf16x3 kernels
+    g = torch.Generator().manual_seed(31)
+    z_v = torch.randn(B, 8, 12, 32, 32, generator=g)
+    z_a = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn, tp = torch.full((B,), 500), torch.full((B,), 480)
+    eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video",
+                          latent_shape=tuple(z_v.shape), prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=matmul)
+    eng.set_prompt(z_a.to(dev))
+    before = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)).cpu()
+    ws2 = R.synth_weights(seed=9)
+    core.load_state_dict(ws2["core"])
+    head.load_state_dict(ws2["head"])
+    av.load_state_dict(ws2["adapt_v"])
+    aa.load_state_dict(ws2["adapt_a"])
+    after = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)).cpu()
+    ref = R.denoise_step_a2v(z_v[:2], z_a[:2], tn[:2], tp[:2], abar, adapt_v=ws2["adapt_v"], adapt_a=ws2["adapt_a"],
+                             core=ws2["core"], head=ws2["head"], n_layers=8, n_heads=8, guidance=3.5)
+    assert not torch.equal(before, after)
+    assert rel_err(after[:2], ref) < TOL

@@ -184,3 +184,20 @@ def test_g14_stream_stitch_oracle_and_host_split():
     assert [wa, ha, wf, hf] == list(g["split_meta"])
     one, _, _ = S.split_audio_into_windows(g["y_long"][:100], sr=1000, win_s=3.0, hop_s=1.0)
     assert one.shape == (1, 100)
+
+
+def test_g15_add_mode_step(small_model):
+    """next-4: the trainer's embedding (d-wide adapters + ADDED timestep embedding, train/trainer.py:36-49), one CFG step
+    produced by the reference's own helper definitions (tools/make_golden.py G15)."""
+    _, W, meta = small_model
+    g = load_golden("g15_add_mode_step.npz")
+    Wa = split_weights(g)
+    z, eps = R.denoise_step_a2v(T(g["z_v"]), T(g["z_a"]), T(g["t_now"]), T(g["t_prev"]), T(g["abar"]), adapt_v=Wa["adapt_v"],
+                                adapt_a=Wa["adapt_a"], core=W["core"], head=W["head"], n_layers=meta["n_layers"],
+                                n_heads=meta["n_heads"], tdim=meta["tdim"], guidance=float(g["guidance"]), return_eps=True,
+                                temb_mode="add")
+    assert rel_err(eps, g["eps_tok"]) < TOL
+    assert rel_err(z, g["z_next"]) < TOL
+    tok_v = R.tube_patch(T(g["z_v"]), 2, 4, 4)
+    Xv = R.embed_with_time(tok_v, Wa["adapt_v"]["proj.weight"], Wa["adapt_v"]["proj.bias"], T(g["t_now"]), 0, "add")
+    assert rel_err(Xv, g["X"][:, :tok_v.shape[1]]) < 1e-6

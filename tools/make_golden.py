@@ -12,7 +12,9 @@ Fixture list: G1 schedules, G2 timestep embedding, G3 token ind
 G4 RMSNorm, G5 Block/MMDiT, G6 MultiModalNoiseHead, G7 ddim_step, G8 one CFG step both directions,
 G9 chained A->V via the reference's own ``sample_one_direction``, G10 TimestepEmbedder(mlp),
 G11 VideoVAE.decode, G12 VideoVAE.encode, G13 AudioCodec,
-G14 stream_infer splitting / cross-fade stitching.
+G14 stream_infer splitting / cross-fade stitching,
+G15 one CFG step with the TRAINER's embedding (d-wide adapters, timestep embedding added; train/trainer.py:36-49),
+G16 drop-in corners: MMDiT with key_padding_mask, norm="layernorm", VideoVAE variational eval encode, non-GELU head.
 """
 from __future__ import annotations
 
@@ -38,7 +40,12 @@ def _sd(mod):
     return {k: _np(v) for k, v in mod.state_dict().items()}
 
 
+ONLY = None          # --only g15,g16: write just these fixtures (the others are computed and dropped)
+
+
 def _save(name, **arrays):
+    if ONLY is not None and name.split("_")[0] not in ONLY:
+        return
     OUT.mkdir(parents=True, exist_ok=True)
     path = OUT / name
     np.savez_compressed(path, **arrays)
@@ -71,7 +78,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full-size-report", action="store_true",
                     help="also compare oracle vs reference at mvp.yaml size (slow, writes a JSON report)")
+    ap.add_argument("--only", default=None, help="comma-separated fixture ids to write, e.g. g15,g16 (default: all)")
     args = ap.parse_args()
+    global ONLY
+    ONLY = set(args.only.split(",")) if args.only else None
     if not REF.exists():
         print("reference tree not present; nothing to do (committed fixtures stay authoritative)")
         return 0
@@ -309,6 +319,40 @@ def main():
           v_fade=si.crossfade_video(v_chunks, hop=4, win=12, fade_f=3),
           v_rect=si.crossfade_video(v_chunks, hop=4, win=12, fade_f=0),
           y_long=y_long, f_long=f_long, split_a=sa, split_f=sf, split_meta=np.array([wa, ha, wf, hf]))
+
+    # ---- G15 trainer-style embedding (next-4).  avdiff.models.train.trainer cannot be imported (tensorboard is absent), but
+    # its two embedding helpers (trainer.py:36-49: LinearAdapter, add_sinusoidal_timestep) depend only on torch and `su`:
+    # take exactly those two definitions out of the module's syntax tree and execute them, unmodified, against the reference's
+    # own schedule_utils.  One CFG step A->V with the reduced core/head above and d-wide adapters, statements as in G8.
+    import ast
+    tsrc = (REF / "avdiff/models/train/trainer.py").read_text()
+    keep = [n for n in ast.parse(tsrc).body
+            if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in ("LinearAdapter", "add_sinusoidal_timestep")]
+    assert [n.name for n in keep] == ["LinearAdapter", "add_sinusoidal_timestep"]
+    tns = {"torch": torch, "su": su}
+    exec(compile(ast.Module(body=keep, type_ignores=[]), str(REF / "avdiff/models/train/trainer.py"), "exec"), tns)
+    torch.manual_seed(15)
+    av_t, aa_t = tns["LinearAdapter"](256, 128), tns["LinearAdapter"](32, 128)
+    add_t = tns["add_sinusoidal_timestep"]
+    gen = torch.Generator().manual_seed(16)
+    z_v = torch.randn(B, 8, 4, 8, 8, generator=gen)
+    z_a = torch.randn(B, 8, 22, generator=gen)
+    tn = torch.tensor([982, 500], dtype=torch.long)
+    tp = torch.tensor([966, 480], dtype=torch.long)
+    tok_v = sc.latents_to_tokens_video(z_v, t_p=t_p, p=p)
+    tok_a = sc.latents_to_tokens_audio(z_a, l_chunk=l_chunk, s_chunk=s_chunk)
+    Nv = tok_v.size(1)
+    Xv = add_t(av_t(tok_v), tn, 128)
+    Xa = add_t(aa_t(tok_a), zero_t, 128)
+    hc = core(torch.cat([Xv, Xa], 1))
+    ec = head({"video": hc[:, :Nv], "audio": hc[:, Nv:]})["video"]
+    hn = core(torch.cat([Xv, torch.zeros_like(Xa)], 1))
+    en = head({"video": hn[:, :Nv], "audio": hn[:, Nv:]})["video"]
+    et = en + 3.0 * (ec - en)
+    el = ops.tube_unpatch_video(et, C=Cv, T=4, H=8, W=8, t=t_p, h=p, w=p)
+    _save("g15_add_mode_step.npz", z_v=_np(z_v), z_a=_np(z_a), t_now=_np(tn), t_prev=_np(tp), abar=_np(abar),
+          guidance=np.float32(3.0), X=_np(torch.cat([Xv, Xa], 1)), eps_cond=_np(ec), eps_null=_np(en), eps_tok=_np(et),
+          z_next=_np(su.ddim_step(z_v, tn, tp, el, abar, eta=0.0)), **_flat("adapt_v", _sd(av_t)), **_flat("adapt_a", _sd(aa_t)))
 
     # ---- optional: full-size live comparison oracle vs reference --------------------------
     if args.full_size_report:
