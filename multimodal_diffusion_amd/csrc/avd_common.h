@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <atomic>
 
 #include "../../include/avdiff_hip.h"
 
@@ -22,6 +23,13 @@ int set_error(int code, const char* fmt, ...);
         if (e__ != hipSuccess)                                                          \
             return avd::set_error(AVD_ELAUNCH, "%s: %s", (name), hipGetErrorString(e__)); \
     } while (0)
+
+// Dynamic-LDS limit of one kernel, raised once per device (hipFuncSetAttribute acts on the current device's copy of the
+// function).  Idempotent: two host threads racing here only repeat the call.
+struct LdsAttr {
+    std::atomic<uint64_t> done{0};
+    int ensure(const void* kern, int lds_bytes, const char* what);
+};
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -143,6 +151,9 @@ struct ProfScope {
 int gemm_f32(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm,
              float* C, RowMap cm, int64_t M, int N, int K, int act, hipStream_t st);
 
+extern int g_gemm_persist;       // 1 = persistent tile-queue launch for big GEMM grids (avd_tune_set "gemm_persist")
+extern int g_gemm_stages;        // 2 or 3 LDS stages for the 128x64 / 64x64 tiles (avd_tune_set "gemm_stages")
+extern int g_gemm_stagger_pct;   // first-generation stagger of co-resident GEMM blocks, percent of a block's MFMA time (avd_tune_set "gemm_stagger")
 extern int g_gemm_force_tile;     // -1 = automatic tile choice; 0 / 1 / 2 = 128x128 / 128x64 / 64x64 (avd_tune_set "gemm_tile")
 bool gemm_f32_fold_supported(int N, int K);
 int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm, float* C, RowMap cm,

@@ -6,7 +6,10 @@
 #include <stdlib.h>
 
 #include <string.h>
+#include <map>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace avd {
@@ -21,7 +24,19 @@ int set_error(int code, const char* fmt, ...) {
     return code;
 }
 
-// ---------------------------------------------------------------- measurement hooks
+int LdsAttr::ensure(const void* kern, int lds_bytes, const char* what) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return set_error(AVD_ELAUNCH, "%s: hipGetDevice: %s", what, hipGetErrorString(e));
+    const uint64_t bit = dev < 64 ? (uint64_t)1 << dev : 0;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return AVD_OK;
+    e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (e != hipSuccess) return set_error(AVD_ELAUNCH, "%s: hipFuncSetAttribute: %s", what, hipGetErrorString(e));
+    done.fetch_or(bit, std::memory_order_release);
+    return AVD_OK;
+}
+
+// ---------------------------------------------------------------- measurement hooks (single host thread; see the header)
 bool g_prof_on = false;
 namespace {
 struct ProfRec { hipEvent_t a, b; int tag; double work; };
@@ -299,13 +314,22 @@ static int embed_cfg_pair(const avd_embed_desc* e, const float* z, const float* 
         if (e__ != hipSuccess) return set_error(AVD_ELAUNCH, "%s: %s", #call, hipGetErrorString(e__)); \
     } while (0)
 
-static hipStream_t g_aux = nullptr;
-static hipEvent_t g_fork = nullptr, g_join = nullptr;
-static int ensure_aux() {
-    if (g_aux) return AVD_OK;
-    AVD_HIP(hipStreamCreateWithFlags(&g_aux, hipStreamNonBlocking));
-    AVD_HIP(hipEventCreateWithFlags(&g_fork, hipEventDisableTiming));
-    AVD_HIP(hipEventCreateWithFlags(&g_join, hipEventDisableTiming));
+// second stream + fork/join events of the split-stream step, one set per (device, caller stream): created on first use (the one
+// place the library allocates, outside any capture), never shared between two caller streams
+struct AuxState { hipStream_t aux = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+static std::mutex g_aux_mu;
+static std::map<std::pair<int, hipStream_t>, AuxState> g_aux_map;
+static int ensure_aux(hipStream_t st, AuxState& out) {
+    int dev = 0;
+    AVD_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_aux_mu);
+    AuxState& a = g_aux_map[{dev, st}];
+    if (!a.aux) {
+        AVD_HIP(hipStreamCreateWithFlags(&a.aux, hipStreamNonBlocking));
+        AVD_HIP(hipEventCreateWithFlags(&a.fork, hipEventDisableTiming));
+        AVD_HIP(hipEventCreateWithFlags(&a.join, hipEventDisableTiming));
+    }
+    out = a;
     return AVD_OK;
 }
 
@@ -345,6 +369,9 @@ extern "C" const char* avd_last_error(void) { return g_err; }
 extern "C" int avd_tune_set(const char* key, int64_t value) {
     AVD_REQUIRE(key, AVD_EINVAL, "tune_set: null key");
     if (!strcmp(key, "gemm_tile")) { g_gemm_force_tile = (int)value; return AVD_OK; }
+    if (!strcmp(key, "gemm_persist")) { g_gemm_persist = (int)value; return AVD_OK; }
+    if (!strcmp(key, "gemm_stages")) { g_gemm_stages = (int)value; return AVD_OK; }
+    if (!strcmp(key, "gemm_stagger")) { g_gemm_stagger_pct = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_min_rows")) { g_s3_min_rows = value; return AVD_OK; }
     if (!strcmp(key, "no_fold")) { g_no_fold = value != 0; return AVD_OK; }
     return set_error(AVD_EINVAL, "tune_set: unknown key '%s'", key);
@@ -353,7 +380,10 @@ extern "C" int avd_tune_set(const char* key, int64_t value) {
 extern "C" int avd_device_arch(char* buf, int buflen) {
     AVD_REQUIRE(buf && buflen > 0, AVD_EINVAL, "device_arch: bad buffer");
     hipDeviceProp_t prop;
-    hipError_t e = hipGetDeviceProperties(&prop, 0);
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return set_error(AVD_ELAUNCH, "hipGetDevice: %s", hipGetErrorString(e));
+    e = hipGetDeviceProperties(&prop, dev);
     if (e != hipSuccess) return set_error(AVD_ELAUNCH, "hipGetDeviceProperties: %s", hipGetErrorString(e));
     strncpy(buf, prop.gcnArchName, buflen - 1);
     buf[buflen - 1] = 0;
@@ -424,7 +454,10 @@ extern "C" int avd_denoise_step_f32(const avd_step_desc* s, const float* z, cons
     } else {
         // the cond and null halves are independent until the CFG combine: run them as two kernel chains on two
         // streams so one chain's partially-filled last rounds overlap the other chain's kernels
-        if (int rc = ensure_aux()) return rc;
+        AuxState ax;
+        if (int rc = ensure_aux(st, ax)) return rc;
+        hipStream_t g_aux = ax.aux;
+        hipEvent_t g_fork = ax.fork, g_join = ax.join;
         const int64_t half_rows = (int64_t)e.B * p.N * e.d;
         const int64_t hc = p.core / 2, hh = p.head / 2;
         AVD_HIP(hipEventRecord(g_fork, st));

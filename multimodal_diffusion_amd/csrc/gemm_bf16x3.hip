@@ -496,13 +496,9 @@ template <int EPI>
 static int launch_s3(const S3Args& a, hipStream_t st) {
     const int tile = s3_tile_for(EPI, a.M, a.N);
     const int BMt = tile ? S3B_BM : S3_BM, BNt = tile ? S3B_BN : S3_BN, lds = tile ? S3B_LDS : S3_LDS;
-    static bool attr[2] = {false, false};
+    static LdsAttr attr[2];
     const void* kern = tile ? reinterpret_cast<const void*>(gemm_bf16x3_b_kernel<EPI>) : reinterpret_cast<const void*>(gemm_bf16x3_kernel<EPI>);
-    if (!attr[tile]) {
-        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return set_error(AVD_ELAUNCH, "gemm_bf16x3 attr: %s", hipGetErrorString(e));
-        attr[tile] = true;
-    }
+    if (int rc = attr[tile].ensure(kern, lds, "gemm_bf16x3")) return rc;
     S3Args g = a;
     g.nbn = a.N / BNt;
     int sn = 8;

@@ -55,7 +55,35 @@ struct GemmArgs {
     int ss_in_cols;
     float ss_sqrt_d, ss_eps;
     float* ss_out;
+    // first-generation stagger (cycles per resident slot, 0 = off): blocks blockIdx >= 256 are the 2nd, 3rd ... block of their CU
+    // and start that many shader cycles late, so co-resident blocks do not run their prologues / epilogues in lockstep
+    int stagger;
+    // persistent mode (queue != null): the grid is 2 blocks per CU, each pulls tiles from its XCD's counter until the XCD's
+    // contiguous tile range is exhausted.  queue[0..7] next tile per XCD label, queue[8] blocks that have finished (the last
+    // one re-zeroes the slot for its next use).  ntiles = row blocks x column blocks.
+    unsigned int* queue;
+    int ntiles;
+#ifdef AVD_GEMM_STAMPS      // diagnostic build only (tools/micro/gemm_stamps.py): per-block phase stamps, never in the product library
+    unsigned long long* dbg;
+#endif
 };
+
+#ifdef AVD_GEMM_STAMPS
+#define AVD_STAMP(i)                                                                                           \
+    do {                                                                                                        \
+        if (threadIdx.x == 0) {                                                                                 \
+            g.dbg[(size_t)blockIdx.x * 16 + 2 * (i)] = __builtin_amdgcn_s_memtime();                            \
+            g.dbg[(size_t)blockIdx.x * 16 + 2 * (i) + 1] = __builtin_amdgcn_s_memrealtime();                    \
+        }                                                                                                       \
+    } while (0)
+#else
+#define AVD_STAMP(i) do { } while (0)
+#endif
+
+// tile-queue slots of the persistent launches: zero at module load, every launch leaves its slot zeroed again.  A slot is 16
+// words; consecutive launches take consecutive slots, so kernels that overlap on two streams never share one.
+constexpr int GEMM_QUEUE_SLOTS = 64;
+__device__ unsigned int g_gemm_queue[GEMM_QUEUE_SLOTS * 16];
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = b & 7;
@@ -68,7 +96,11 @@ __device__ __forceinline__ int xcd_remap(int b, int nwg) {
 // =====================================================================================================
 // hot path: LDS-DMA staged main loop + LDS-staged float4 epilogue
 // =====================================================================================================
-template <int BM, int BN, int WM, int WN, int EPI, int WPS>
+// vmcnt(n) lgkmcnt(0) / vmcnt(n) alone as s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14])
+constexpr int waitcnt_vm_lgkm0(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0070; }
+constexpr int waitcnt_vm(int n) { return (n & 15) | ((n >> 4) << 14) | 0x0f70; }
+
+template <int BM, int BN, int WM, int WN, int EPI, int WPS, int NST>
 __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
     constexpr int BK = GEMM_BK;
     constexpr int WAVES_N = BN / WN;
@@ -76,13 +108,60 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int A_PIECES = BM / 32, B_PIECES = BN / 32;   // 1-KiB pieces (8 rows x 128 B) per wave
     constexpr int STAGE = (BM + BN) * BK;                   // floats per stage
+    constexpr int TILE_BOX = (NST * STAGE > 4 * WM * (WN + 4) ? NST * STAGE : 4 * WM * (WN + 4));   // word index behind stages / slabs
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    const int wg = xcd_remap(blockIdx.x, gridDim.x);
-    const int bm = wg / g.nbn, bn = wg % g.nbn;
+    if (g.stagger > 0) {
+        const int slot = blockIdx.x >> 8;
+        if (slot > 0 && slot < WPS) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime(), want = (unsigned long long)slot * g.stagger;
+            while (__builtin_amdgcn_s_memtime() - t0 < want) __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    AVD_STAMP(0);
+#ifdef AVD_GEMM_STAMPS
+    if (threadIdx.x == 0) {
+        unsigned hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g.dbg[(size_t)blockIdx.x * 16 + 8] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+    // Tile supply.  Classic: one tile per block, block ids remapped so an XCD gets a contiguous tile range.  Persistent: two
+    // blocks per CU with FIXED matrix-pipe priority (the first 256 block ids high, the rest low) pull tiles of their XCD's
+    // range from an atomic counter.  Equal co-resident blocks drift into lockstep — a block that is alone on the pipe runs
+    // twice as fast and catches up — and then run prologue and epilogue together with the pipe idle (measured: 17-21 % of
+    // the kernel).  With fixed priorities the high block runs its main loop at full speed and the low block takes exactly
+    // the slots the high one leaves: its prologue (first-stage DMA latency), its epilogue and its barrier waits.
+    const bool persist = g.queue != nullptr;
+    int* tile_box = reinterpret_cast<int*>(smem) + TILE_BOX;      // one word past stages / slabs: next tile id, block-wide
+    int xq = 0, xr = 0, xstart = 0, xcount = 0;
+    if (persist) {
+        const int x = blockIdx.x & 7;
+        xq = g.ntiles >> 3;
+        xr = g.ntiles & 7;
+        xstart = x < xr ? x * (xq + 1) : xr * (xq + 1) + (x - xr) * xq;
+        xcount = xq + (x < xr ? 1 : 0);
+        if (blockIdx.x < 256) __builtin_amdgcn_s_setprio(3);
+        if (tid == 0) *tile_box = (int)atomicAdd(g.queue + x, 1u);
+        __syncthreads();
+    }
+    for (int round = 0;; ++round) {
+    int wg;
+    if (persist) {
+        const int ticket = *tile_box;
+        if (ticket >= xcount) break;
+        wg = xstart + ticket;
+    } else {
+        if (round) break;
+        wg = xcd_remap(blockIdx.x, gridDim.x);
+    }
+    const int bm = wg / g.nbn, bn = wg % g.nbn;
 
     // ---- DMA source addresses: piece p = tile rows 8p..8p+7; lane -> row 8p + lane/8, PHYSICAL chunk lane%8 ----
     const int r8 = lane >> 3, pc = lane & 7;
@@ -123,9 +202,19 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = g.K / BK;
+    // NST-stage ring: tiles 0 .. NST-2 are in flight before the loop, tile kt + NST - 1 is issued during tile kt
+    constexpr int NPIECE_ = A_PIECES + B_PIECES;
     stage(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
-    __syncthreads();
+    if (NST > 2 && nk > 1) {
+        stage(1, 1);
+        __builtin_amdgcn_s_waitcnt(waitcnt_vm(NST > 2 ? NPIECE_ : 0));   // tile 0 landed, tile 1 may still fly
+    } else {
+        __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    }
+    __builtin_amdgcn_s_barrier();
+    // everyone has read this tile's id: fetch the next one now, its latency hides under the main loop
+    unsigned int next_ticket = 0;
+    if (persist && tid == 0) next_ticket = atomicAdd(g.queue + (blockIdx.x & 7), 1u);
 
     // fragment read offsets (floats): row*32 + ((2kk+hi) ^ ((row>>1)&7))*4 — conflict-free ds_read_b128
     int a_row[TM], a_sw[TM], b_row[TN], b_sw[TN];
@@ -157,20 +246,30 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
     static_assert(NPIECE <= 11 * MPS, "DMA pieces must all be issued before the tile's last k-group");
 #define AVD_SB() __builtin_amdgcn_sched_barrier(0)
     auto ld_frag = [&](const float* as, const float* bs, int kk, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
+#ifdef AVD_LAB_NOLDS       // diagnostic build: fragments stay whatever the registers hold
+        if (kk >= 0) { asm volatile("" : "+v"(af[0]), "+v"(bf[0])); return; }
+#endif
 #pragma unroll
         for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(as + a_row[i] + (((2 * kk + hi) ^ a_sw[i]) << 2));
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(bs + b_row[j] + (((2 * kk + hi) ^ b_sw[j]) << 2));
     };
     f32x4 af0[TM], bf0[TN], af1[TM], bf1[TN];
-    auto ktile = [&](int kt, auto dma_tag) {
-        constexpr bool DMA = decltype(dma_tag)::value;
-        const int cur = kt & 1;
+    int cur = 0, dbuf = NST - 1;                  // ring slots of tile kt and of tile kt + NST - 1
+    // mode 2: issue tile kt+NST-1's DMA, then wait for tile kt+1 leaving the newer tiles in flight; 1: nothing left to issue,
+    // wait for everything; 0: last tile
+    auto ktile = [&](int kt, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        constexpr bool DMA = MODE == 2;
         const float* as = smem + cur * STAGE;
         const float* bs = as + BM * BK;
-        float* nas = smem + (cur ^ 1) * STAGE;
+        float* nas = smem + dbuf * STAGE;
         float* nbs = nas + BM * BK;
-        const int k1 = (kt + 1) * BK;
+#ifdef AVD_LAB_SAMEK       // diagnostic build: every stage re-reads K tile 0 (all DMA traffic becomes L2 hits; results wrong by design)
+        const int k1 = 0 * kt;
+#else
+        const int k1 = (kt + NST - 1) * BK;
+#endif
         // steps [s0, s1) of k-group g on the registers (af, bf); MFMA number m of the tile is followed by DMA piece m - MPS
         auto mma = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], int g, int s0, int s1) {
 #pragma unroll
@@ -181,7 +280,11 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
                     for (int j = 0; j < TN; ++j) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
                         const int pc = (g * 4 + s) * MPS + i * TN + j - MPS;
+#ifdef AVD_LAB_NODMA       // diagnostic build: no global traffic inside the main loop (results are wrong by design)
+                        if (false) {
+#else
                         if (DMA && pc >= 0 && pc < NPIECE) {
+#endif
                             AVD_SB();
                             if (pc < A_PIECES)
                                 __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(a_src[pc < A_PIECES ? pc : 0] + k1),
@@ -197,18 +300,27 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
         AVD_SB(); mma(af1, bf1, 1, 0, 1); AVD_SB(); ld_frag(as, bs, 2, af0, bf0); AVD_SB(); mma(af1, bf1, 1, 1, 4);
         AVD_SB(); mma(af0, bf0, 2, 0, 1); AVD_SB(); ld_frag(as, bs, 3, af1, bf1); AVD_SB(); mma(af0, bf0, 2, 1, 4);
         AVD_SB(); mma(af1, bf1, 3, 0, 2); AVD_SB();
-        if constexpr (DMA) {
+        cur = cur + 1 == NST ? 0 : cur + 1;
+        dbuf = dbuf + 1 == NST ? 0 : dbuf + 1;
+        if constexpr (MODE != 0) {
             // every wave holds its last fragments of this stage in registers: wait for the next stage's DMA, swap
-            __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+            __builtin_amdgcn_s_waitcnt(waitcnt_vm_lgkm0(MODE == 2 ? (NST - 2) * NPIECE : 0));
             __builtin_amdgcn_s_barrier();
-            ld_frag(nas, nbs, 0, af0, bf0);
+            const float* an = smem + cur * STAGE;
+            ld_frag(an, an + BM * BK, 0, af0, bf0);
         }
         AVD_SB(); mma(af1, bf1, 3, 2, 4); AVD_SB();
     };
+    AVD_STAMP(1);
     ld_frag(smem, smem + BM * BK, 0, af0, bf0);
-    for (int kt = 0; kt + 1 < nk; ++kt) ktile(kt, std::true_type{});
-    ktile(nk - 1, std::false_type{});
+    {
+        int kt = 0;
+        for (; kt + NST - 1 < nk; ++kt) ktile(kt, std::integral_constant<int, 2>{});
+        for (; kt + 1 < nk; ++kt) ktile(kt, std::integral_constant<int, 1>{});
+        ktile(kt, std::integral_constant<int, 0>{});
+    }
 #undef AVD_SB
+    AVD_STAMP(2);
     __syncthreads();    // the slabs below overlay the stages: every wave must be past its last fragment read
 
     // ---- epilogue: park the wave's WM x WN tile in its own LDS slab, stream it out as 16-byte row segments ----
@@ -245,7 +357,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
             inv_r = 1.0f / (sqrtf(ss) / g.ss_sqrt_d + g.ss_eps);
         }
     }
-    if (n >= g.N) return;           // N % 4 == 0: a float4 is wholly in or out (never taken when folding: N % BN == 0 there)
+    if (n < g.N) {                  // N % 4 == 0: a float4 is wholly in or out (always true when folding: N % BN == 0 there)
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
     const int64_t mbase = (int64_t)bm * BM + wm * WM + cr;
@@ -285,6 +397,20 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
             }
         }
     }
+    }   // n < N
+    if (!persist) break;
+    if (tid == 0) *tile_box = (int)next_ticket;
+    __syncthreads();                // slabs drained before the next tile's DMA lands on them; next tile id visible
+    }   // tiles
+    if (persist && tid == 0) {
+        // the last block to leave re-zeroes the slot (every block has drawn its final ticket before it counts itself done)
+        const unsigned int done = atomicAdd(g.queue + 8, 1u);
+        if (done == gridDim.x - 1) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) __hip_atomic_store(g.queue + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    AVD_STAMP(3);
 }
 
 // =====================================================================================================
@@ -426,48 +552,69 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_reg_kernel(GemmArgs g) {
 // =====================================================================================================
 // host side
 // =====================================================================================================
-template <typename Kern>
-static int set_lds(Kern kern, int lds, bool& done) {
-    if (!done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        if (e != hipSuccess) return set_error(AVD_ELAUNCH, "gemm attr: %s", hipGetErrorString(e));
-        done = true;
+
+// device address of g_gemm_queue on the current device (looked up once per device)
+static int gemm_queue_base(unsigned int** out) {
+    static std::atomic<unsigned int*> cache[64];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return set_error(AVD_ELAUNCH, "gemm queue: hipGetDevice: %s", hipGetErrorString(e));
+    unsigned int* p = dev < 64 ? cache[dev].load(std::memory_order_acquire) : nullptr;
+    if (!p) {
+        e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_gemm_queue));
+        if (e != hipSuccess) return set_error(AVD_ELAUNCH, "gemm queue: %s", hipGetErrorString(e));
+        if (dev < 64) cache[dev].store(p, std::memory_order_release);
     }
+    *out = p;
     return AVD_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int EPI, int WPS>
+template <int BM, int BN, int WM, int WN, int EPI, int WPS, int NST>
 static int launch_dma(const GemmArgs& a, hipStream_t st) {
-    constexpr int stage_lds = 2 * (BM + BN) * GEMM_BK * 4, epi_lds = 4 * WM * (WN + 4) * 4;
-    constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
-    static bool attr = false;
-    auto kern = gemm_f32_dma_kernel<BM, BN, WM, WN, EPI, WPS>;
-    if (int rc = set_lds(kern, lds, attr)) return rc;
+    constexpr int stage_lds = NST * (BM + BN) * GEMM_BK * 4, epi_lds = 4 * WM * (WN + 4) * 4;
+    constexpr int lds = (stage_lds > epi_lds ? stage_lds : epi_lds) + 16;       // + the tile box
+    static LdsAttr attr;
+    auto kern = gemm_f32_dma_kernel<BM, BN, WM, WN, EPI, WPS, NST>;
+    if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), lds, "gemm_f32_dma")) return rc;
     GemmArgs g = a;
     g.nbn = (a.N + BN - 1) / BN;
     const int64_t nwg = ((a.M + BM - 1) / BM) * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm grid too large");
+    // one slot's delay = the block's own MFMA issue time (K/32 tiles x TM*TN*16 MFMAs x 64 cycles), scaled by the knob
+    g.stagger = nwg > 256 ? (int)((int64_t)(a.K / GEMM_BK) * (WM / 32) * (WN / 32) * 16 * 64 * g_gemm_stagger_pct / 100) : 0;
+    // persistent launch: worth it once there are a few tiles per resident block
+    int64_t grid = nwg;
+    g.queue = nullptr;
+    g.ntiles = (int)nwg;
+    if (g_gemm_persist && nwg >= 2 * 512) {
+        static std::atomic<unsigned> seq{0};
+        unsigned int* base = nullptr;
+        if (int rc = gemm_queue_base(&base)) return rc;
+        g.queue = base + (seq.fetch_add(1) % GEMM_QUEUE_SLOTS) * 16;
+        g.stagger = 0;
+        grid = 512;
+    }
     // tag = the kernel name exactly as rocprofv3 prints its template arguments (EPI: 0 bias, 1 gelu, 2 residual)
-    static const int tag = prof_tag_id("gemm_f32_dma_kernel<%d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, EPI, WPS);
+    static const int tag = prof_tag_id("gemm_f32_dma_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, EPI, WPS, NST);
     ProfScope prof(tag, 2.0 * (double)a.M * a.N * a.K, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, g);
     AVD_CHECK_LAUNCH("gemm_f32_dma");
     return AVD_OK;
 }
 
-template <int BM, int BN, int WM, int WN, int WPS>
+template <int BM, int BN, int WM, int WN, int WPS, int NST>
 static int launch_dma_epi(const GemmArgs& a, hipStream_t st) {
-    if (a.R != nullptr) return launch_dma<BM, BN, WM, WN, EPI_RES, WPS>(a, st);
-    if (a.act == AVD_ACT_GELU) return launch_dma<BM, BN, WM, WN, EPI_GELU, WPS>(a, st);
-    return launch_dma<BM, BN, WM, WN, EPI_BIAS, WPS>(a, st);
+    if (a.R != nullptr) return launch_dma<BM, BN, WM, WN, EPI_RES, WPS, NST>(a, st);
+    if (a.act == AVD_ACT_GELU) return launch_dma<BM, BN, WM, WN, EPI_GELU, WPS, NST>(a, st);
+    return launch_dma<BM, BN, WM, WN, EPI_BIAS, WPS, NST>(a, st);
 }
 
 template <int BM, int BN, int WM, int WN, bool KTAIL>
 static int launch_reg(const GemmArgs& a, hipStream_t st) {
     constexpr int lds = 2 * (BM + BN) * GEMM_LD * 4;
-    static bool attr = false;
+    static LdsAttr attr;
     auto kern = gemm_f32_reg_kernel<BM, BN, WM, WN, KTAIL>;
-    if (int rc = set_lds(kern, lds, attr)) return rc;
+    if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), lds, "gemm_f32_reg")) return rc;
     GemmArgs g = a;
     g.nbn = (a.N + BN - 1) / BN;
     const int64_t nwg = ((a.M + BM - 1) / BM) * g.nbn;
@@ -484,8 +631,22 @@ static int launch_reg_k(const GemmArgs& a, hipStream_t st) {
     return (a.K % GEMM_BK) ? launch_reg<BM, BN, WM, WN, true>(a, st) : launch_reg<BM, BN, WM, WN, false>(a, st);
 }
 
+#ifdef AVD_GEMM_STAMPS
+unsigned long long* g_gemm_dbg = nullptr;
+extern "C" void lab_set_dbg(unsigned long long* p) { g_gemm_dbg = p; }
+extern "C" void lab_set_tile(int t);
+#endif
+int g_gemm_persist = getenv("AVD_GEMM_PERSIST") ? atoi(getenv("AVD_GEMM_PERSIST")) : 0;   // persistent tile queue for big grids
+int g_gemm_stages = getenv("AVD_GEMM_STAGES") ? atoi(getenv("AVD_GEMM_STAGES")) : 3;      // LDS ring depth of the 128x64 / 64x64 tiles
+int g_gemm_stagger_pct = getenv("AVD_GEMM_STAGGER") ? atoi(getenv("AVD_GEMM_STAGGER")) : 0;
 int g_gemm_force_tile = getenv("AVD_GEMM_TILE") ? atoi(getenv("AVD_GEMM_TILE")) : -1;
 
+#ifdef AVD_GEMM_STAMPS
+extern "C" void lab_set_tile(int t) { g_gemm_force_tile = t; }
+extern "C" void lab_set_stagger(int pct) { g_gemm_stagger_pct = pct; }
+extern "C" void lab_set_stages(int n) { g_gemm_stages = n; }
+extern "C" void lab_set_persist(int n) { g_gemm_persist = n; }
+#endif
 bool gemm_f32_fold_supported(int N, int K) { return K % GEMM_BK == 0 && N % 128 == 0; }
 
 int gemm_f32(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm,
@@ -505,7 +666,10 @@ int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, 
     AVD_REQUIRE(aligned16(A) && aligned16(W), AVD_EUNSUPPORTED, "gemm: A/W must be 16-byte aligned");
     AVD_REQUIRE(act == AVD_ACT_NONE || act == AVD_ACT_GELU || act == AVD_ACT_SILU, AVD_EINVAL, "gemm: bad act %d", act);
     if (M == 0) return AVD_OK;
-    GemmArgs g{A, am, W, bias, R, rm, C, cm, M, N, K, act, 0, ss_in, ss_in_cols, sqrt_d, eps, ss_out};
+    GemmArgs g{A, am, W, bias, R, rm, C, cm, M, N, K, act, 0, ss_in, ss_in_cols, sqrt_d, eps, ss_out, 0, nullptr, 0};
+#ifdef AVD_GEMM_STAMPS
+    g.dbg = g_gemm_dbg;
+#endif
 
     const int force = g_gemm_force_tile;      // tuning / test hook (avd_tune_set "gemm_tile"; env AVD_GEMM_TILE)
     const bool dma_ok = K % GEMM_BK == 0 && N % 4 == 0 && N > 32 && cm.seg <= 0 && cm.ld % 4 == 0 && aligned16(C) &&
@@ -520,12 +684,10 @@ int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, 
         // N = 512 projections so the last round is not half empty; 64x64 for small problems
         int tile = (N >= 128 && mb128 * ((N + 127) / 128) >= 1536) ? 0 : (mb128 * ((N + 63) / 64) >= 512) ? 1 : 2;
         if (force >= 0 && force <= 2) tile = force;
-        if (tile == 0) return launch_dma_epi<128, 128, 64, 64, 2>(g, st);
-        if (tile == 1) {
-            static const bool three = getenv("AVD_GEMM_WPS3") != nullptr;      // measurement aid: three resident blocks per CU
-            return three ? launch_dma_epi<128, 64, 64, 32, 3>(g, st) : launch_dma_epi<128, 64, 64, 32, 2>(g, st);
-        }
-        return launch_dma_epi<64, 64, 32, 32, 4>(g, st);
+        const bool ring3 = g_gemm_stages == 3;
+        if (tile == 0) return launch_dma_epi<128, 128, 64, 64, 2, 2>(g, st);
+        if (tile == 1) return ring3 ? launch_dma_epi<128, 64, 64, 32, 2, 3>(g, st) : launch_dma_epi<128, 64, 64, 32, 2, 2>(g, st);
+        return ring3 ? launch_dma_epi<64, 64, 32, 32, 3, 3>(g, st) : launch_dma_epi<64, 64, 32, 32, 4, 2>(g, st);
     }
     if (N <= 32) return launch_reg_k<128, 32, 32, 32>(g, st);
     if (N >= 128 && mb128 * ((N + 127) / 128) >= 512) return launch_reg_k<128, 128, 64, 64>(g, st);

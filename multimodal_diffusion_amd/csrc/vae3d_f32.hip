@@ -638,6 +638,8 @@ struct VaePlan {
     int64_t THW, pad_b, y_b, hlow_b, part_b, stats_b, total;
 };
 
+static LdsAttr g_conv3_attr;      // dynamic-LDS limit of conv3d_k3_bf16x3_kernel (per device)
+
 static int vae_plan(const avd_vae_decode_desc* d, VaePlan& p) {
     AVD_REQUIRE(d, AVD_EINVAL, "vae_decode: null descriptor");
     AVD_REQUIRE(d->B > 0 && d->Cv > 0 && d->Tp > 0 && d->Hp > 0 && d->Wp > 0, AVD_EINVAL, "vae_decode: bad latent dims");
@@ -732,12 +734,8 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
     constexpr int stage_lds = 2 * (VBM + VC) * VBK * 4, epi_lds = 4 * 64 * 36 * 4;
     constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
     constexpr int lds3 = 2 * (3 * VBM * 64 + W3_STAGE);
-    static bool attr3 = false;
-    if (s3 && !attr3) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-        if (e != hipSuccess) return set_error(AVD_ELAUNCH, "vae_decode attr: %s", hipGetErrorString(e));
-        attr3 = true;
-    }
+    if (s3)
+        if (int rc = g_conv3_attr.ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel), lds3, "vae_decode")) return rc;
     for (int blk = 0; blk < d->n_blocks; ++blk) {
         ConvArgs a{Xp, d->conv_w[blk], d->conv_b[blk], Y, part, p.T, p.H, p.W, p.tiles};
         if (s3) {
@@ -854,12 +852,8 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
     constexpr int stage_lds = 2 * (VBM + VC) * VBK * 4, epi_lds = 4 * 64 * 36 * 4;
     constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
     constexpr int lds3 = 2 * (3 * VBM * 64 + W3_STAGE);
-    static bool attr3 = false;
-    if (s3 && !attr3) {
-        hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
-        if (ea != hipSuccess) return set_error(AVD_ELAUNCH, "vae_encode attr: %s", hipGetErrorString(ea));
-        attr3 = true;
-    }
+    if (s3)
+        if (int rc = g_conv3_attr.ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel), lds3, "vae_encode")) return rc;
     for (int blk = 0; blk < d->n_blocks; ++blk) {
         ConvArgs a{blk == 0 ? Xp4 : Xp, d->conv_w[blk], d->conv_b[blk], Y, part, T, H, W, p.tiles};
         if (blk > 0 && s3) {
