@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AVD_ABI_VERSION 2
+#define AVD_ABI_VERSION 3
 
 #define AVD_OK            0
 #define AVD_EINVAL       -1   /* bad shape / argument (reference: AssertionError / ValueError) */
@@ -37,6 +37,8 @@ extern "C" {
 #define AVD_ACT_GELU 1        /* exact erf GELU (torch.nn.functional.gelu default) */
 #define AVD_ACT_SILU 2
 #define AVD_ACT_TANH 3        /* conv1d only (AudioCodec.decode output) */
+#define AVD_ACT_RELU 4        /* avd_layernorm_act_f32 / noise head only (heads/noise_heads.py:28-36) */
+#define AVD_ACT_LEAKY_RELU 5  /* slope 0.1, same scope */
 
 typedef void* avd_stream_t;   /* hipStream_t */
 
@@ -78,9 +80,12 @@ int avd_gemm_rmsfold_f32(const float* A, const float* W, const float* bias, cons
  * avdiff/models/mmdt.py:51-61 between in_proj and out_proj: out = softmax(q k^T * scale) v per head,
  * no mask, eval.  qkv: [B,N,3*H*Dh] (q | k | v along the last dim, heads contiguous inside each),
  * out: [B,N,H*Dh].  Dh must be 64.  n_query <= N limits the query rows computed (rows >= n_query of
- * `out` are left untouched); pass N for the reference behaviour. */
+ * `out` are left untouched); pass N for the reference behaviour.
+ * key_padding_mask: NULL, or bytes [B,N] with non-zero = this key is padding and gets no attention weight
+ * (MMDiT.forward's key_padding_mask, mmdt.py:57-60,134-149).  A sample whose keys are ALL padded is undefined in the reference
+ * (NaN); here it attends uniformly. */
 int avd_attn_fwd_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float scale,
-                     int n_query, avd_stream_t stream);
+                     int n_query, const uint8_t* key_padding_mask, avd_stream_t stream);
 
 /* ---- a7: LayerNorm(d, eps, affine) followed by an activation — the Linear→LayerNorm→GELU block of
  * avdiff/models/heads/noise_heads.py:141-147.  x,y: [rows,d]. */
@@ -103,11 +108,12 @@ int avd_tube_unpatch_f32(const float* tok, float* z, int B, int C, int T, int H,
 
 /* ---- a2 / a8': audio chunk tokens and their overlap-add inverse —
  * avdiff/models/infer/sample_clip.py:184-188 and :191-215 (-> avdiff/utils/ops.py:17-45, 48-93).
- * z: [B,Ca,F] -> tok: [B,Na,Ca*len], Na = (F-len)/stride + 1.  Inverse: rectangular-window overlap-add,
- * divided by the overlap count, cropped / zero-padded to F frames. */
+ * z: [B,Ca,F] -> tok: [B,Na,Ca*len], Na = (F-len)/stride + 1.  Inverse: overlap-add weighted by `window` [len] and divided
+ * by the summed weights (window == NULL: rectangular, i.e. the overlap count; a Hann table gives ops.py's apply_hann=True),
+ * cropped / zero-padded to F frames. */
 int avd_audio_tokens_f32(const float* z, float* tok, int B, int Ca, int F, int len, int stride,
                          avd_stream_t stream);
-int avd_audio_untokens_f32(const float* tok, float* z, int B, int Ca, int F, int len, int stride,
+int avd_audio_untokens_f32(const float* tok, const float* window, float* z, int B, int Ca, int F, int len, int stride,
                            avd_stream_t stream);
 
 /* ---- a8: DDIM update — avdiff/utils/schedule_utils.py:146-200 (ddim_step).
@@ -162,7 +168,7 @@ int avd_embed_cfg_pair_f32(const avd_embed_desc* desc, const float* z_target, co
  * These enqueue exactly the kernels above in order; they exist to keep the per-step host cost at one FFI
  * call and to make a step one hipGraph-capturable unit. */
 typedef struct {                       /* avdiff/models/mmdt.py:88-99 (Block) state_dict, device ptrs */
-    const float* norm1_scale;          /* blocks.{i}.norm1.scale              [d]      */
+    const float* norm1_scale;          /* blocks.{i}.norm1.scale (norm="layernorm": .weight) [d] */
     const float* in_proj_weight;       /* blocks.{i}.attn.mha.in_proj_weight  [3d,d]   */
     const float* in_proj_bias;         /* blocks.{i}.attn.mha.in_proj_bias    [3d]     */
     const float* out_proj_weight;      /* blocks.{i}.attn.mha.out_proj.weight [d,d]    */
@@ -183,6 +189,8 @@ typedef struct {                       /* avdiff/models/mmdt.py:88-99 (Block) st
     const void* out_proj_weight3;
     const void* fc1_weight3;
     const void* fc2_weight3;
+    const float* norm1_bias;           /* norm="layernorm" only: blocks.{i}.norm1.bias / norm2.bias [d]; NULL for RMSNorm */
+    const float* norm2_bias;
 } avd_block_weights;
 
 typedef struct {                       /* avdiff/models/mmdt.py:116-149 (MMDiT) */
@@ -190,6 +198,10 @@ typedef struct {                       /* avdiff/models/mmdt.py:116-149 (MMDiT) 
     float norm_eps;                    /* 1e-6 */
     const avd_block_weights* blocks;   /* HOST array [n_layers] of device-pointer tables */
     const float* final_norm_scale;     /* final_norm.scale [d] */
+    int norm_kind;                     /* 0: RMSNorm (every shipped config); 1: nn.LayerNorm (build_norm, mmdt.py:44-45) — fp32 path only */
+    const float* final_norm_bias;      /* final_norm.bias [d] for norm_kind 1, else NULL */
+    int split_terms;                   /* bf16x3 path only: product terms kept per k — 0 or 6: default (fp32-level error), 9: strict
+                                        * (nothing dropped), 1: plain bf16 operands (reduced precision, BASELINE config C2) */
 } avd_core_weights;
 
 typedef struct {                       /* avdiff/models/heads/noise_heads.py:94-229, one modality path */
@@ -210,7 +222,13 @@ typedef struct {                       /* avdiff/models/heads/noise_heads.py:94-
  * avdiff/models/mmdt.py:60,77-83).  Every fp32 operand is split exactly into three bf16 planes (x = h + m + l); a
  * product keeps the six terms down to 2^-16 and accumulates them in fp32, so the result carries the error of an fp32
  * FMA chain (measured slightly below it) while the matrix pipe runs 2.67x fewer cycles than with fp32 MFMA.
- * Operands travel as "split3 images" (tiled, 6 bytes per element, rows padded to 256; layout in csrc/gemm_bf16x3.hip). */
+ * Operands travel as "split3 images" (tiled, 6 bytes per element, rows padded to 256; layout in csrc/gemm_bf16x3.hip).
+ * `terms` selects the product terms kept per k: 6 (or 0) the default above; 9 strict — all nine, nothing dropped; 1 — only the
+ * high planes, i.e. plain bf16 operands with fp32 accumulation: the reduced-precision variant BASELINE config C2 names, whose
+ * error is REPORTED against the fp32 oracle and which is never a parity path.
+ * Domain: finite operands with |x| >= ~2^-110 or 0 split exactly (below that the lower planes leave bf16's range and the
+ * absolute error per product is < 2^-126); +-inf / NaN in an operand row make that output row non-finite (NaN where an
+ * fp32 chain would give +-inf). */
 int64_t avd_split3_bytes(int64_t rows, int K);                     /* bytes of the image of a [rows,K] matrix; -1 if K % 16 */
 int avd_split3_f32(const float* x, void* out, int64_t rows, int K, avd_stream_t stream);   /* x [rows,K] contiguous */
 /* RMSNorm (mmdt.py:39-42) whose output is written as a split3 image (the A operand of the next Linear) */
@@ -225,25 +243,26 @@ int avd_attn_fwd_split3_f32(const float* qkv, void* out3, int B, int N, int H, i
 int64_t avd_qkv3_bytes(int B, int N, int H);                       /* bytes of the image for [B,N,3*H*64] */
 /* qkv = A W^T + bias, A3/W3 split3 images of A [M,K] (M = B*tokens rows) and in_proj_weight [3*heads*64, K] */
 int avd_gemm_bf16x3_qkv3_f32(const void* A3, const void* W3, const float* bias, void* qkv3, int64_t M, int tokens,
-                             int heads, int K, float qscale, avd_stream_t stream);
+                             int heads, int K, float qscale, int terms, avd_stream_t stream);
 /* softmax(q k^T) v from a qkv3 image; out3 == NULL: fp32 out [B,N,H*64]; else the split3 image of [B*N, H*64].
  * Rows >= n_query of every sample are not computed and left untouched. */
-int avd_attn_fwd_qkv3_f32(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query,
+int avd_attn_fwd_qkv3_f32(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms,
                           avd_stream_t stream);
 /* C = act(A W^T + bias) (+ residual), A3/W3 split3 images of A [M,K] and W [N,K]; N % 256 == 0, K % 16 == 0.
  * C3 == NULL: fp32 row-major C [M,N], act AVD_ACT_NONE, residual optional (may alias C).
  * C3 != NULL: the result is written as the split3 image of [M,N] instead (bias + AVD_ACT_GELU, no residual). */
 int avd_gemm_bf16x3_f32(const void* A3, const void* W3, const float* bias, const float* residual, float* C, void* C3,
-                        int64_t M, int N, int K, int act, avd_stream_t stream);
+                        int64_t M, int N, int K, int act, int terms, avd_stream_t stream);
 
 /* bytes of scratch avd_core_forward_f32 needs for a [B,N,d] input */
 int64_t avd_core_workspace_bytes(const avd_core_weights* w, int B, int N);
 /* MMDiT.forward(x) -> y, x,y: [B,N,d] (y may alias x).  n_out_rows: number of leading rows per sample whose
  * output is needed (N = reference behaviour; fewer lets the last block skip dead rows when the caller only
- * consumes the first n_out_rows — the engine passes the target-row count). out_row0: first needed row. */
+ * consumes the first n_out_rows — the engine passes the target-row count). out_row0: first needed row.
+ * key_padding_mask: NULL or bytes [B,N], see avd_attn_fwd_f32 (a mask keeps the step on the fp32 kernels). */
 int avd_core_forward_f32(const avd_core_weights* w, const float* x, float* y, int B, int N,
-                         int out_row0, int n_out_rows, void* workspace, int64_t workspace_bytes,
-                         avd_stream_t stream);
+                         int out_row0, int n_out_rows, const uint8_t* key_padding_mask, void* workspace,
+                         int64_t workspace_bytes, avd_stream_t stream);
 
 int64_t avd_head_workspace_bytes(const avd_head_weights* w, int64_t rows);
 /* MultiModalNoiseHead path for ONE modality over `rows` token rows taken from h with segmented addressing:

@@ -16,7 +16,7 @@ import torch
 _HERE = Path(__file__).resolve().parent
 LIB_PATH = Path(os.environ.get("AVDIFF_HIP_LIB", _HERE / "csrc" / "libavdiff_hip.so"))
 
-ACT_NONE, ACT_GELU, ACT_SILU, ACT_TANH = 0, 1, 2, 3
+ACT_NONE, ACT_GELU, ACT_SILU, ACT_TANH, ACT_RELU, ACT_LEAKY_RELU = 0, 1, 2, 3, 4, 5
 EINVAL, EUNSUPPORTED, ELAUNCH, EWORKSPACE = -1, -2, -3, -4
 
 
@@ -36,12 +36,14 @@ class BlockWeights(C.Structure):
         "norm1_scale", "in_proj_weight", "in_proj_bias", "out_proj_weight", "out_proj_bias",
         "norm2_scale", "fc1_weight", "fc1_bias", "fc2_weight", "fc2_bias",
         "in_proj_weight_n", "fc1_weight_n",
-        "in_proj_weight3", "out_proj_weight3", "fc1_weight3", "fc2_weight3")]
+        "in_proj_weight3", "out_proj_weight3", "fc1_weight3", "fc2_weight3",
+        "norm1_bias", "norm2_bias")]
 
 
 class CoreWeights(C.Structure):
     _fields_ = [("d", C.c_int), ("n_layers", C.c_int), ("n_heads", C.c_int), ("mlp_hidden", C.c_int),
-                ("norm_eps", C.c_float), ("blocks", C.POINTER(BlockWeights)), ("final_norm_scale", C.c_void_p)]
+                ("norm_eps", C.c_float), ("blocks", C.POINTER(BlockWeights)), ("final_norm_scale", C.c_void_p),
+                ("norm_kind", C.c_int), ("final_norm_bias", C.c_void_p), ("split_terms", C.c_int)]
 
 
 class HeadWeights(C.Structure):
@@ -81,7 +83,7 @@ class VaeEncodeDesc(C.Structure):
                 ("conv_w3", C.POINTER(C.c_void_p))]
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); must list every symbol include/avdiff_hip.h declares
@@ -93,20 +95,20 @@ SIGNATURES = {
     "avd_gemm_bias_act_f32": (_I, [_P, _L, _P, _P, _P, _L, _P, _L, _L, _I, _I, _I, _P]),
     "avd_gemm_rmsfold_f32": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _I, _F, _P, _P]),
     "avd_tune_set": (_I, [C.c_char_p, _L]),
-    "avd_attn_fwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _F, _I, _P]),
+    "avd_attn_fwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _F, _I, _P, _P]),
     "avd_layernorm_act_f32": (_I, [_P, _P, _P, _P, _L, _I, _F, _I, _P]),
     "avd_timestep_embedding_f32": (_I, [_P, _P, _P, _I, _I, _F, _P]),
     "avd_tube_patch_f32": (_I, [_P, _P] + [_I] * 8 + [_P]),
     "avd_tube_unpatch_f32": (_I, [_P, _P] + [_I] * 8 + [_P]),
     "avd_audio_tokens_f32": (_I, [_P, _P] + [_I] * 5 + [_P]),
-    "avd_audio_untokens_f32": (_I, [_P, _P] + [_I] * 5 + [_P]),
+    "avd_audio_untokens_f32": (_I, [_P, _P, _P] + [_I] * 5 + [_P]),
     "avd_ddim_step_f32": (_I, [_P, _P, _P, _P, _P, _I, _F, _P, _P, _I, _L, _P]),
     "avd_cfg_unpatch_ddim_f32": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _P, _P] + [_I] * 8 + [_P]),
     "avd_cfg_untoken_ddim_audio_f32": (_I, [_P, _P, _P, _P, _P, _I, _F, _F, _P, _P] + [_I] * 5 + [_P]),
     "avd_embed_workspace_floats": (_L, [C.POINTER(EmbedDesc)]),
     "avd_embed_cfg_pair_f32": (_I, [C.POINTER(EmbedDesc), _P, _P, _P, _P, _P, _P, _P, _P]),
     "avd_core_workspace_bytes": (_L, [C.POINTER(CoreWeights), _I, _I]),
-    "avd_core_forward_f32": (_I, [C.POINTER(CoreWeights), _P, _P, _I, _I, _I, _I, _P, _L, _P]),
+    "avd_core_forward_f32": (_I, [C.POINTER(CoreWeights), _P, _P, _I, _I, _I, _I, _P, _P, _L, _P]),
     "avd_head_workspace_bytes": (_L, [C.POINTER(HeadWeights), _L]),
     "avd_head_forward_f32": (_I, [C.POINTER(HeadWeights), _P, _L, _L, _L, _L, _P, _P, _L, _P]),
     "avd_step_workspace_bytes": (_L, [C.POINTER(StepDesc)]),
@@ -117,9 +119,9 @@ SIGNATURES = {
     "avd_rmsnorm_split3_f32": (_I, [_P, _P, _P, _L, _I, _F, _P]),
     "avd_attn_fwd_split3_f32": (_I, [_P, _P, _I, _I, _I, _I, _F, _I, _P]),
     "avd_qkv3_bytes": (_L, [_I, _I, _I]),
-    "avd_gemm_bf16x3_qkv3_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _F, _P]),
-    "avd_attn_fwd_qkv3_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "avd_gemm_bf16x3_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "avd_gemm_bf16x3_qkv3_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _F, _I, _P]),
+    "avd_attn_fwd_qkv3_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "avd_gemm_bf16x3_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "avd_conv3_weight_bytes": (_L, []),
     "avd_conv3_weight_f32": (_I, [_P, _P, _P]),
     "avd_vae_decode_workspace_bytes": (_L, [C.POINTER(VaeDecodeDesc)]),
@@ -179,7 +181,17 @@ def check(rc: int) -> None:
 
 
 def stream_ptr(device: torch.device) -> int:
+    """torch's current stream on `device`.  The library launches on the CURRENT device (one device per call, per-device lazy
+    state inside), so a tensor living on another device than the current one is refused rather than silently mis-launched."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx != torch.cuda.current_device():
+        raise AvdError(f"tensors are on cuda:{idx} but the current device is cuda:{torch.cuda.current_device()}: "
+                       "call torch.cuda.set_device / use torch.cuda.device(...) around the call")
     return torch.cuda.current_stream(device).cuda_stream
+
+
+# matrix-pipe modes of the MMDiT core / engine -> product terms of the split-operand kernels (avd_core_weights.split_terms)
+MATMUL_TERMS = {"f32": 0, "bf16x3": 6, "bf16x3_strict": 9, "bf16": 1}
 
 
 def dev_f32(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:

@@ -25,7 +25,13 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 #define AVD_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define AVD_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
 
-template <bool SPLIT_OUT>   // SPLIT_OUT: the [B*N, H*64] result is written as a split3 image (A operand of out_proj)
+// product terms per k (see S3Terms in gemm_bf16x3.hip): 6 default, 9 strict, 1 plain bf16 operands
+template <int TERMS> struct A3Terms;
+template <> struct A3Terms<6> { static constexpr int N = 6; static constexpr int PA[6] = {2, 0, 1, 1, 0, 0}; static constexpr int PB[6] = {0, 2, 1, 0, 1, 0}; };
+template <> struct A3Terms<9> { static constexpr int N = 9; static constexpr int PA[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}; static constexpr int PB[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}; };
+template <> struct A3Terms<1> { static constexpr int N = 1; static constexpr int PA[1] = {0}; static constexpr int PB[1] = {0}; };
+
+template <bool SPLIT_OUT, int TERMS>   // SPLIT_OUT: the [B*N, H*64] result is written as a split3 image (A operand of out_proj)
 __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsigned char* __restrict__ img, float* __restrict__ out,
                                                                     int Bt, int N, int Npad, int H, int n_query, int nqb) {
     constexpr int NW = A3_NW, ROWB = QKV3_ROWB;
@@ -111,22 +117,22 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
         f32x16 s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-        // (K plane, Q plane) resp. (V plane, P plane): (l,h) (h,l) (m,m) (m,h) (h,m) (h,h)
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+        // (K plane, Q plane) resp. (V plane, P plane), small terms first
+        using TT = A3Terms<TERMS>;
+        constexpr int NPL = TERMS == 1 ? 1 : 3;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bf16x8 ka[3], kb2[3];
             const int ch = ((2 * s + hi) ^ ksw) << 4;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
+            for (int p = 0; p < NPL; ++p) {
                 ka[p] = *reinterpret_cast<const bf16x8*>(Ks + k_rd + p * 128 + ch);
                 kb2[p] = *reinterpret_cast<const bf16x8*>(Ks + k_rd + 32 * ROWB + p * 128 + ch);
             }
 #pragma unroll
-            for (int t = 0; t < 6; ++t) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[PA[t]], qf[s][PB[t]], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[PA[t]], qf[s][PB[t]], s1, 0, 0, 0);
+            for (int t = 0; t < TT::N; ++t) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[TT::PA[t]], qf[s][TT::PB[t]], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[TT::PA[t]], qf[s][TT::PB[t]], s1, 0, 0, 0);
             }
         }
         // K is free once every wave is here; V(kt) (issued a phase ago) has landed after the wait
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pv[j] = kb ? s1[8 * t + j] : s0[8 * t + j];
                 u32x4 P[3];
-                split8(pv, P[0], P[1], P[2]);
+                split8<false>(pv, P[0], P[1], P[2]);
                 bf16x8 pf[3];
 #pragma unroll
                 for (int p = 0; p < 3; ++p) pf[p] = __builtin_bit_cast(bf16x8, P[p]);
@@ -189,7 +195,7 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
                     const int chunk = 4 * db + 2 * cb + (v_p >> 1);
                     bf16x8 vf[3];
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) {
+                    for (int p = 0; p < NPL; ++p) {
                         const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)AVD_LDS_PTR(
                             Vs + key0 * ROWB + p * 128 + ((chunk ^ sw) << 4) + 8 * (v_p & 1)));
                         const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)AVD_LDS_PTR(
@@ -199,9 +205,9 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
                         vf[p] = __builtin_bit_cast(bf16x8, w);
                     }
 #pragma unroll
-                    for (int tt = 0; tt < 6; ++tt) {
-                        if (db == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PA[tt]], pf[PB[tt]], o0, 0, 0, 0);
-                        else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PA[tt]], pf[PB[tt]], o1, 0, 0, 0);
+                    for (int tt = 0; tt < TT::N; ++tt) {
+                        if (db == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[TT::PA[tt]], pf[TT::PB[tt]], o0, 0, 0, 0);
+                        else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[TT::PA[tt]], pf[TT::PB[tt]], o1, 0, 0, 0);
                     }
                 }
             }
@@ -253,7 +259,17 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
 int64_t qkv3_bytes(int B, int N, int H) { return (int64_t)3 * B * H * qkv3_npad(N) * QKV3_ROWB; }
 
 // out3 != null: split3 image of the [B*N, H*64] result; otherwise fp32 out [B, N, H*64]
-int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, hipStream_t st) {
+template <int TERMS>
+static void attn3_launch(const unsigned char* img, float* out, void* out3, int B, int N, int Npad, int H, int n_query, int nqb, hipStream_t st) {
+    if (out3)
+        hipLaunchKernelGGL((attn_bf16x3_kernel<true, TERMS>), dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, static_cast<float*>(out3), B, N,
+                           Npad, H, n_query, nqb);
+    else
+        hipLaunchKernelGGL((attn_bf16x3_kernel<false, TERMS>), dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, out, B, N, Npad, H, n_query, nqb);
+}
+
+int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms, hipStream_t st) {
+    AVD_REQUIRE(terms == 0 || terms == 6 || terms == 9 || terms == 1, AVD_EINVAL, "attn_bf16x3: terms must be 6, 9 or 1, got %d", terms);
     AVD_REQUIRE(qkv3 && (out || out3), AVD_EINVAL, "attn_bf16x3: null pointer");
     AVD_REQUIRE(B > 0 && N > 0 && H > 0, AVD_EINVAL, "attn_bf16x3: bad dims B=%d N=%d H=%d", B, N, H);
     AVD_REQUIRE(n_query >= 0 && n_query <= N, AVD_EINVAL, "attn_bf16x3: n_query=%d outside [0,%d]", n_query, N);
@@ -262,15 +278,13 @@ int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, i
     if (n_query == 0) return AVD_OK;
     const int nqb = (n_query + 32 * A3_NW - 1) / (32 * A3_NW);
     AVD_REQUIRE((int64_t)B * H * nqb < (1ll << 31), AVD_EUNSUPPORTED, "attn_bf16x3: grid too large");
-    static const int tag = prof_tag_id("attn_bf16x3_kernel");
+    const int tag = prof_tag_id("attn_bf16x3_kernel<%d>", terms ? terms : 6);
     ProfScope prof(tag, 4.0 * (double)B * H * (double)n_query * N * A3_DH, st);
     const int Npad = qkv3_npad(N);
     const auto* img = static_cast<const unsigned char*>(qkv3);
-    if (out3)
-        hipLaunchKernelGGL(attn_bf16x3_kernel<true>, dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, static_cast<float*>(out3), B, N, Npad, H,
-                           n_query, nqb);
-    else
-        hipLaunchKernelGGL(attn_bf16x3_kernel<false>, dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, out, B, N, Npad, H, n_query, nqb);
+    if (terms == 9) attn3_launch<9>(img, out, out3, B, N, Npad, H, n_query, nqb, st);
+    else if (terms == 1) attn3_launch<1>(img, out, out3, B, N, Npad, H, n_query, nqb, st);
+    else attn3_launch<6>(img, out, out3, B, N, Npad, H, n_query, nqb, st);
     AVD_CHECK_LAUNCH("attn_bf16x3");
     return AVD_OK;
 }
@@ -281,6 +295,7 @@ extern "C" int64_t avd_qkv3_bytes(int B, int N, int H) {
     if (B <= 0 || N <= 0 || H <= 0) return -1;
     return avd::qkv3_bytes(B, N, H);
 }
-extern "C" int avd_attn_fwd_qkv3_f32(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, avd_stream_t stream) {
-    return avd::attn_bf16x3(qkv3, out, out3, B, N, H, n_query, static_cast<hipStream_t>(stream));
+extern "C" int avd_attn_fwd_qkv3_f32(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms,
+                                     avd_stream_t stream) {
+    return avd::attn_bf16x3(qkv3, out, out3, B, N, H, n_query, terms, static_cast<hipStream_t>(stream));
 }

@@ -32,7 +32,8 @@ constexpr float LOG2E = 1.4426950408889634f;
 
 template <int NW, bool SPLIT = false>   // SPLIT: `out` is the split3 image of the [B*N, d] result (bf16x3 path)
 __global__ __launch_bounds__(NW * 64, 2) void attn_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                              int N, int H, float scale, int n_query, int nqb) {
+                                                              int N, int H, float scale, int n_query, int nqb,
+                                                              const unsigned char* __restrict__ kpm) {
     constexpr int PPW = 16 / NW;       // 1-KiB DMA pieces (4 key rows) per wave per operand per tile
     __shared__ __attribute__((aligned(16))) float Ks[ATT_KT * ATT_DH];
     __shared__ __attribute__((aligned(16))) float Vs[ATT_KT * ATT_DH];
@@ -153,6 +154,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_f32_kernel(const float* __res
                 if (key + 32 >= N) s1[r] = ATT_NEG;
             }
         }
+        if (kpm) {                           // key_padding_mask (mmdt.py:57-60): padded keys get no weight (wave-uniform branch)
+            const unsigned char* mrow = kpm + (int64_t)b * N + kt * ATT_KT;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kl = mfma32_row(r, hi), key = kt * ATT_KT + kl;
+                if (key < N && mrow[kl]) s0[r] = ATT_NEG;
+                if (key + 32 < N && mrow[kl + 32]) s1[r] = ATT_NEG;
+            }
+        }
 
         // ---- online softmax for this lane's query column ----
         float mt = s0[0];
@@ -238,7 +248,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_f32_kernel(const float* __res
 }
 
 template <bool SPLIT>
-static int attn_launch(const float* qkv, float* out, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st) {
+static int attn_launch(const float* qkv, float* out, int B, int N, int H, int Dh, float scale, int n_query, const unsigned char* kpm,
+                       hipStream_t st) {
     AVD_REQUIRE(qkv && out, AVD_EINVAL, "attn: null pointer");
     AVD_REQUIRE(B > 0 && N > 0 && H > 0, AVD_EINVAL, "attn: bad dims B=%d N=%d H=%d", B, N, H);
     AVD_REQUIRE(Dh == ATT_DH, AVD_EUNSUPPORTED, "attn: head_dim %d unsupported (kernel is built for 64)", Dh);
@@ -257,27 +268,28 @@ static int attn_launch(const float* qkv, float* out, int B, int N, int H, int Dh
     const bool use4 = pad4 == pad2;
     ProfScope prof(use4 ? tag4 : tag2, 4.0 * (double)B * H * (double)n_query * N * ATT_DH, st);
     if (use4) {
-        hipLaunchKernelGGL((attn_f32_kernel<4, SPLIT>), dim3((pad4 / 128) * H * B), dim3(256), 0, st, qkv, out, N, H, scale, n_query, pad4 / 128);
+        hipLaunchKernelGGL((attn_f32_kernel<4, SPLIT>), dim3((pad4 / 128) * H * B), dim3(256), 0, st, qkv, out, N, H, scale, n_query, pad4 / 128, kpm);
     } else {
-        hipLaunchKernelGGL((attn_f32_kernel<2, SPLIT>), dim3((pad2 / 64) * H * B), dim3(128), 0, st, qkv, out, N, H, scale, n_query, pad2 / 64);
+        hipLaunchKernelGGL((attn_f32_kernel<2, SPLIT>), dim3((pad2 / 64) * H * B), dim3(128), 0, st, qkv, out, N, H, scale, n_query, pad2 / 64, kpm);
     }
     AVD_CHECK_LAUNCH("attn_f32");
     return AVD_OK;
 }
 
-int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st) {
-    return attn_launch<false>(qkv, out, B, N, H, Dh, scale, n_query, st);
+int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float scale, int n_query, const unsigned char* kpm,
+             hipStream_t st) {
+    return attn_launch<false>(qkv, out, B, N, H, Dh, scale, n_query, kpm, st);
 }
 int attn_f32_split3(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st) {
     AVD_REQUIRE((H * Dh) % 16 == 0, AVD_EUNSUPPORTED, "attn: split3 output needs d %% 16 == 0");
-    return attn_launch<true>(qkv, static_cast<float*>(out3), B, N, H, Dh, scale, n_query, st);
+    return attn_launch<true>(qkv, static_cast<float*>(out3), B, N, H, Dh, scale, n_query, nullptr, st);
 }
 
 }  // namespace avd
 
 extern "C" int avd_attn_fwd_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float scale,
-                                int n_query, avd_stream_t stream) {
-    return avd::attn_f32(qkv, out, B, N, H, Dh, scale, n_query, static_cast<hipStream_t>(stream));
+                                int n_query, const uint8_t* key_padding_mask, avd_stream_t stream) {
+    return avd::attn_f32(qkv, out, B, N, H, Dh, scale, n_query, key_padding_mask, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int avd_attn_fwd_split3_f32(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query,

@@ -102,13 +102,32 @@ __device__ __forceinline__ unsigned int pk_bf16(float a, float b) {
 __device__ __forceinline__ float bf16_lo(unsigned int p) { return __uint_as_float(p << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned int p) { return __uint_as_float(p & 0xffff0000u); }
 
-// v[8] -> three 16-byte chunks of 8 bf16: h = rn(x), m = rn(x - h), l = rn(x - h - m); both residuals are exact in fp32
+// v[8] -> three 16-byte chunks of 8 bf16: h = rn(x), m = rn(x - h), l = rn(x - h - m); both residuals are exact in fp32.
+// Edge of the range (rare, so behind one wave-uniform test): a finite |x| > 0x1.fep127 would round to a bf16 infinity —
+// h keeps the largest finite bf16 instead and the remainder moves to m, the sum is still exact; x = +-inf gives
+// (inf, 0, 0) rather than (inf, NaN, NaN).  NaN stays NaN in every plane.
+template <bool RANGE_CHECK = true>     // false: the caller guarantees |v| far below the top of the range (softmax probabilities)
 __device__ __forceinline__ void split8(const float* v, u32x4& H, u32x4& Mi, u32x4& Lo) {
+    bool edge = false;
+    if constexpr (RANGE_CHECK) {
+        float amax = fabsf(v[0]);
+#pragma unroll
+        for (int e = 1; e < 8; ++e) amax = fmaxf(amax, fabsf(v[e]));    // fmaxf ignores NaN operands
+        edge = __any(amax > 3.3895313892515355e38f);                      // largest finite bf16
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float a = v[2 * e], b = v[2 * e + 1];
-        const unsigned int h = pk_bf16(a, b);
-        const float ra = a - bf16_lo(h), rb = b - bf16_hi(h);
+        unsigned int h = pk_bf16(a, b);
+        float ra = a - bf16_lo(h), rb = b - bf16_hi(h);
+        if (edge) {
+            if ((h & 0x7fffu) == 0x7f80u) {                  // low half became +-inf
+                if (fabsf(a) < __builtin_inff()) { h = (h & 0xffff8000u) | 0x7f7fu; ra = a - bf16_lo(h); } else ra = 0.f;
+            }
+            if ((h & 0x7fff0000u) == 0x7f800000u) {          // high half became +-inf
+                if (fabsf(b) < __builtin_inff()) { h = (h & 0x8000ffffu) | 0x7f7f0000u; rb = b - bf16_hi(h); } else rb = 0.f;
+            }
+        }
         const unsigned int m = pk_bf16(ra, rb);
         const float sa = ra - bf16_lo(m), sb = rb - bf16_hi(m);
         H[e] = h;
@@ -161,7 +180,8 @@ int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, 
                   hipStream_t st);
 int rowss_f32(const float* x, float* ss, int64_t rows, int d, hipStream_t st);
 
-int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st);
+int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float scale, int n_query, const unsigned char* key_padding_mask,
+             hipStream_t st);
 int rmsnorm_f32(const float* x, RowMap xm, const float* scale, float* y, RowMap ym, int64_t rows, int d, float eps,
                 hipStream_t st);
 int layernorm_act_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int d, float eps,
@@ -174,10 +194,10 @@ int rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t ro
 bool gemm_bf16x3_supported(int64_t M, int N, int K);
 int attn_f32_split3(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st);
 int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* img, int64_t M, int tokens, int heads, int K, float qscale,
-                     hipStream_t st);
+                     int terms, hipStream_t st);
 int64_t qkv3_bytes(int B, int N, int H);
-int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, hipStream_t st);
+int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms, hipStream_t st);
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
-                int act, hipStream_t st);
+                int act, int terms, hipStream_t st);
 
 }  // namespace avd

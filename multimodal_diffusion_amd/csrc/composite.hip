@@ -101,7 +101,7 @@ static int64_t g_s3_min_rows = [] { const char* e = getenv("AVD_S3_MIN_ROWS"); r
 static bool g_no_fold = getenv("AVD_NO_FOLD") != nullptr;
 static int64_t split_min_rows() { return g_s3_min_rows; }      // avd_tune_set "s3_min_rows": measurement aid
 static bool core_use_split(const avd_core_weights* w, int64_t M) {
-    if (M < split_min_rows()) return false;
+    if (M < split_min_rows() || w->norm_kind != 0) return false;
     if (!gemm_bf16x3_supported(M, 3 * w->d, w->d) || !gemm_bf16x3_supported(M, w->d, w->d) ||
         !gemm_bf16x3_supported(M, w->mlp_hidden, w->d) || !gemm_bf16x3_supported(M, w->d, w->mlp_hidden))
         return false;
@@ -114,7 +114,7 @@ static bool core_use_split(const avd_core_weights* w, int64_t M) {
 
 // fp32 path with RMSNorm folded into the neighbouring GEMM epilogues: needs the scale-carrying weights and LDS-DMA-able shapes
 static bool core_use_fold(const avd_core_weights* w) {
-    if (g_no_fold) return false;                                   // avd_tune_set "no_fold": measurement aid
+    if (g_no_fold || w->norm_kind != 0) return false;              // avd_tune_set "no_fold": measurement aid
     if (!gemm_f32_fold_supported(3 * w->d, w->d) || !gemm_f32_fold_supported(w->d, w->d) ||
         !gemm_f32_fold_supported(w->mlp_hidden, w->d) || !gemm_f32_fold_supported(w->d, w->mlp_hidden))
         return false;
@@ -144,13 +144,24 @@ static int check_core(const avd_core_weights* w) {
     AVD_REQUIRE(w && w->blocks && w->final_norm_scale, AVD_EINVAL, "core: null weight table");
     AVD_REQUIRE(w->d > 0 && w->n_layers > 0 && w->n_heads > 0 && w->mlp_hidden > 0, AVD_EINVAL, "core: bad dims");
     AVD_REQUIRE(w->d % w->n_heads == 0, AVD_EINVAL, "core: d_model %d not divisible by n_heads %d", w->d, w->n_heads);
+    AVD_REQUIRE(w->norm_kind == 0 || w->norm_kind == 1, AVD_EINVAL, "core: norm_kind must be 0 (RMSNorm) or 1 (LayerNorm)");
     AVD_REQUIRE(w->d / w->n_heads == 64, AVD_EUNSUPPORTED, "core: head_dim %d unsupported (64 only)", w->d / w->n_heads);
     AVD_REQUIRE(w->d % 4 == 0 && w->mlp_hidden % 4 == 0, AVD_EUNSUPPORTED, "core: widths must be multiples of 4");
+    AVD_REQUIRE(w->split_terms == 0 || w->split_terms == 6 || w->split_terms == 9 || w->split_terms == 1, AVD_EINVAL,
+                "core: split_terms must be 0/6 (default), 9 (strict) or 1 (plain bf16), got %d", w->split_terms);
     return AVD_OK;
 }
 
+// norm of the generic path: RMSNorm (mmdt.py:39-42) or, for norm="layernorm", nn.LayerNorm (mmdt.py:44-45)
+static int core_norm(const avd_core_weights* w, const float* x, const float* scale, const float* bias, float* y, int64_t M, hipStream_t st) {
+    const RowMap rd{w->d, 0, 0};
+    if (w->norm_kind == 0) return rmsnorm_f32(x, rd, scale, y, rd, M, w->d, w->norm_eps, st);
+    AVD_REQUIRE(bias, AVD_EINVAL, "core: norm_kind 1 (LayerNorm) needs the bias vectors");
+    return layernorm_act_f32(x, scale, bias, y, M, w->d, w->norm_eps, AVD_ACT_NONE, st);
+}
+
 static int core_forward(const avd_core_weights* w, const float* x, float* y, int B, int N, int out_row0,
-                        int n_out_rows, void* ws, int64_t ws_bytes, hipStream_t st) {
+                        int n_out_rows, const unsigned char* kpm, void* ws, int64_t ws_bytes, hipStream_t st) {
     if (int rc = check_core(w)) return rc;
     AVD_REQUIRE(x && y && B > 0 && N > 0, AVD_EINVAL, "core: bad input");
     AVD_REQUIRE(out_row0 >= 0 && n_out_rows > 0 && out_row0 + n_out_rows <= N, AVD_EINVAL, "core: bad output row window");
@@ -164,8 +175,9 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
     const RowMap rd{d, 0, 0}, r3{3 * d, 0, 0}, rh{hid, 0, 0};
     const float scale = 1.0f / sqrtf((float)(d / H));
     const float* cur = x;                                           // residual stream lives in y after the first write
-    if (core_use_split(w, M)) {
+    if (!kpm && core_use_split(w, M)) {
         // same op sequence with the four projections on the bf16 matrix pipe (gemm_bf16x3.hip); hs / wide3 are split3 images
+        const int terms = w->split_terms;
         Carver cs{static_cast<char*>(ws), 0, ws_bytes};
         const int64_t wide_b = core_split_wide_bytes(w, B, N);
         float* qkv = cs.take((wide_b + 3) / 4);
@@ -176,13 +188,13 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
             const bool last = l == w->n_layers - 1;
             const int nq = (last && out_row0 == 0) ? n_out_rows : N;
             if (int rc = rmsnorm_split3_f32(cur, b.norm1_scale, hs, M, d, w->norm_eps, st)) return rc;
-            if (int rc = gemm_bf16x3_qkv3(hs, b.in_proj_weight3, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, st)) return rc;
-            if (int rc = attn_bf16x3(qkv, nullptr, hs, B, N, H, nq, st)) return rc;
-            if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, nullptr, M, d, d, AVD_ACT_NONE, st)) return rc;
+            if (int rc = gemm_bf16x3_qkv3(hs, b.in_proj_weight3, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, terms, st)) return rc;
+            if (int rc = attn_bf16x3(qkv, nullptr, hs, B, N, H, nq, terms, st)) return rc;
+            if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, nullptr, M, d, d, AVD_ACT_NONE, terms, st)) return rc;
             cur = y;
             if (int rc = rmsnorm_split3_f32(y, b.norm2_scale, hs, M, d, w->norm_eps, st)) return rc;
-            if (int rc = gemm_bf16x3(hs, b.fc1_weight3, b.fc1_bias, nullptr, nullptr, wide3, M, hid, d, AVD_ACT_GELU, st)) return rc;
-            if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, nullptr, M, d, hid, AVD_ACT_NONE, st)) return rc;
+            if (int rc = gemm_bf16x3(hs, b.fc1_weight3, b.fc1_bias, nullptr, nullptr, wide3, M, hid, d, AVD_ACT_GELU, terms, st)) return rc;
+            if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, nullptr, M, d, hid, AVD_ACT_NONE, terms, st)) return rc;
         }
         return rmsnorm_f32(y, rd, w->final_norm_scale, y, rd, M, d, w->norm_eps, st);
     }
@@ -200,7 +212,7 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
             const int nq = (last && out_row0 == 0) ? n_out_rows : N;
             if (int rc = gemm_f32_fold(cur, rd, b.in_proj_weight_n, b.in_proj_bias, nullptr, rd, wide, r3, M, 3 * d, d, AVD_ACT_NONE, ssA,
                                        colsA, sqrt_d, w->norm_eps, nullptr, st)) return rc;
-            if (int rc = attn_f32(wide, hbuf, B, N, H, d / H, scale, nq, st)) return rc;
+            if (int rc = attn_f32(wide, hbuf, B, N, H, d / H, scale, nq, kpm, st)) return rc;
             if (int rc = gemm_f32_fold(hbuf, rd, b.out_proj_weight, b.out_proj_bias, cur, rd, y, rd, M, d, d, AVD_ACT_NONE, nullptr, 0,
                                        1.f, 0.f, ssB, st)) return rc;
             cur = y;
@@ -217,16 +229,16 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
         const bool last = l == w->n_layers - 1;
         // dead-row elimination: after the last block's K/V are formed only the rows the caller consumes matter
         const int nq = (last && out_row0 == 0) ? n_out_rows : N;
-        if (int rc = rmsnorm_f32(cur, rd, b.norm1_scale, hbuf, rd, M, d, w->norm_eps, st)) return rc;
+        if (int rc = core_norm(w, cur, b.norm1_scale, b.norm1_bias, hbuf, M, st)) return rc;
         if (int rc = gemm_f32(hbuf, rd, b.in_proj_weight, b.in_proj_bias, nullptr, rd, wide, r3, M, 3 * d, d, AVD_ACT_NONE, st)) return rc;
-        if (int rc = attn_f32(wide, hbuf, B, N, H, d / H, scale, nq, st)) return rc;
+        if (int rc = attn_f32(wide, hbuf, B, N, H, d / H, scale, nq, kpm, st)) return rc;
         if (int rc = gemm_f32(hbuf, rd, b.out_proj_weight, b.out_proj_bias, cur, rd, y, rd, M, d, d, AVD_ACT_NONE, st)) return rc;
         cur = y;
-        if (int rc = rmsnorm_f32(y, rd, b.norm2_scale, hbuf, rd, M, d, w->norm_eps, st)) return rc;
+        if (int rc = core_norm(w, y, b.norm2_scale, b.norm2_bias, hbuf, M, st)) return rc;
         if (int rc = gemm_f32(hbuf, rd, b.fc1_weight, b.fc1_bias, nullptr, rd, wide, rh, M, hid, d, AVD_ACT_GELU, st)) return rc;
         if (int rc = gemm_f32(wide, rh, b.fc2_weight, b.fc2_bias, y, rd, y, rd, M, d, hid, AVD_ACT_NONE, st)) return rc;
     }
-    return rmsnorm_f32(y, rd, w->final_norm_scale, y, rd, M, d, w->norm_eps, st);
+    return core_norm(w, y, w->final_norm_scale, w->final_norm_bias, y, M, st);
 }
 
 // ---------------------------------------------------------------- MultiModalNoiseHead (one modality path)
@@ -395,8 +407,10 @@ extern "C" int64_t avd_core_workspace_bytes(const avd_core_weights* w, int B, in
     return core_ws_bytes(w, B, N);
 }
 extern "C" int avd_core_forward_f32(const avd_core_weights* w, const float* x, float* y, int B, int N, int out_row0,
-                                    int n_out_rows, void* workspace, int64_t workspace_bytes, avd_stream_t stream) {
-    return core_forward(w, x, y, B, N, out_row0, n_out_rows, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+                                    int n_out_rows, const uint8_t* key_padding_mask, void* workspace, int64_t workspace_bytes,
+                                    avd_stream_t stream) {
+    return core_forward(w, x, y, B, N, out_row0, n_out_rows, key_padding_mask, workspace, workspace_bytes,
+                        static_cast<hipStream_t>(stream));
 }
 
 extern "C" int64_t avd_head_workspace_bytes(const avd_head_weights* w, int64_t rows) {
@@ -449,7 +463,7 @@ extern "C" int avd_denoise_step_f32(const avd_step_desc* s, const float* z, cons
     // head over the target rows only (per-token independent, so skipping prompt rows is exact)
     const RowMap hm{e.d, e.Nt, (int64_t)p.N * e.d};
     if (!s->split_streams) {
-        if (int rc = core_forward(s->core, X2, X2, 2 * e.B, p.N, row0, e.Nt, core_ws, p.core, st)) return rc;
+        if (int rc = core_forward(s->core, X2, X2, 2 * e.B, p.N, row0, e.Nt, nullptr, core_ws, p.core, st)) return rc;
         if (int rc = head_forward(s->head, X2 + (int64_t)row0 * e.d, hm, p.rows, eps2, head_ws, p.head, st)) return rc;
     } else {
         // the cond and null halves are independent until the CFG combine: run them as two kernel chains on two
@@ -465,7 +479,7 @@ extern "C" int avd_denoise_step_f32(const avd_step_desc* s, const float* z, cons
         for (int half = 0; half < 2; ++half) {
             hipStream_t hs = half ? g_aux : st;
             float* xh = X2 + half * half_rows;
-            if (int rc = core_forward(s->core, xh, xh, e.B, p.N, row0, e.Nt, static_cast<char*>(core_ws) + half * hc, hc, hs)) return rc;
+            if (int rc = core_forward(s->core, xh, xh, e.B, p.N, row0, e.Nt, nullptr, static_cast<char*>(core_ws) + half * hc, hc, hs)) return rc;
             if (int rc = head_forward(s->head, xh + (int64_t)row0 * e.d, hm, p.rows / 2, eps2 + half * (p.rows / 2) * p.D,
                                       static_cast<char*>(head_ws) + half * hh, hh, hs)) return rc;
         }

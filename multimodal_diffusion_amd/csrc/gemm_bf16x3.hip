@@ -102,6 +102,7 @@ struct S3Args {
     int N, K, nbn, sm, sn;
     int tokN, tokNpad, heads;   // EPI_QKV3: tokens per sample, padded tokens per sample, heads (N == 3 * heads * 64)
     float qscale;               // EPI_QKV3: factor folded into q before it is split (softmax scale * log2 e)
+    int terms;                  // 6 (default), 9 (strict) or 1 (plain bf16 operands)
 };
 
 template <int N> __device__ __forceinline__ void wait_vm() {
@@ -202,15 +203,26 @@ __device__ __forceinline__ void s3_epilogue(const S3Args& g, f32x16 (&acc)[4][2]
     }
 }
 
+// Product terms kept per k (A plane, B plane), small first.  6: everything down to 2^-16 relative (hh, hm, mh, hl, lh, mm) — the
+// default, error of an fp32 FMA chain.  9: all nine, nothing dropped ("strict": the only rounding left is the fp32 accumulate).
+// 1: hh only — plain bf16 operands with fp32 accumulation, the reduced-precision variant BASELINE config C2 names (error is
+// reported against the fp32 result, never a parity path); it also moves only the h plane from global memory.
+template <int TERMS> struct S3Terms;
+template <> struct S3Terms<6> { static constexpr int N = 6; static constexpr int PA[6] = {2, 0, 1, 1, 0, 0}; static constexpr int PB[6] = {0, 2, 1, 0, 1, 0}; };
+template <> struct S3Terms<9> { static constexpr int N = 9; static constexpr int PA[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}; static constexpr int PB[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}; };
+template <> struct S3Terms<1> { static constexpr int N = 1; static constexpr int PA[1] = {0}; static constexpr int PB[1] = {0}; };
+
 constexpr int S3_BM = 256, S3_BN = 256, S3_NST = 3;
 constexpr int S3_STAGE = (S3_BM + S3_BN) * 96;          // 48 KiB
 constexpr int S3_LDS = S3_NST * S3_STAGE;                // 144 KiB (the epilogue slabs, 8 x 64 x 68 floats, fit inside)
 
-template <int EPI>
+template <int EPI, int TERMS>
 __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
     constexpr int BM = S3_BM, BN = S3_BN, WM = 128, WN = 64;
     constexpr int TM = 4, TN = 2, NST = S3_NST, STAGE = S3_STAGE;
-    constexpr int PPW = 6;                                // 48 one-KiB pieces per stage / 8 waves
+    constexpr int NPL = TERMS == 1 ? 1 : 3;               // planes moved and read
+    constexpr int PPR = 4 * NPL;                          // one-KiB pieces per 128-row region per stage
+    constexpr int PPW = 4 * PPR / 8;                      // 4 regions per stage / 8 waves
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
     int wg;
@@ -232,25 +244,28 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
     const int ng = g.K >> 4;
     const int nrtA = (int)((g.M + 127) >> 7);
 
-    // DMA: the stage image is [A row-tile 0 | A row-tile 1 | W row-tile 0 | W row-tile 1], 12 pieces of 1 KiB each
+    // DMA: the stage image is [A row-tile 0 | A row-tile 1 | W row-tile 0 | W row-tile 1], each a 12 KiB chunk of which the
+    // first NPL planes (4 KiB each) are moved
     const unsigned char* src[PPW];
+    int dst_off[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int q = wave * PPW + i;
-        const int region = q / 12, within = (q % 12) * 1024 + lane * 16;
+        const int region = q / PPR, within = (q % PPR) * 1024;
+        dst_off[i] = region * S3_CHUNK + within;
         if (region < 2) {
             int rt = bm * 2 + region;
             rt = rt < nrtA ? rt : nrtA - 1;
-            src[i] = g.A + (int64_t)rt * ng * S3_CHUNK + within;
+            src[i] = g.A + (int64_t)rt * ng * S3_CHUNK + within + lane * 16;
         } else {
-            src[i] = g.W + (int64_t)(bn * 2 + region - 2) * ng * S3_CHUNK + within;
+            src[i] = g.W + (int64_t)(bn * 2 + region - 2) * ng * S3_CHUNK + within + lane * 16;
         }
     }
     auto issue = [&](int kt, int buf) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(src[i] + (int64_t)kt * S3_CHUNK),
-                                             AVD_LDS_PTR(smem3 + buf * STAGE + (wave * PPW + i) * 1024), 16, 0, 0);
+                                             AVD_LDS_PTR(smem3 + buf * STAGE + dst_off[i]), 16, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -277,6 +292,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
     issue(0, 0);
     if (nk > 1) issue(1, 1);
     int cur = 0, nxt = NST - 1;
+    using TT = S3Terms<TERMS>;
     for (int kt = 0; kt < nk; ++kt) {
         if (kt + NST - 1 <= nk) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>();
         asm volatile("s_barrier" ::: "memory");   // no fence: a fence would drain vmcnt and with it the tiles in flight
@@ -284,25 +300,22 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
         const unsigned char* st = smem3 + cur * STAGE;
         cur = cur + 1 == NST ? 0 : cur + 1;
         nxt = nxt + 1 == NST ? 0 : nxt + 1;
-        bf16x8 af[TM][3], bf[TN][3];
+        bf16x8 af[TM][NPL], bf[TN][NPL];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + S3_PLANE * p);
+            for (int p = 0; p < NPL; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + S3_PLANE * p);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + S3_PLANE * p);
-        // (l,h) (h,l) (m,m) (m,h) (h,m) (h,h): small terms first
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+            for (int p = 0; p < NPL; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + S3_PLANE * p);
 #pragma unroll
-        for (int t = 0; t < 6; ++t)
+        for (int t = 0; t < TT::N; ++t)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[j][PB[t]], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TT::PA[t]], bf[j][TT::PB[t]], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
 
@@ -319,11 +332,13 @@ constexpr int S3B_BM = 256, S3B_BN = 128;
 constexpr int S3B_STAGE = (S3B_BM + S3B_BN) * 96;        // 36 KiB
 constexpr int S3B_LDS = 2 * S3B_STAGE;                    // 72 KiB (4 epilogue slabs of 64 x 68 floats fit inside)
 
-template <int EPI>
+template <int EPI, int TERMS>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
     constexpr int BM = S3B_BM, BN = S3B_BN, WM = 128, WN = 64;
     constexpr int TM = 4, TN = 2, STAGE = S3B_STAGE;
-    constexpr int PPW = 9;                                // 36 one-KiB pieces per stage / 4 waves
+    constexpr int NPL = TERMS == 1 ? 1 : 3;
+    constexpr int PPR = 4 * NPL;                          // one-KiB pieces per 128-row region per stage
+    constexpr int PPW = 3 * PPR / 4;                      // 3 regions per stage / 4 waves
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
     int wg;
@@ -344,25 +359,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
     const int ng = g.K >> 4;
     const int nrtA = (int)((g.M + 127) >> 7);
 
-    // stage image [A row-tile 0 | A row-tile 1 | W row-tile], 12 one-KiB pieces each
+    // stage image [A row-tile 0 | A row-tile 1 | W row-tile], 12 KiB chunks of which the first NPL planes are moved
     const unsigned char* src[PPW];
+    int dst_off[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int q = wave * PPW + i;
-        const int region = q / 12, within = (q % 12) * 1024 + lane * 16;
+        const int region = q / PPR, within = (q % PPR) * 1024;
+        dst_off[i] = region * S3_CHUNK + within;
         if (region < 2) {
             int rt = bm * 2 + region;
             rt = rt < nrtA ? rt : nrtA - 1;
-            src[i] = g.A + (int64_t)rt * ng * S3_CHUNK + within;
+            src[i] = g.A + (int64_t)rt * ng * S3_CHUNK + within + lane * 16;
         } else {
-            src[i] = g.W + (int64_t)bn * ng * S3_CHUNK + within;
+            src[i] = g.W + (int64_t)bn * ng * S3_CHUNK + within + lane * 16;
         }
     }
     auto issue = [&](int kt, int buf) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i)
             __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(src[i] + (int64_t)kt * S3_CHUNK),
-                                             AVD_LDS_PTR(smem3 + buf * STAGE + (wave * PPW + i) * 1024), 16, 0, 0);
+                                             AVD_LDS_PTR(smem3 + buf * STAGE + dst_off[i]), 16, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -395,8 +412,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
     asm volatile("s_barrier" ::: "memory");
     if (nk > 1) issue(1, 1);
     bf16x8 ah[TM], am[TM], al[TM], bh[TN], bmm[TN], bl[TN];
-    S3_LDA(ah, smem3, 0); S3_LDA(am, smem3, 1); S3_LDA(al, smem3, 2);
-    S3_LDB(bh, smem3, 0); S3_LDB(bmm, smem3, 1); S3_LDB(bl, smem3, 2);
+    S3_LDA(ah, smem3, 0);
+    S3_LDB(bh, smem3, 0);
+    if constexpr (TERMS != 1) {
+        S3_LDA(am, smem3, 1); S3_LDA(al, smem3, 2);
+        S3_LDB(bmm, smem3, 1); S3_LDB(bl, smem3, 2);
+    }
 
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt+1 has landed in stage (kt+1)&1; stage kt&1 (whose fragments are in registers) is free for tile kt+2
@@ -406,28 +427,49 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
         const unsigned char* nx = smem3 + ((kt + 1) & 1) * STAGE;
         bf16x8 ah_n[TM], bl_n[TN];
         __builtin_amdgcn_sched_barrier(0);
-        S3_MM(am, bmm);                    // (m,m)
-        S3_LDA(ah_n, nx, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        S3_MM(am, bh);                     // (m,h)  -> am dead
-        S3_LDA(am, nx, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        S3_MM(al, bh);                     // (l,h)  -> al dead
-        S3_LDA(al, nx, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        S3_MM(ah, bh);                     // (h,h)  -> bh dead
-        S3_LDB(bh, nx, 0);
-        S3_LDB(bl_n, nx, 2);
-        __builtin_amdgcn_sched_barrier(0);
-        S3_MM(ah, bmm);                    // (h,m)  -> bmm dead
-        S3_LDB(bmm, nx, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        S3_MM(ah, bl);                     // (h,l)  -> ah, bl dead
-        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (TERMS == 1) {
+            bf16x8 bh_n[TN];
+            S3_LDA(ah_n, nx, 0);
+            S3_LDB(bh_n, nx, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            S3_MM(ah, bh);                     // (h,h)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bh[j] = bh_n[j];
+        } else {
+            S3_MM(am, bmm);                    // (m,m)
+            S3_LDA(ah_n, nx, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (TERMS == 9) {
+                S3_MM(am, bl);                 // (m,l)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            S3_MM(am, bh);                     // (m,h)  -> am dead
+            S3_LDA(am, nx, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (TERMS == 9) {
+                S3_MM(al, bl);                 // (l,l)
+                __builtin_amdgcn_sched_barrier(0);
+                S3_MM(al, bmm);                // (l,m)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            S3_MM(al, bh);                     // (l,h)  -> al dead
+            S3_LDA(al, nx, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            S3_MM(ah, bh);                     // (h,h)  -> bh dead
+            S3_LDB(bh, nx, 0);
+            S3_LDB(bl_n, nx, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            S3_MM(ah, bmm);                    // (h,m)  -> bmm dead
+            S3_LDB(bmm, nx, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            S3_MM(ah, bl);                     // (h,l)  -> ah, bl dead
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bl[j] = bl_n[j];
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) ah[i] = ah_n[i];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bl[j] = bl_n[j];
     }
 #undef S3_LDA
 #undef S3_LDB
@@ -492,12 +534,13 @@ static int s3_tile_for(int epi, int64_t M, int N) {
     return (M + 255) / 256 * (N / 256) >= 192 ? 0 : 1;
 }
 
-template <int EPI>
-static int launch_s3(const S3Args& a, hipStream_t st) {
+template <int EPI, int TERMS>
+static int launch_s3t(const S3Args& a, hipStream_t st) {
     const int tile = s3_tile_for(EPI, a.M, a.N);
     const int BMt = tile ? S3B_BM : S3_BM, BNt = tile ? S3B_BN : S3_BN, lds = tile ? S3B_LDS : S3_LDS;
     static LdsAttr attr[2];
-    const void* kern = tile ? reinterpret_cast<const void*>(gemm_bf16x3_b_kernel<EPI>) : reinterpret_cast<const void*>(gemm_bf16x3_kernel<EPI>);
+    const void* kern = tile ? reinterpret_cast<const void*>(gemm_bf16x3_b_kernel<EPI, TERMS>)
+                            : reinterpret_cast<const void*>(gemm_bf16x3_kernel<EPI, TERMS>);
     if (int rc = attr[tile].ensure(kern, lds, "gemm_bf16x3")) return rc;
     S3Args g = a;
     g.nbn = a.N / BNt;
@@ -518,25 +561,35 @@ static int launch_s3(const S3Args& a, hipStream_t st) {
     const int64_t nbm = (a.M + BMt - 1) / BMt;
     const int64_t nwg = (nbm + g.sm - 1) / g.sm * g.sm * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
-    static const int tag0 = prof_tag_id("gemm_bf16x3_kernel<%d>", EPI), tag1 = prof_tag_id("gemm_bf16x3_b_kernel<%d>", EPI);
+    static const int tag0 = prof_tag_id("gemm_bf16x3_kernel<%d, %d>", EPI, TERMS), tag1 = prof_tag_id("gemm_bf16x3_b_kernel<%d, %d>", EPI, TERMS);
     ProfScope prof(tile ? tag1 : tag0, 2.0 * (double)a.M * a.N * a.K, st);
-    if (tile) hipLaunchKernelGGL(gemm_bf16x3_b_kernel<EPI>, dim3((unsigned)nwg), dim3(256), lds, st, g);
-    else hipLaunchKernelGGL(gemm_bf16x3_kernel<EPI>, dim3((unsigned)nwg), dim3(512), lds, st, g);
+    if (tile) hipLaunchKernelGGL((gemm_bf16x3_b_kernel<EPI, TERMS>), dim3((unsigned)nwg), dim3(256), lds, st, g);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI, TERMS>), dim3((unsigned)nwg), dim3(512), lds, st, g);
     AVD_CHECK_LAUNCH("gemm_bf16x3");
     return AVD_OK;
+}
+
+template <int EPI>
+static int launch_s3(const S3Args& a, hipStream_t st) {
+    switch (a.terms) {
+        case 0: case 6: return launch_s3t<EPI, 6>(a, st);
+        case 9: return launch_s3t<EPI, 9>(a, st);
+        case 1: return launch_s3t<EPI, 1>(a, st);
+        default: return set_error(AVD_EINVAL, "gemm_bf16x3: terms must be 6 (default), 9 (strict) or 1 (plain bf16), got %d", a.terms);
+    }
 }
 
 // C = act(A W^T + bias) (+ residual).  C3 != null: the output is written as a split3 image (act must be GELU);
 // otherwise fp32 row-major into C (act NONE; residual optional, may alias C).
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
-                int act, hipStream_t st) {
+                int act, int terms, hipStream_t st) {
     AVD_REQUIRE(A3 && W3 && (C || C3), AVD_EINVAL, "gemm_bf16x3: null pointer");
     AVD_REQUIRE(gemm_bf16x3_supported(M, N, K), AVD_EUNSUPPORTED, "gemm_bf16x3: need N %% 256 == 0 and K %% 16 == 0 (M=%lld N=%d K=%d)",
                 (long long)M, N, K);
     AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(C) && aligned16(C3) && aligned16(bias) && aligned16(R), AVD_EUNSUPPORTED,
                 "gemm_bf16x3: pointers must be 16-byte aligned");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, R, C,
-             static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0, 0, 0, 0, 0.f};
+             static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0, 0, 0, 0, 0.f, terms};
     if (C3) {
         AVD_REQUIRE(act == AVD_ACT_GELU && !R && bias, AVD_EUNSUPPORTED, "gemm_bf16x3: split3 output implies bias + GELU, no residual");
         return launch_s3<S3_EPI_GELU_SPLIT>(a, st);
@@ -548,7 +601,7 @@ int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* 
 
 // in_proj for the bf16x3 attention: qkv = A W^T + bias written as the qkv3 image (q pre-multiplied by qscale)
 int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* img, int64_t M, int tokens, int heads, int K, float qscale,
-                     hipStream_t st) {
+                     int terms, hipStream_t st) {
     AVD_REQUIRE(A3 && W3 && bias && img, AVD_EINVAL, "gemm_bf16x3_qkv3: null pointer");
     const int N = 3 * heads * 64;
     AVD_REQUIRE(tokens > 0 && heads > 0 && M > 0 && M % tokens == 0, AVD_EINVAL, "gemm_bf16x3_qkv3: rows %lld not a multiple of tokens %d",
@@ -556,7 +609,7 @@ int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* im
     AVD_REQUIRE(gemm_bf16x3_supported(M, N, K), AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: need 3*heads*64 %% 256 == 0 and K %% 16 == 0");
     AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(bias) && aligned16(img), AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: alignment");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, nullptr, nullptr,
-             static_cast<unsigned char*>(img), M, N, K, 0, 0, 0, tokens, qkv3_npad(tokens), heads, qscale};
+             static_cast<unsigned char*>(img), M, N, K, 0, 0, 0, tokens, qkv3_npad(tokens), heads, qscale, terms};
     return launch_s3<S3_EPI_QKV3>(a, st);
 }
 
@@ -576,10 +629,10 @@ extern "C" int avd_rmsnorm_split3_f32(const float* x, const float* scale, void* 
     return rmsnorm_split3_f32(x, scale, out, rows, d, eps, static_cast<hipStream_t>(stream));
 }
 extern "C" int avd_gemm_bf16x3_f32(const void* A3, const void* W3, const float* bias, const float* residual, float* C, void* C3,
-                                   int64_t M, int N, int K, int act, avd_stream_t stream) {
-    return gemm_bf16x3(A3, W3, bias, residual, C, C3, M, N, K, act, static_cast<hipStream_t>(stream));
+                                   int64_t M, int N, int K, int act, int terms, avd_stream_t stream) {
+    return gemm_bf16x3(A3, W3, bias, residual, C, C3, M, N, K, act, terms, static_cast<hipStream_t>(stream));
 }
 extern "C" int avd_gemm_bf16x3_qkv3_f32(const void* A3, const void* W3, const float* bias, void* qkv3, int64_t M, int tokens, int heads,
-                                        int K, float qscale, avd_stream_t stream) {
-    return gemm_bf16x3_qkv3(A3, W3, bias, qkv3, M, tokens, heads, K, qscale, static_cast<hipStream_t>(stream));
+                                        int K, float qscale, int terms, avd_stream_t stream) {
+    return gemm_bf16x3_qkv3(A3, W3, bias, qkv3, M, tokens, heads, K, qscale, terms, static_cast<hipStream_t>(stream));
 }

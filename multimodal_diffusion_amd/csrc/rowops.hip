@@ -44,9 +44,9 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const float* x, RowMap xm,
 }
 
 template <int NV>
-__global__ __launch_bounds__(256) void layernorm_act_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(256) void layernorm_act_kernel(const float* x,          // y may alias x (in-place)
                                                             const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float* __restrict__ y,
+                                                            const float* __restrict__ beta, float* y,
                                                             int64_t rows, int d, float eps, int act) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -90,6 +90,8 @@ __global__ __launch_bounds__(256) void layernorm_act_kernel(const float* __restr
                 float t = (v[i][e] - mean) * rstd * gm[e] + bt[e];
                 if (act == AVD_ACT_GELU) t = gelu_erf(t);
                 else if (act == AVD_ACT_SILU) t = silu(t);
+                else if (act == AVD_ACT_RELU) t = fmaxf(t, 0.f);
+                else if (act == AVD_ACT_LEAKY_RELU) t = t > 0.f ? t : 0.1f * t;       // nn.LeakyReLU(0.1), noise_heads.py:34
                 o[e] = t;
             }
             *reinterpret_cast<f32x4*>(yr + c) = o;

@@ -121,23 +121,32 @@ __global__ void audio_tok_kernel(const float* __restrict__ z, float* __restrict_
     tok[i] = z[((int64_t)b * Ca + c) * F + n * stride + j];
 }
 
-// overlap-add value for frame f (f < L): windows summed in increasing window order, divided by the count
+// overlap-add value for frame f (f < L): windows summed in increasing window order, divided by the summed window weights
+// (win == nullptr: rectangular window, i.e. the overlap count; otherwise ops.py:76-93 with apply_hann — multiply and add are
+// rounded separately like the reference's `y += windows * win`)
 __device__ __forceinline__ float ola_gather(const float* __restrict__ tokb, int D, int c, int len, int stride, int Na,
-                                            int f) {
+                                            int f, const float* __restrict__ win = nullptr) {
     int n_hi = f / stride;
     if (n_hi > Na - 1) n_hi = Na - 1;
     int n_lo = (f - len + stride) / stride;   // ceil((f-len+1)/stride)
     if (f - len + 1 <= 0) n_lo = 0;
     float acc = 0.f, cnt = 0.f;
     for (int n = n_lo; n <= n_hi; ++n) {
-        acc += tokb[(int64_t)n * D + c * len + (f - n * stride)];
-        cnt += 1.f;
+        const int j = f - n * stride;
+        const float v = tokb[(int64_t)n * D + c * len + j];
+        if (win) {
+            acc = __fadd_rn(acc, __fmul_rn(v, win[j]));
+            cnt += win[j];
+        } else {
+            acc += v;
+            cnt += 1.f;
+        }
     }
     return acc / fmaxf(cnt, 1e-8f);
 }
 
 __global__ void audio_untok_kernel(const float* __restrict__ tok, float* __restrict__ z, int B, int Ca, int F, int len,
-                                   int stride, int Na) {
+                                   int stride, int Na, const float* __restrict__ win) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)B * Ca * F) return;
     const int f = (int)(i % F);
@@ -145,7 +154,7 @@ __global__ void audio_untok_kernel(const float* __restrict__ tok, float* __restr
     const int b = (int)(i / ((int64_t)F * Ca));
     const int L = (Na - 1) * stride + len;
     const int D = Ca * len;
-    z[i] = f < L ? ola_gather(tok + (int64_t)b * Na * D, D, c, len, stride, Na, f) : 0.f;
+    z[i] = f < L ? ola_gather(tok + (int64_t)b * Na * D, D, c, len, stride, Na, f, win) : 0.f;
 }
 
 static int audio_na(int F, int len, int stride) { return (F - len) / stride + 1; }
@@ -162,13 +171,13 @@ int audio_tokens_f32(const float* z, float* tok, int B, int Ca, int F, int len, 
     return AVD_OK;
 }
 
-int audio_untokens_f32(const float* tok, float* z, int B, int Ca, int F, int len, int stride, hipStream_t st) {
+int audio_untokens_f32(const float* tok, const float* win, float* z, int B, int Ca, int F, int len, int stride, hipStream_t st) {
     AVD_REQUIRE(z && tok && B > 0 && Ca > 0, AVD_EINVAL, "audio_untokens: bad arguments");
     AVD_REQUIRE(len > 0 && stride > 0 && F >= len, AVD_EUNSUPPORTED, "audio_untokens: bad chunking");
     const int Na = audio_na(F, len, stride);
     const int64_t n = (int64_t)B * Ca * F;
     hipLaunchKernelGGL(audio_untok_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tok, z, B, Ca, F, len,
-                       stride, Na);
+                       stride, Na, win);
     AVD_CHECK_LAUNCH("audio_untokens");
     return AVD_OK;
 }
@@ -408,9 +417,9 @@ extern "C" int avd_audio_tokens_f32(const float* z, float* tok, int B, int Ca, i
                                     avd_stream_t stream) {
     return audio_tokens_f32(z, tok, B, Ca, F, len, stride, static_cast<hipStream_t>(stream));
 }
-extern "C" int avd_audio_untokens_f32(const float* tok, float* z, int B, int Ca, int F, int len, int stride,
+extern "C" int avd_audio_untokens_f32(const float* tok, const float* window, float* z, int B, int Ca, int F, int len, int stride,
                                       avd_stream_t stream) {
-    return audio_untokens_f32(tok, z, B, Ca, F, len, stride, static_cast<hipStream_t>(stream));
+    return audio_untokens_f32(tok, window, z, B, Ca, F, len, stride, static_cast<hipStream_t>(stream));
 }
 extern "C" int avd_ddim_step_f32(const float* x_t, const float* eps_hat, const int64_t* t_now, const int64_t* t_prev,
                                  const float* alpha_bar, int T_train, float eta, const float* noise, float* x_prev,

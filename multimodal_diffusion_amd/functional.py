@@ -66,16 +66,31 @@ def linear_rmsfold(x: Tensor, weight_n: Tensor, bias: Optional[Tensor] = None, a
     return y, ss_out
 
 
-def attention(qkv: Tensor, n_heads: int, n_query: Optional[int] = None) -> Tensor:
+def key_padding_bytes(mask: Optional[Tensor], B: int, N: int, device: torch.device) -> Optional[Tensor]:
+    """nn.MultiheadAttention's key_padding_mask ([B,N], True / non-zero = ignore this key) as the uint8 table the kernels read.
+    Float masks (additive) are not supported: the reference documents the boolean form (mmdt.py:120-123)."""
+    if mask is None:
+        return None
+    if mask.is_floating_point():
+        raise NotImplementedError("key_padding_mask must be boolean / integer (True = padding), as MMDiT.forward documents")
+    if tuple(mask.shape) != (B, N):
+        raise RuntimeError(f"key_padding_mask shape {tuple(mask.shape)} != {(B, N)}")
+    if not mask.is_cuda:
+        raise L.AvdError("key_padding_mask must be on the ROCm device (no CPU fallback)")
+    return (mask != 0).to(torch.uint8).contiguous()
+
+
+def attention(qkv: Tensor, n_heads: int, n_query: Optional[int] = None, key_padding_mask: Optional[Tensor] = None) -> Tensor:
     """softmax(q k^T / sqrt(Dh)) v over packed qkv [B,N,3d] -> [B,N,d] (head_dim must be 64)."""
     qkv = L.dev_f32(qkv, "qkv")
     B, N, d3 = qkv.shape
+    kpm = key_padding_bytes(key_padding_mask, B, N, qkv.device)
     d = d3 // 3
     dh = d // n_heads
     out = torch.empty(B, N, d, device=qkv.device, dtype=torch.float32) if n_query in (None, N) else \
         torch.zeros(B, N, d, device=qkv.device, dtype=torch.float32)
     L.check(L.lib().avd_attn_fwd_f32(qkv.data_ptr(), out.data_ptr(), B, N, n_heads, dh, 1.0 / math.sqrt(dh),
-                                     N if n_query is None else n_query, _st(qkv)))
+                                     N if n_query is None else n_query, L.ptr(kpm), _st(qkv)))
     return out
 
 
@@ -146,14 +161,17 @@ def audio_tokens(z_a: Tensor, length: int, stride: int) -> Tensor:
     return tok
 
 
-def audio_untokens(tokens: Tensor, Ca: int, length: int, frames: int, stride: int) -> Tensor:
+def audio_untokens(tokens: Tensor, Ca: int, length: int, frames: int, stride: int, window: Optional[Tensor] = None) -> Tensor:
     tokens = L.dev_f32(tokens, "tokens")
+    if window is not None:
+        window = L.dev_f32(window, "window")
+        assert window.numel() == length
     B, na, D = tokens.shape
     assert D == Ca * length
     if na != (frames - length) // stride + 1:
         raise L.AvdError("audio_untokens: token count does not match (frames, length, stride)")
     z = torch.empty(B, Ca, frames, device=tokens.device, dtype=torch.float32)
-    L.check(L.lib().avd_audio_untokens_f32(tokens.data_ptr(), z.data_ptr(), B, Ca, frames, length, stride, _st(z)))
+    L.check(L.lib().avd_audio_untokens_f32(tokens.data_ptr(), L.ptr(window), z.data_ptr(), B, Ca, frames, length, stride, _st(z)))
     return z
 
 
@@ -207,9 +225,9 @@ def rmsnorm_split3(x: Tensor, scale: Tensor, eps: float = 1e-6) -> Tensor:
 
 
 def linear_bf16x3(x3: Tensor, rows: int, w3: Tensor, n: int, k: int, bias: Optional[Tensor] = None,
-                  residual: Optional[Tensor] = None, act: int = L.ACT_NONE, out_split3: bool = False) -> Tensor:
+                  residual: Optional[Tensor] = None, act: int = L.ACT_NONE, out_split3: bool = False, terms: int = 6) -> Tensor:
     """act(x @ W.T + bias) + residual with both operands given as split3 images; fp32 [rows, n] result, or its split3
-    image when out_split3 (bias + GELU only)."""
+    image when out_split3 (bias + GELU only).  terms: 6 default, 9 strict (nothing dropped), 1 plain bf16 operands."""
     b = None if bias is None else L.dev_f32(bias, "bias")
     r = None if residual is None else L.dev_f32(residual, "residual")
     if out_split3:
@@ -218,5 +236,5 @@ def linear_bf16x3(x3: Tensor, rows: int, w3: Tensor, n: int, k: int, bias: Optio
     else:
         out = torch.empty(rows, n, dtype=torch.float32, device=x3.device)
         c, c3 = out.data_ptr(), None
-    L.check(L.lib().avd_gemm_bf16x3_f32(x3.data_ptr(), w3.data_ptr(), L.ptr(b), L.ptr(r), c, c3, rows, n, k, act, _st(x3)))
+    L.check(L.lib().avd_gemm_bf16x3_f32(x3.data_ptr(), w3.data_ptr(), L.ptr(b), L.ptr(r), c, c3, rows, n, k, act, terms, _st(x3)))
     return out

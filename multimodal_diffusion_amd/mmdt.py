@@ -32,10 +32,16 @@ class RMSNorm(nn.Module):
         return Fn.rmsnorm(x, self.scale, self.eps)
 
 
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm as a parameter container (state_dict keys ``weight`` / ``bias``, eps 1e-5) with the HIP kernel underneath —
+    what ``build_norm`` returns for anything but "rmsnorm" (mmdt.py:44-45)."""
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return Fn.layernorm_act(x, self.weight, self.bias, eps=self.eps, act=L.ACT_NONE)
+
+
 def build_norm(kind: str, d: int) -> nn.Module:
-    if kind.lower() != "rmsnorm":
-        raise NotImplementedError("the HIP path implements norm='rmsnorm' (every shipped reference config uses it)")
-    return RMSNorm(d)
+    return RMSNorm(d) if kind.lower() == "rmsnorm" else LayerNorm(d)
 
 
 class _OutProj(nn.Module):
@@ -71,13 +77,13 @@ class MHA(nn.Module):
         self.attn_dropout, self.resid_dropout = attn_dropout, resid_dropout
 
     def forward(self, x, attn_mask=None, key_padding_mask=None, residual=None):
-        if attn_mask is not None or key_padding_mask is not None:
-            raise NotImplementedError("masks are never passed on the sampler path (sample_clip.py:374,378)")
+        if attn_mask is not None:
+            raise NotImplementedError("attn_mask is always None in the reference (MMDiT.forward passes attn_mask=None, mmdt.py:147)")
         if self.training and (self.attn_dropout > 0 or self.resid_dropout > 0):
             raise NotImplementedError("HIP path is inference-only; call .eval()")
         m = self.mha
         qkv = Fn.linear(x, m.in_proj_weight, m.in_proj_bias)
-        o = Fn.attention(qkv, m.num_heads)
+        o = Fn.attention(qkv, m.num_heads, key_padding_mask=key_padding_mask)
         return Fn.linear(o, m.out_proj.weight, m.out_proj.bias, residual=residual)
 
 
@@ -147,8 +153,9 @@ class MMDiT(nn.Module):
                                      for _ in range(n_layers)])
         self.final_norm = build_norm(norm, d_model)
         self._ws: Optional[torch.Tensor] = None
-        # "f32": fp32 MFMA everywhere.  "bf16x3": the four projections of every block run on the bf16 matrix pipe with
-        # exactly split operands (fp32-level error, csrc/gemm_bf16x3.hip) whenever the batch is large enough.
+        # "f32": fp32 MFMA everywhere.  "bf16x3": the four projections of every block and the attention run on the bf16 matrix
+        # pipe with exactly split operands (fp32-level error, csrc/gemm_bf16x3.hip) whenever the batch is large enough;
+        # "bf16x3_strict" keeps all nine product terms; "bf16" keeps one (plain bf16 operands — reduced precision, config C2).
         self.matmul = "f32"
         self.fold_norms = True        # fp32 path: fold norm1 / norm2 into the neighbouring Linear epilogues (same math, one pass less)
         self._split3: dict = {}
@@ -178,55 +185,64 @@ class MMDiT(nn.Module):
 
     # ---- pointer table for the composite (rebuilt per call: parameters may have moved) ----
     def weight_table(self):
-        dev = self.final_norm.scale.device
+        dev = next(self.final_norm.parameters()).device
         arr = (L.BlockWeights * len(self.blocks))()
         keep = []
         for i, b in enumerate(self.blocks):
-            ps = dict(norm1_scale=b.norm1.scale, in_proj_weight=b.attn.mha.in_proj_weight,
+            ln = isinstance(b.norm1, LayerNorm)
+            ps = dict(norm1_scale=b.norm1.weight if ln else b.norm1.scale, in_proj_weight=b.attn.mha.in_proj_weight,
                       in_proj_bias=b.attn.mha.in_proj_bias, out_proj_weight=b.attn.mha.out_proj.weight,
-                      out_proj_bias=b.attn.mha.out_proj.bias, norm2_scale=b.norm2.scale,
+                      out_proj_bias=b.attn.mha.out_proj.bias, norm2_scale=b.norm2.weight if ln else b.norm2.scale,
                       fc1_weight=b.mlp.fc1.weight, fc1_bias=b.mlp.fc1.bias,
                       fc2_weight=b.mlp.fc2.weight, fc2_bias=b.mlp.fc2.bias)
+            if ln:
+                ps.update(norm1_bias=b.norm1.bias, norm2_bias=b.norm2.bias)
             for k, p in ps.items():
                 t = L.dev_f32(p.detach(), k)
                 if t.device != dev:
                     raise L.AvdError("all MMDiT parameters must live on one device")
                 keep.append(t)
                 setattr(arr[i], k, t.data_ptr())
-            if self.fold_norms and self.matmul == "f32":
+            if self.matmul not in L.MATMUL_TERMS:
+                raise ValueError(f"matmul must be one of {sorted(L.MATMUL_TERMS)}, got {self.matmul!r}")
+            if self.fold_norms and self.matmul == "f32" and not ln:
                 for k, sc in (("in_proj_weight", "norm1_scale"), ("fc1_weight", "norm2_scale")):
                     t = self._folded_weight(f"{i}.{k}", L.dev_f32(ps[k].detach(), k), L.dev_f32(ps[sc].detach(), sc))
                     keep.append(t)
                     setattr(arr[i], k + "_n", t.data_ptr())
-            if self.matmul == "bf16x3":
+            if self.matmul != "f32" and not ln:
                 for k in ("in_proj_weight", "out_proj_weight", "fc1_weight", "fc2_weight"):
                     img = self._split3_image(f"{i}.{k}", ps[k])
                     keep.append(img)
                     setattr(arr[i], k + "3", img.data_ptr())
-            elif self.matmul != "f32":
-                raise ValueError(f"matmul must be 'f32' or 'bf16x3', got {self.matmul!r}")
-        fin = L.dev_f32(self.final_norm.scale.detach(), "final_norm.scale")
+        ln = isinstance(self.final_norm, LayerNorm)
+        fin = L.dev_f32((self.final_norm.weight if ln else self.final_norm.scale).detach(), "final_norm.scale")
         keep.append(fin)
+        fin_b = None
+        if ln:
+            fin_b = L.dev_f32(self.final_norm.bias.detach(), "final_norm.bias")
+            keep.append(fin_b)
         hidden = self.blocks[0].mlp.fc1.weight.shape[0]
         cw = L.CoreWeights(self.cfg.d_model, len(self.blocks), self.cfg.n_heads, hidden, self.final_norm.eps,
-                           C.cast(arr, C.POINTER(L.BlockWeights)), fin.data_ptr())
+                           C.cast(arr, C.POINTER(L.BlockWeights)), fin.data_ptr(), 1 if ln else 0, L.ptr(fin_b),
+                           L.MATMUL_TERMS[self.matmul])
         return cw, (arr, keep)
 
     def forward(self, x: torch.Tensor, key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if key_padding_mask is not None:
-            raise NotImplementedError("key_padding_mask is never passed on the sampler path (sample_clip.py:374,378)")
+        """x [B,N,d]; key_padding_mask [B,N] bool, True = padding key (mmdt.py:134-149)."""
         if self.training and (self.cfg.token_dropout > 0 or self.cfg.dropout > 0 or self.cfg.attn_dropout > 0):
             raise NotImplementedError("HIP path is inference-only; call .eval()")
         x = L.dev_f32(x, "x")
         B, N, d = x.shape
         if d != self.cfg.d_model:
             raise RuntimeError(f"expected last dim {self.cfg.d_model}, got {d}")
+        kpm = Fn.key_padding_bytes(key_padding_mask, B, N, x.device)
         cw, keep = self.weight_table()
         need = L.lib().avd_core_workspace_bytes(C.byref(cw), B, N)
         if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
         y = torch.empty_like(x)
-        L.check(L.lib().avd_core_forward_f32(C.byref(cw), x.data_ptr(), y.data_ptr(), B, N, 0, N,
+        L.check(L.lib().avd_core_forward_f32(C.byref(cw), x.data_ptr(), y.data_ptr(), B, N, 0, N, L.ptr(kpm),
                                              self._ws.data_ptr(), self._ws.numel(), L.stream_ptr(x.device)))
         del keep
         return y

@@ -17,15 +17,13 @@ from . import _lib as L
 
 __all__ = ["MultiModalNoiseHead"]
 
-_ACTS = {"gelu": L.ACT_GELU}
+_ACTS = {"gelu": L.ACT_GELU, "relu": L.ACT_RELU, "leaky_relu": L.ACT_LEAKY_RELU}      # noise_heads.py:28-36 (LeakyReLU slope 0.1)
 
 
 def _act_code(name: str) -> int:
     name = (name or "gelu").lower()
     if name in _ACTS:
         return _ACTS[name]
-    if name in ("relu", "leaky_relu"):
-        raise NotImplementedError(f"activation '{name}' has no HIP kernel (all shipped configs use gelu)")
     raise ValueError(f"Unsupported activation: {name}")
 
 

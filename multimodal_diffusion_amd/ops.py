@@ -34,9 +34,8 @@ def chunk_1d(x: torch.Tensor, length: int, stride: int, dim: int = -1) -> torch.
 
 def overlap_add_1d(windows: torch.Tensor, stride: int, length: Optional[int] = None, dim_windows: int = -2,
                    apply_hann: bool = False) -> torch.Tensor:
-    """[..., N, W] -> [..., (N-1)*stride + W]: rectangular-window overlap-add divided by the overlap count."""
-    if apply_hann:
-        raise NotImplementedError("apply_hann=True is never used by the sampler (sample_clip.py:205)")
+    """[..., N, W] -> [..., (N-1)*stride + W]: overlap-add divided by the summed window weights (rectangular window, or
+    torch.hann_window(W) with apply_hann as ops.py:76-93)."""
     if dim_windows not in (-2, windows.dim() - 2):
         raise NotImplementedError("overlap_add_1d: windows must be indexed by dim -2")
     W = windows.size(-1)
@@ -45,5 +44,6 @@ def overlap_add_1d(windows: torch.Tensor, stride: int, length: Optional[int] = N
     prefix, N = windows.shape[:-2], windows.size(-2)
     L_out = (N - 1) * stride + W
     flat = windows.reshape(-1, N, W)                 # one 'channel' per prefix row
-    y = Fn.audio_untokens(flat, 1, W, L_out, stride)  # [P,1,L]
+    win = torch.hann_window(W, dtype=torch.float32).to(windows.device) if apply_hann else None      # host-built table, as the reference
+    y = Fn.audio_untokens(flat, 1, W, L_out, stride, window=win)  # [P,1,L]
     return y.view(*prefix, L_out)

@@ -58,12 +58,12 @@ def build_components(cfg: Dict, device: torch.device, vid_vae: Optional[nn.Modul
     MMDiT core and the VAE decoder (default "f32"; same fp32-level error either way).
     """
     matmul = str(cfg.get("runtime", {}).get("matmul", "f32"))
-    if matmul not in ("f32", "bf16x3"):
-        raise ValueError(f"runtime.matmul must be 'f32' or 'bf16x3', got {matmul!r}")
+    if matmul not in L.MATMUL_TERMS:
+        raise ValueError(f"runtime.matmul must be one of {sorted(L.MATMUL_TERMS)}, got {matmul!r}")
     if vid_vae is None and "video" in cfg:
         from .vae_video3d import VideoVAE
         vid_vae = VideoVAE.from_config(cfg["video"]).to(device).eval()
-        vid_vae.matmul = matmul
+        vid_vae.matmul = "bf16x3" if matmul.startswith("bf16") else "f32"
     if aud_codec is None and "audio" in cfg:
         from .audio_codec import AudioCodec
         aud_codec = AudioCodec.from_config(cfg["audio"]).to(device).eval()
@@ -127,7 +127,7 @@ class DenoiseEngine:
         self.tdim = self.d if temb_mode == "add" else int(tstep_dim)     # the trainer embeds at token width
         self.tube, self.chunk = tuple(tube), tuple(chunk)
         self.guidance, self.eta = float(guidance), float(eta)
-        self.device = core.final_norm.scale.device
+        self.device = next(core.final_norm.parameters()).device
         if not self.device.type == "cuda":
             raise L.AvdError("DenoiseEngine needs its modules on a ROCm device (no CPU fallback)")
         self.latent_shape = tuple(int(s) for s in latent_shape)      # with batch dim

@@ -108,9 +108,12 @@ class VideoVAE(nn.Module):
 
     @torch.no_grad()
     def encode(self, x: torch.Tensor, max_workspace_bytes: int = 12 << 30) -> torch.Tensor:
-        """x [B,3,T,H,W] -> z [B,Cv,T',H',W'] (vae_video3d.py:164-189, deterministic path)."""
-        if self.cfg.variational:
-            raise NotImplementedError("variational=True encode (mu/logvar + KL cache) has no HIP path; shipped configs are deterministic")
+        """x [B,3,T,H,W] -> z [B,Cv,T',H',W'] (vae_video3d.py:164-189).  variational=True in eval mode returns z = mu
+        (:175-184): to_mu and to_logv run as ONE stacked 1x1x1 head of the fused pool kernel; the KL term is cached lazily."""
+        if self.cfg.variational and self.training:
+            raise NotImplementedError("variational sampling (mu + eps * std) is training-only; the HIP path is inference-only, call .eval()")
+        if self.cfg.variational and 2 * self.cfg.lat_ch > 16:
+            raise NotImplementedError("variational encode supports up to 8 latent channels (mu and logvar share the 16-wide head)")
         x = L.dev_f32(x, "x")
         B, Cin, T, H, W = x.shape
         if Cin != self.cfg.in_ch:
@@ -118,7 +121,7 @@ class VideoVAE(nn.Module):
         T2, H2, W2, (t0, t1, h0, h1, w0, w1) = self._check_divisible(T, H, W)
         if (T2, H2, W2) != (T, H, W):
             x = x[:, :, t0:t1, h0:h1, w0:w1].contiguous()
-        self._kld = None
+        self._mu_logv = None
         nb = len(self.enc_net)
         keep = [self._enc_weight(i) for i in range(nb)]
 
@@ -134,13 +137,26 @@ class VideoVAE(nn.Module):
         cb = tab([self.enc_net[i][0].bias for i in range(nb)])
         gw = tab([self.enc_net[i][2].weight for i in range(nb)])
         gb = tab([self.enc_net[i][2].bias for i in range(nb)])
-        tlw = L.dev_f32(self.to_lat.weight.detach().reshape(self.cfg.lat_ch, self.cfg.enc_base), "to_lat.weight")
+        if self.cfg.variational:
+            key = tuple((p.data_ptr(), p._version) for p in (self.to_mu.weight, self.to_mu.bias, self.to_logv.weight, self.to_logv.bias))
+            hit = self._relaid.get("mu_logv")
+            if hit is None or hit[0] != key:
+                wcat = torch.cat([self.to_mu.weight.detach().reshape(self.cfg.lat_ch, self.cfg.enc_base),
+                                  self.to_logv.weight.detach().reshape(self.cfg.lat_ch, self.cfg.enc_base)], 0).contiguous()
+                bcat = torch.cat([self.to_mu.bias.detach(), self.to_logv.bias.detach()], 0).contiguous()
+                hit = (key, wcat, bcat)
+                self._relaid["mu_logv"] = hit
+            tlw, tlb, lat_out = L.dev_f32(hit[1], "to_mu|to_logv.weight"), L.dev_f32(hit[2]), 2 * self.cfg.lat_ch
+        else:
+            tlw = L.dev_f32(self.to_lat.weight.detach().reshape(self.cfg.lat_ch, self.cfg.enc_base), "to_lat.weight")
+            tlb, lat_out = L.dev_f32(self.to_lat.bias.detach()), self.cfg.lat_ch
+        keep.extend([tlw, tlb])
         d = L.VaeEncodeDesc()
         d.in_ch, d.T, d.H, d.W, d.t_down, d.s_down = Cin, T2, H2, W2, self.cfg.t_down, self.cfg.s_down
-        d.base, d.n_blocks, d.lat_ch, d.gn_eps = self.cfg.enc_base, nb, self.cfg.lat_ch, self.enc_net[0][2].eps
+        d.base, d.n_blocks, d.lat_ch, d.gn_eps = self.cfg.enc_base, nb, lat_out, self.enc_net[0][2].eps
         d.conv_w, d.conv_b = C.cast(cw, C.POINTER(C.c_void_p)), C.cast(cb, C.POINTER(C.c_void_p))
         d.gn_w, d.gn_b = C.cast(gw, C.POINTER(C.c_void_p)), C.cast(gb, C.POINTER(C.c_void_p))
-        d.to_lat_w, d.to_lat_b = tlw.data_ptr(), L.dev_f32(self.to_lat.bias.detach()).data_ptr()
+        d.to_lat_w, d.to_lat_b = tlw.data_ptr(), tlb.data_ptr()
         if self.matmul == "bf16x3" and nb > 1:
             imgs = [self._conv3_image(i, enc=True) for i in range(1, nb)]
             keep.extend(imgs)
@@ -156,7 +172,7 @@ class VideoVAE(nn.Module):
         need = L.lib().avd_vae_encode_workspace_bytes(C.byref(d))
         if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-        z = torch.empty(B, self.cfg.lat_ch, T2 // self.cfg.t_down, H2 // self.cfg.s_down, W2 // self.cfg.s_down,
+        z = torch.empty(B, lat_out, T2 // self.cfg.t_down, H2 // self.cfg.s_down, W2 // self.cfg.s_down,
                         device=x.device, dtype=torch.float32)
         for lo in range(0, B, chunk):
             hi = min(B, lo + chunk)
@@ -164,10 +180,19 @@ class VideoVAE(nn.Module):
             L.check(L.lib().avd_vae_encode_f32(C.byref(d), x[lo:hi].data_ptr(), z[lo:hi].data_ptr(), self._ws.data_ptr(),
                                                self._ws.numel(), L.stream_ptr(x.device)))
         del keep
+        if self.cfg.variational:
+            self._mu_logv = z                                  # kld_loss() reduces it on demand (off the sampler path)
+            return z[:, :self.cfg.lat_ch].contiguous()         # eval: z = mu (reference :182)
         return z
 
     def kld_loss(self):
-        return getattr(self, "_kld", None)
+        """Last KL term (reference :185) if variational and encode() was called, else None.  Host-side bookkeeping for a loss
+        the sampler never reads: reduced with torch from the cached (mu, logvar) head output."""
+        ml = getattr(self, "_mu_logv", None)
+        if not self.cfg.variational or ml is None:
+            return None
+        mu, logv = ml[:, :self.cfg.lat_ch], ml[:, self.cfg.lat_ch:]
+        return 0.5 * torch.mean(-1 - logv + mu.pow(2) + logv.exp())
 
     # conv weight [out,in,kt,kh,kw] -> [out][kt][kh][kw][in] (K = tap-major, channel-minor), cached per parameter version
     def _conv3_image(self, i: int, enc: bool = False) -> torch.Tensor:

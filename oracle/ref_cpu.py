@@ -146,18 +146,19 @@ def audio_tokens(z_a: Tensor, length: int, stride: int) -> Tensor:
     return win.permute(0, 2, 1, 3).reshape(B, na, Ca * length)
 
 
-def audio_untokens(tok: Tensor, Ca: int, length: int, frames: int, stride: int) -> Tensor:
-    """Overlap-add with a rectangular window and overlap-count normalisation, then crop / zero-pad
-    to ``frames`` (sample_clip.py:191-215 → ops.py:48-93)."""
+def audio_untokens(tok: Tensor, Ca: int, length: int, frames: int, stride: int, hann: bool = False) -> Tensor:
+    """Overlap-add with a rectangular (or, ops.py's apply_hann, Hann) window and summed-weight normalisation, then crop /
+    zero-pad to ``frames`` (sample_clip.py:191-215 → ops.py:48-93)."""
     B, na, D = tok.shape
     assert D == Ca * length
     win = tok.view(B, na, Ca, length).permute(0, 2, 1, 3)              # [B,Ca,Na,l]
     L = (na - 1) * stride + length
     acc = torch.zeros(B, Ca, L, dtype=tok.dtype)
     cnt = torch.zeros(L, dtype=tok.dtype)
+    w = torch.hann_window(length, dtype=tok.dtype) if hann else torch.ones(length, dtype=tok.dtype)
     for i in range(na):
-        acc[..., i * stride:i * stride + length] += win[:, :, i]
-        cnt[i * stride:i * stride + length] += 1
+        acc[..., i * stride:i * stride + length] += win[:, :, i] * w
+        cnt[i * stride:i * stride + length] += w
     acc = acc / cnt.clamp(min=1e-8)
     if L >= frames:
         return acc[..., :frames].contiguous()
@@ -183,31 +184,41 @@ def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None) -> Tensor:
     return y if b is None else y + b
 
 
-def self_attention(x: Tensor, w_in: Tensor, b_in: Tensor, w_out: Tensor, b_out: Tensor, n_heads: int) -> Tensor:
-    """nn.MultiheadAttention(batch_first=True), q=k=v=x, no mask, eval (mmdt.py:51-61)."""
+def self_attention(x: Tensor, w_in: Tensor, b_in: Tensor, w_out: Tensor, b_out: Tensor, n_heads: int,
+                   key_padding_mask: Optional[Tensor] = None) -> Tensor:
+    """nn.MultiheadAttention(batch_first=True), q=k=v=x, eval (mmdt.py:51-61); key_padding_mask [B,N] True = ignore the key."""
     B, N, d = x.shape
     dh = d // n_heads
     qkv = linear(x, w_in, b_in).view(B, N, 3, n_heads, dh)
     q, k, v = (qkv[:, :, i].transpose(1, 2) for i in range(3))          # [B,H,N,dh]
     s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
+    if key_padding_mask is not None:
+        s = s.masked_fill(key_padding_mask.bool()[:, None, None, :], float("-inf"))
     p = torch.softmax(s, dim=-1)
     o = (p @ v).transpose(1, 2).reshape(B, N, d)
     return linear(o, w_out, b_out)
 
 
-def mmdit_block(x: Tensor, W: Weights, pre: str, n_heads: int) -> Tensor:
-    h = rmsnorm(x, W[pre + "norm1.scale"])
+def _norm(x: Tensor, W: Weights, pre: str) -> Tensor:
+    """build_norm (mmdt.py:44-45): RMSNorm keys `scale`, nn.LayerNorm keys `weight` / `bias` (eps 1e-5)."""
+    if pre + "scale" in W:
+        return rmsnorm(x, W[pre + "scale"])
+    return layernorm(x, W[pre + "weight"], W[pre + "bias"])
+
+
+def mmdit_block(x: Tensor, W: Weights, pre: str, n_heads: int, key_padding_mask: Optional[Tensor] = None) -> Tensor:
+    h = _norm(x, W, pre + "norm1.")
     x = x + self_attention(h, W[pre + "attn.mha.in_proj_weight"], W[pre + "attn.mha.in_proj_bias"],
-                           W[pre + "attn.mha.out_proj.weight"], W[pre + "attn.mha.out_proj.bias"], n_heads)
-    h = rmsnorm(x, W[pre + "norm2.scale"])
+                           W[pre + "attn.mha.out_proj.weight"], W[pre + "attn.mha.out_proj.bias"], n_heads, key_padding_mask)
+    h = _norm(x, W, pre + "norm2.")
     h = gelu_erf(linear(h, W[pre + "mlp.fc1.weight"], W[pre + "mlp.fc1.bias"]))
     return x + linear(h, W[pre + "mlp.fc2.weight"], W[pre + "mlp.fc2.bias"])
 
 
-def mmdit_forward(x: Tensor, W: Weights, n_layers: int, n_heads: int) -> Tensor:
+def mmdit_forward(x: Tensor, W: Weights, n_layers: int, n_heads: int, key_padding_mask: Optional[Tensor] = None) -> Tensor:
     for i in range(n_layers):
-        x = mmdit_block(x, W, f"blocks.{i}.", n_heads)
-    return rmsnorm(x, W["final_norm.scale"])
+        x = mmdit_block(x, W, f"blocks.{i}.", n_heads, key_padding_mask)
+    return _norm(x, W, "final_norm.")
 
 
 # --------------------------------------------------------------------------------------
@@ -220,12 +231,16 @@ def layernorm(x: Tensor, g: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
     return (x - mu) / (var + eps).sqrt() * g + b
 
 
-def noise_head(h: Tensor, W: Weights, modality: str, n_shared: int = 2) -> Tensor:
+_HEAD_ACTS = {"gelu": gelu_erf, "relu": lambda t: t.clamp(min=0), "leaky_relu": lambda t: torch.where(t > 0, t, 0.1 * t)}
+
+
+def noise_head(h: Tensor, W: Weights, modality: str, n_shared: int = 2, activation: str = "gelu") -> Tensor:
     shp = h.shape
+    act = _HEAD_ACTS[activation]                          # noise_heads.py:28-36
     y = linear(h.reshape(-1, shp[-1]), W[f"input_proj.{modality}.weight"], W[f"input_proj.{modality}.bias"])
     for j in range(n_shared):
         y = linear(y, W[f"shared.{j}.0.weight"], W[f"shared.{j}.0.bias"])
-        y = gelu_erf(layernorm(y, W[f"shared.{j}.1.weight"], W[f"shared.{j}.1.bias"]))
+        y = act(layernorm(y, W[f"shared.{j}.1.weight"], W[f"shared.{j}.1.bias"]))
     y = linear(y, W[f"out_proj.{modality}.weight"], W[f"out_proj.{modality}.bias"])
     return y.view(*shp[:-1], y.shape[-1])
 
@@ -452,8 +467,9 @@ def synth_vae_decoder(seed: int = 0, cv: int = 8, base: int = 64, n_blocks: int 
     return W
 
 
-def vae_encode(x: Tensor, W: Weights, t_down: int = 4, s_down: int = 8, n_blocks: int = 2) -> Tensor:
-    """VideoVAE.encode, deterministic path (vae_video3d.py:164-189); x already divisible by the down factors."""
+def vae_encode(x: Tensor, W: Weights, t_down: int = 4, s_down: int = 8, n_blocks: int = 2, variational: bool = False):
+    """VideoVAE.encode (vae_video3d.py:164-189); x already divisible by the down factors.  variational (eval): returns
+    (z = to_mu(h), kld) as :175-185."""
     conv3d = torch.nn.functional.conv3d
     h = x
     for i in range(n_blocks):
@@ -462,6 +478,9 @@ def vae_encode(x: Tensor, W: Weights, t_down: int = 4, s_down: int = 8, n_blocks
         h = group_norm(h, min(8, cw.shape[0]), W[f"enc_net.{i}.2.weight"], W[f"enc_net.{i}.2.bias"])
     B, Cc, T, H, Wd = h.shape
     h = h.view(B, Cc, T // t_down, t_down, H // s_down, s_down, Wd // s_down, s_down).mean(dim=(3, 5, 7))
+    if variational:
+        mu, logv = conv3d(h, W["to_mu.weight"], W["to_mu.bias"]), conv3d(h, W["to_logv.weight"], W["to_logv.bias"])
+        return mu, 0.5 * torch.mean(-1 - logv + mu.pow(2) + logv.exp())
     return conv3d(h, W["to_lat.weight"], W["to_lat.bias"])
 
 

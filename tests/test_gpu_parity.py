@@ -482,8 +482,6 @@ def test_vae_decode_vs_oracle_bigger(dev):
     ref = R.vae_decode(z.double(), {k: v.double() for k, v in W.items()}, n_blocks=3, out_act="tanh")
     x = vae.to(dev).decode(z.to(dev)).cpu()
     assert rel_err(x, ref) < TOL
-    with pytest.raises(NotImplementedError):
-        A.VideoVAE(A.VideoVAEConfig(variational=True)).to(dev).encode(torch.zeros(1, 3, 4, 8, 8, device=dev))
 
 
 def test_vae_encode_golden(dev):
@@ -752,9 +750,9 @@ def test_attention_bf16x3(dev, B, N, H):
     x3, w3 = Fn.split3(qkv.to(dev)), Fn.split3(torch.eye(3 * d).to(dev))      # identity in_proj: the image holds qkv + bias exactly
     bd = bias.to(dev)
     L.check(lib.avd_gemm_bf16x3_qkv3_f32(x3.data_ptr(), w3.data_ptr(), bd.data_ptr(), img.data_ptr(), B * N, N, H, 3 * d,
-                                         0.125 * 1.4426950408889634, L.stream_ptr(dev)))
+                                         0.125 * 1.4426950408889634, 6, L.stream_ptr(dev)))
     out = torch.empty(B, N, d, device=dev)
-    L.check(lib.avd_attn_fwd_qkv3_f32(img.data_ptr(), out.data_ptr(), None, B, N, H, N, L.stream_ptr(dev)))
+    L.check(lib.avd_attn_fwd_qkv3_f32(img.data_ptr(), out.data_ptr(), None, B, N, H, N, 6, L.stream_ptr(dev)))
     full = (qkv + bias).double().view(B, N, 3, H, 64)
     q, k, v = (full[:, :, i].transpose(1, 2) for i in range(3))                  # [B,H,N,64]
     ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v).transpose(1, 2).reshape(B, N, d)
@@ -764,7 +762,7 @@ def test_attention_bf16x3(dev, B, N, H):
     # split3-image output == fp32 output; n_query leaves later rows untouched
     o3 = torch.zeros(lib.avd_split3_bytes(B * N, d), dtype=torch.uint8, device=dev)
     nq = max(1, N - 5)
-    L.check(lib.avd_attn_fwd_qkv3_f32(img.data_ptr(), None, o3.data_ptr(), B, N, H, nq, L.stream_ptr(dev)))
+    L.check(lib.avd_attn_fwd_qkv3_f32(img.data_ptr(), None, o3.data_ptr(), B, N, H, nq, 6, L.stream_ptr(dev)))
     got = _split3_decode(o3.cpu().numpy(), B * N, d).astype(np.float64).sum(0).reshape(B, N, d)
     assert np.array_equal(got[:, :nq], out.cpu().double().numpy()[:, :nq])
     assert not got[:, nq:].any()
@@ -845,9 +843,9 @@ def test_attention_bf16x3_edge_shapes(dev, B, N, H, nq):
     x3, w3 = Fn.split3(qkv.to(dev)), Fn.split3(torch.eye(3 * d).to(dev))
     zb = torch.zeros(3 * d, device=dev)
     L.check(lib.avd_gemm_bf16x3_qkv3_f32(x3.data_ptr(), w3.data_ptr(), zb.data_ptr(), img.data_ptr(), B * N, N, H, 3 * d,
-                                         0.125 * 1.4426950408889634, L.stream_ptr(dev)))
+                                         0.125 * 1.4426950408889634, 6, L.stream_ptr(dev)))
     out = torch.full((B, N, d), 7.0, device=dev)
-    L.check(lib.avd_attn_fwd_qkv3_f32(img.data_ptr(), out.data_ptr(), None, B, N, H, nq, L.stream_ptr(dev)))
+    L.check(lib.avd_attn_fwd_qkv3_f32(img.data_ptr(), out.data_ptr(), None, B, N, H, nq, 6, L.stream_ptr(dev)))
     full = qkv.double().view(B, N, 3, H, 64)
     q, k, v = (full[:, :, i].transpose(1, 2) for i in range(3))
     ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v).transpose(1, 2).reshape(B, N, d)
@@ -1110,3 +1108,178 @@ def test_engine_follows_weight_updates(dev, full, matmul):
                              core=ws2["core"], head=ws2["head"], n_layers=8, n_heads=8, guidance=3.5)
     assert not torch.equal(before, after)
     assert rel_err(after[:2], ref) < TOL
+
+
+# ------------------------------------------------------------------------------------------------- bf16x3 adversarial suite
+def _bf16x3_vs_f32(dev, x, w, b=None, strict=False):
+    """(bf16x3 result, fp32-MFMA result, fp64 reference, sum_k |x_k w_k|) for y = x w^T (+ b)."""
+    from multimodal_diffusion_amd import functional as Fn
+    M, K = x.shape
+    N = w.shape[0]
+    y3 = Fn.linear_bf16x3(Fn.split3(x.to(dev)), M, Fn.split3(w.to(dev)), N, K, bias=None if b is None else b.to(dev),
+                          terms=9 if strict else 6).cpu().double()
+    y32 = Fn.linear(x.to(dev), w.to(dev), None if b is None else b.to(dev)).cpu().double()
+    ref = x.double() @ w.double().t()
+    if b is not None:
+        ref = ref + b.double()
+    mag = x.double().abs() @ w.double().abs().t()
+    return y3, y32, ref, mag
+
+
+@pytest.mark.parametrize("strict", [False, True])
+@pytest.mark.parametrize("scale", [1e-30, 1e-20, 1.0, 1e15, 3e18])
+def test_bf16x3_dynamic_range(dev, scale, strict):
+    """Operands from 1e-30 up to products near the top of the fp32 range: the split-operand GEMM stays within the fp32
+    FMA chain's error bound (gamma_K * sum|x w|) and no worse than 2x the fp32-MFMA kernel's own error."""
+    g = torch.Generator().manual_seed(int(abs(math.log10(scale))) + 3)
+    M, N, K = 300, 256, 512
+    x = torch.randn(M, K, generator=g) * scale
+    w = torch.randn(N, K, generator=g) * (1.0 / math.sqrt(K)) * (scale if scale > 1 else 1.0)
+    y3, y32, ref, mag = _bf16x3_vs_f32(dev, x, w, strict=strict)
+    assert torch.isfinite(y3).all()
+    bound = 2.0 * K * 2.0 ** -24 * mag            # a generous multiple of the fp32 dot-product bound
+    assert ((y3 - ref).abs() <= bound).all()
+    e3, e32 = (y3 - ref).abs().max().item(), (y32 - ref).abs().max().item()
+    assert e3 <= 2.0 * e32 + 1e-30, (e3, e32)
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_bf16x3_top_of_range_and_exact_bf16(dev, strict):
+    """(a) values above the largest finite bf16 (3.3895e38 < |x| <= FLT_MAX) must not turn into infinities: their high plane is
+    clamped and the remainder moves to the middle plane; (b) operands that ARE bf16 numbers (m = l = 0 planes) and small
+    integers give exact results."""
+    from multimodal_diffusion_amd import functional as Fn
+    K, N = 64, 256
+    x = torch.zeros(4, K)
+    x[0, 0], x[0, 1] = 3.4e38, -3.39e38                 # both round to +-inf in bf16
+    x[1, 0] = torch.finfo(torch.float32).max
+    x[2, 8:40] = 3.0e38                                 # 32 huge terms whose weighted sum (1.5e38) still fits
+    x[3, 5] = -torch.finfo(torch.float32).max
+    w = torch.zeros(N, K)
+    w[:, 0], w[:, 1], w[:, 5] = 0.5, 0.25, 1.0
+    w[:, 8:40] = 1.0 / 64.0
+    y3, y32, ref, _ = _bf16x3_vs_f32(dev, x, w, strict=strict)
+    assert torch.isfinite(y3).all()
+    assert rel_err(y3, ref) < 1e-6 and rel_err(y32, ref) < 1e-6
+    # the image itself: planes still sum to x exactly
+    pl = _split3_decode(Fn.split3(x.to(dev)).cpu().numpy(), 4, K).astype(np.float64)
+    assert np.array_equal(pl.sum(0), x.numpy().astype(np.float64)) and np.isfinite(pl).all()
+    # exact bf16 / integer operands: every product and partial sum is representable, so all three results are identical
+    g = torch.Generator().manual_seed(4)
+    xi = torch.randint(-8, 9, (130, 512), generator=g).float()
+    wi = torch.randint(-4, 5, (256, 512), generator=g).float()
+    y3, y32, ref, _ = _bf16x3_vs_f32(dev, xi, wi, strict=strict)
+    assert torch.equal(y3, ref) and torch.equal(y32, ref)
+    xb = torch.randn(130, 512, generator=g).bfloat16().float()
+    wb = (torch.randn(256, 512, generator=g) / 16).bfloat16().float()
+    y3, y32, ref, mag = _bf16x3_vs_f32(dev, xb, wb, strict=strict)
+    assert ((y3 - ref).abs() <= 512 * 2.0 ** -24 * mag).all() and (y3 - ref).abs().max() <= 1.5 * (y32 - ref).abs().max() + 1e-12
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_bf16x3_cancellation(dev, strict):
+    """K-long catastrophic cancellation: products come in +a, -a pairs with a tiny residue, so the exact answer is ~1e-7 of
+    sum|x w|.  Neither path can beat the fp32 dot-product bound here; bf16x3 must not be worse than the fp32-MFMA kernel by
+    more than the terms it drops (6-term: 3 * 2^-24 per product; 9-term: none)."""
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 260, 256, 2048
+    a = torch.randn(M, K // 2, generator=g) * 100.0
+    x = torch.empty(M, K)
+    x[:, 0::2], x[:, 1::2] = a, -a
+    x[:, 1::2] += torch.randn(M, K // 2, generator=g) * 1e-5          # tiny residue
+    w = torch.empty(N, K)
+    wv = torch.randn(N, K // 2, generator=g)
+    w[:, 0::2], w[:, 1::2] = wv, wv
+    y3, y32, ref, mag = _bf16x3_vs_f32(dev, x, w, strict=strict)
+    e3, e32 = (y3 - ref).abs(), (y32 - ref).abs()
+    assert (e32 <= K * 2.0 ** -24 * mag).all()
+    assert (e3 <= (K + 8) * 2.0 ** -24 * mag).all()
+    assert e3.max() <= 2.0 * e32.max(), (e3.max().item(), e32.max().item())
+
+
+def test_bf16x3_tiny_values_document_the_floor(dev):
+    """Below ~2^-110 the lower planes leave bf16's range (bf16 shares fp32's exponent range but has 7 mantissa bits), so the
+    split is no longer exact: the ABSOLUTE error stays below 2^-126 per product — invisible unless every product of a dot
+    product is that small.  This is the documented domain limit of the mode."""
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(64, 64, generator=g) * 1e-36
+    w = torch.randn(256, 64, generator=g)
+    y3, y32, ref, mag = _bf16x3_vs_f32(dev, x, w)
+    assert torch.isfinite(y3).all()
+    assert (y3 - ref).abs().max() <= 64 * 2.0 ** -126 * 8          # absolute floor, not relative accuracy
+    assert (y32 - ref).abs().max() <= 64 * 2.0 ** -149 * 8 + 64 * 2.0 ** -24 * mag.max()
+
+
+def test_bf16x3_nonfinite_rows_stay_local(dev):
+    """inf / NaN in one input row make exactly that output row non-finite in both kernels (bf16x3 may report NaN where the
+    fp32 chain reports +-inf: inf * 0-plane); every other row is untouched and still fp32-accurate."""
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(300, 256, generator=g)
+    w = torch.randn(256, 256, generator=g) / 16
+    x[5, 17] = float("inf")
+    x[77, 3] = float("nan")
+    x[200, 0] = float("-inf")
+    y3, y32, ref, _ = _bf16x3_vs_f32(dev, x, w)
+    bad = torch.tensor([5, 77, 200])
+    good = torch.ones(300, dtype=torch.bool)
+    good[bad] = False
+    assert not torch.isfinite(y3[bad]).any() and not torch.isfinite(y32[bad]).any()
+    assert torch.isfinite(y3[good]).all() and rel_err(y3[good], ref[good]) < 2e-6
+    assert torch.isnan(y3[77]).all() and torch.isnan(y32[77]).all()
+
+
+# ------------------------------------------------------------------------------------------------- drop-in corners (G16)
+def _grp(g, prefix):
+    return {k[len(prefix) + 1:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix + "/")}
+
+
+def test_dropin_corners_golden(dev, small_model):
+    """key_padding_mask, norm="layernorm", relu / leaky_relu heads, variational eval encode and Hann overlap-add against the
+    reference's own outputs (tests/golden/g16_dropin_corners.npz)."""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd import ops
+    g, W, meta = small_model
+    g16 = load_golden("g16_dropin_corners.npz")
+    core, _, _, _ = _small_modules(dev, W, meta)
+    y = core(G(g16["mask/x"], dev), key_padding_mask=G(g16["mask/kpm"], dev))
+    assert rel_err(y.cpu(), g16["mask/y"]) < TOL
+    assert rel_err(core.blocks[0](G(g16["mask/x"], dev), key_padding_mask=G(g16["mask/kpm"], dev)).cpu(),
+                   R.mmdit_block(T(g16["mask/x"]), W["core"], "blocks.0.", meta["n_heads"], T(g16["mask/kpm"]))) < TOL
+    ln = A.MMDiT(d_model=128, n_layers=2, n_heads=2, mlp_ratio=2.0, norm="layernorm").eval()
+    ln.load_state_dict(_grp(g16, "ln_core"), strict=True)
+    assert rel_err(ln.to(dev)(G(g16["ln/x"], dev)).cpu(), g16["ln/y"]) < TOL
+    for act in ("relu", "leaky_relu"):
+        hd = A.MultiModalNoiseHead({"video": 128, "audio": 128}, {"video": 256, "audio": 32}, hidden_dim=64, activation=act).eval()
+        hd.load_state_dict(_grp(g16, f"head_{act}_w"), strict=True)
+        out = hd.to(dev)({"video": G(g16[f"head_{act}/hv"], dev)})["video"]
+        assert rel_err(out.cpu(), g16[f"head_{act}/out_v"]) < TOL
+    vv = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}, "variational": True}).eval()
+    missing, unexpected = vv.load_state_dict(_grp(g16, "vvae_w"), strict=False)
+    assert not unexpected and all(k.startswith(("dec_net", "from_lat", "to_img")) for k in missing)
+    vv = vv.to(dev)
+    z = vv.encode(G(g16["vvae/x"], dev))
+    assert z.shape == (2, 8, 2, 2, 3) and rel_err(z.cpu(), g16["vvae/z"]) < TOL
+    assert abs(float(vv.kld_loss()) - float(g16["vvae/kld"])) < 1e-4
+    y = ops.overlap_add_1d(G(g16["hann/windows"], dev), stride=4, apply_hann=True)
+    assert rel_err(y.cpu(), g16["hann/y"]) < 1e-6
+    assert rel_err(ops.overlap_add_1d(G(g16["hann/windows"], dev), stride=3).cpu(), g16["hann/y_rect"]) < 1e-6
+
+
+def test_attention_key_padding_mask(dev):
+    """Masked keys at tile boundaries, a fully kept and an almost fully masked sample, against masked softmax in fp64."""
+    from multimodal_diffusion_amd import functional as Fn
+    g = torch.Generator().manual_seed(23)
+    B, N, H = 4, 200, 2
+    d = 64 * H
+    qkv = torch.randn(B, N, 3 * d, generator=g)
+    kpm = torch.zeros(B, N, dtype=torch.bool)
+    kpm[0, 64:128] = True            # one whole key tile
+    kpm[1, 1:] = True                # a single visible key
+    kpm[2, torch.randint(0, N, (90,), generator=g)] = True
+    q, k, v = (qkv.double().view(B, N, 3, H, 64)[:, :, i].transpose(1, 2) for i in range(3))
+    s = (q @ k.transpose(-1, -2) / 8.0).masked_fill(kpm[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, N, d)
+    out = Fn.attention(qkv.to(dev), H, key_padding_mask=kpm.to(dev))
+    assert rel_err(out.cpu(), ref) < 2e-5
+    assert torch.equal(Fn.attention(qkv.to(dev), H, key_padding_mask=torch.zeros(B, N, dtype=torch.bool, device=dev)),
+                       Fn.attention(qkv.to(dev), H))

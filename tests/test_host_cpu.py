@@ -22,7 +22,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, name), f"{name} declared in include/avdiff_hip.h but not exported"
         assert name in L.SIGNATURES, f"{name} has no ctypes signature"
     assert set(L.SIGNATURES) <= declared, set(L.SIGNATURES) - declared
-    assert lib.avd_abi_version() == L.ABI_VERSION == 2
+    assert lib.avd_abi_version() == L.ABI_VERSION == 3
 
 
 def test_error_channel_without_gpu():
@@ -31,7 +31,7 @@ def test_error_channel_without_gpu():
     # argument validation happens before any HIP call, so it is testable on a CPU-only box
     assert lib.avd_gemm_bias_act_f32(None, 4, None, None, None, 0, None, 4, 1, 4, 4, 0, None) == L.EINVAL
     assert b"null pointer" in lib.avd_last_error()
-    assert lib.avd_attn_fwd_f32(8, 8, 1, 4, 1, 32, 0.1, 4, None) == L.EUNSUPPORTED     # head_dim != 64
+    assert lib.avd_attn_fwd_f32(8, 8, 1, 4, 1, 32, 0.1, 4, None, None) == L.EUNSUPPORTED     # head_dim != 64
     with pytest.raises(ValueError):
         L.check(L.EINVAL)
     with pytest.raises(L.AvdError):
@@ -41,11 +41,12 @@ def test_error_channel_without_gpu():
     assert lib.avd_split3_bytes(300, 24) == -1                         # K must be a multiple of 16
     assert lib.avd_qkv3_bytes(2, 421, 8) == 3 * 2 * 8 * 448 * 384      # tokens padded to 64, 384-byte rows
     assert lib.avd_qkv3_bytes(0, 421, 8) == -1
-    assert lib.avd_gemm_bf16x3_f32(16, 16, None, None, 16, None, 100, 200, 512, 0, None) == L.EUNSUPPORTED   # N % 256 != 0
+    assert lib.avd_gemm_bf16x3_f32(16, 16, None, None, 16, None, 100, 200, 512, 0, 6, None) == L.EUNSUPPORTED   # N % 256 != 0
     assert b"N % 256" in lib.avd_last_error()
-    assert lib.avd_gemm_bf16x3_f32(None, 16, None, None, 16, None, 100, 256, 512, 0, None) == L.EINVAL
-    assert lib.avd_gemm_bf16x3_qkv3_f32(16, 16, 16, 16, 1000, 421, 8, 512, 0.1, None) == L.EINVAL          # rows not a multiple of tokens
-    assert lib.avd_attn_fwd_qkv3_f32(16, 16, None, 2, 421, 8, 500, None) == L.EINVAL                       # n_query > N
+    assert lib.avd_gemm_bf16x3_f32(None, 16, None, None, 16, None, 100, 256, 512, 0, 6, None) == L.EINVAL
+    assert lib.avd_gemm_bf16x3_f32(16, 16, None, None, 16, None, 100, 256, 512, 0, 7, None) == L.EINVAL                 # terms must be 6, 9 or 1
+    assert lib.avd_gemm_bf16x3_qkv3_f32(16, 16, 16, 16, 1000, 421, 8, 512, 0.1, 6, None) == L.EINVAL          # rows not a multiple of tokens
+    assert lib.avd_attn_fwd_qkv3_f32(16, 16, None, 2, 421, 8, 500, 6, None) == L.EINVAL                       # n_query > N
 
 
 def test_schedule_tables_bit_exact_vs_reference():
@@ -118,8 +119,12 @@ def test_no_cpu_fallback():
                         head=A.MultiModalNoiseHead({"video": 128, "audio": 128}, {"video": 256, "audio": 32}, hidden_dim=64),
                         tstep_dim=64, target="video", latent_shape=(1, 8, 4, 8, 8), prompt_tokens=5,
                         alpha_bar=torch.ones(10), guidance=1.0)
+    ln = A.MMDiT(d_model=128, n_layers=1, n_heads=2, norm="layernorm")          # build_norm's other branch (mmdt.py:44-45)
+    assert {"blocks.0.norm1.weight", "blocks.0.norm1.bias", "final_norm.weight", "final_norm.bias"} <= set(ln.state_dict())
+    with pytest.raises(L.AvdError):
+        ln.eval()(torch.zeros(1, 4, 128))
     with pytest.raises(NotImplementedError):
-        A.MMDiT(d_model=128, n_layers=1, n_heads=2, norm="layernorm")
+        A.MMDiT(d_model=128, n_layers=1, n_heads=2, rope=True)
 
 
 def test_product_does_not_import_oracle():

@@ -201,3 +201,26 @@ def test_g15_add_mode_step(small_model):
     tok_v = R.tube_patch(T(g["z_v"]), 2, 4, 4)
     Xv = R.embed_with_time(tok_v, Wa["adapt_v"]["proj.weight"], Wa["adapt_v"]["proj.bias"], T(g["t_now"]), 0, "add")
     assert rel_err(Xv, g["X"][:, :tok_v.shape[1]]) < 1e-6
+
+
+def _grp(g, prefix):
+    return {k[len(prefix) + 1:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix + "/")}
+
+
+def test_g16_dropin_corners(small_model):
+    """Options of the reference API the shipped sampler never uses: key_padding_mask, norm="layernorm", relu / leaky_relu heads,
+    variational eval encode, Hann-window overlap-add (tools/make_golden.py G16)."""
+    _, W, meta = small_model
+    g = load_golden("g16_dropin_corners.npz")
+    y = R.mmdit_forward(T(g["mask/x"]), W["core"], meta["n_layers"], meta["n_heads"], key_padding_mask=T(g["mask/kpm"]))
+    assert rel_err(y, g["mask/y"]) < TOL
+    assert rel_err(R.mmdit_forward(T(g["ln/x"]), _grp(g, "ln_core"), 2, 2), g["ln/y"]) < TOL
+    for act in ("relu", "leaky_relu"):
+        out = R.noise_head(T(g[f"head_{act}/hv"]), _grp(g, f"head_{act}_w"), "video", activation=act)
+        assert rel_err(out, g[f"head_{act}/out_v"]) < TOL
+    z, kld = R.vae_encode(T(g["vvae/x"]), _grp(g, "vvae_w"), variational=True)
+    assert rel_err(z, g["vvae/z"]) < TOL and abs(float(kld) - float(g["vvae/kld"])) < 1e-5
+    wnd = T(g["hann/windows"])                                         # [2,3,5,8] -> one "channel" per prefix row
+    flat = wnd.reshape(6, 5, 8)
+    y = R.audio_untokens(flat, 1, 8, 24, 4, hann=True).view(2, 3, 24)
+    assert rel_err(y, g["hann/y"]) < 1e-6

@@ -354,6 +354,52 @@ def main():
           guidance=np.float32(3.0), X=_np(torch.cat([Xv, Xa], 1)), eps_cond=_np(ec), eps_null=_np(en), eps_tok=_np(et),
           z_next=_np(su.ddim_step(z_v, tn, tp, el, abar, eta=0.0)), **_flat("adapt_v", _sd(av_t)), **_flat("adapt_a", _sd(aa_t)))
 
+    # ---- G16 drop-in corners: options the reference API accepts although the shipped sampler never uses them -----------------
+    g16 = {}
+    # (a) MMDiT.forward(key_padding_mask) (mmdt.py:134-149): reduced core above, ragged padding per sample
+    gen = torch.Generator().manual_seed(17)
+    xm = torch.randn(3, 70, 128, generator=gen)
+    kpm = torch.zeros(3, 70, dtype=torch.bool)
+    kpm[0, 50:] = True
+    kpm[1, 69:] = True
+    kpm[2, 3:40] = True
+    g16["mask/x"], g16["mask/kpm"], g16["mask/y"] = _np(xm), _np(kpm), _np(core(xm, key_padding_mask=kpm))
+    # (b) norm="layernorm" (build_norm, mmdt.py:44-45)
+    torch.manual_seed(18)
+    core_ln = MMDiT(d_model=128, n_layers=2, n_heads=2, mlp_ratio=2.0, norm="layernorm").eval()
+    for name, p_ in core_ln.named_parameters():
+        if p_.dim() == 1:
+            p_.add_(0.05 * torch.randn(p_.shape, generator=gen))
+    xl = torch.randn(2, 21, 128, generator=gen)
+    g16["ln/x"], g16["ln/y"] = _np(xl), _np(core_ln(xl))
+    g16.update(_flat("ln_core", _sd(core_ln)))
+    # (c) head activations other than gelu (noise_heads.py:28-36)
+    for act in ("relu", "leaky_relu"):
+        torch.manual_seed(19)
+        hd = MultiModalNoiseHead({"video": 128, "audio": 128}, {"video": 256, "audio": 32}, hidden_dim=64, num_shared_layers=2,
+                                 num_modality_specific_layers=1, dropout=0.1, activation=act).eval()
+        for name, p_ in hd.named_parameters():
+            if p_.dim() == 1:
+                p_.add_(0.05 * torch.randn(p_.shape, generator=gen))
+        hv = torch.randn(2, 8, 128, generator=gen)
+        g16[f"head_{act}/hv"], g16[f"head_{act}/out_v"] = _np(hv), _np(hd({"video": hv})["video"])
+        g16.update(_flat(f"head_{act}_w", _sd(hd)))
+    # (d) VideoVAE(variational=True).eval().encode: z = to_mu(h) and the cached KL term (vae_video3d.py:175-185)
+    torch.manual_seed(20)
+    vv = VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}, "variational": True}).eval()
+    for name, p_ in vv.named_parameters():
+        if name.startswith(("enc_net", "to_mu", "to_logv")) and p_.dim() == 1:
+            p_.add_(0.1 * torch.randn(p_.shape, generator=gen))
+    xv = torch.rand(2, 3, 8, 16, 24, generator=gen)
+    zv = vv.encode(xv)
+    g16["vvae/x"], g16["vvae/z"], g16["vvae/kld"] = _np(xv), _np(zv), _np(vv.kld_loss())
+    g16.update(_flat("vvae_w", {k: v for k, v in _sd(vv).items() if k.startswith(("enc_net", "to_mu", "to_logv"))}))
+    # (e) overlap_add_1d(apply_hann=True) (ops.py:48-93)
+    wnd = torch.randn(2, 3, 5, 8, generator=gen)
+    g16["hann/windows"], g16["hann/y"] = _np(wnd), _np(ops.overlap_add_1d(wnd, stride=4, apply_hann=True))
+    g16["hann/y_rect"] = _np(ops.overlap_add_1d(wnd, stride=3))
+    _save("g16_dropin_corners.npz", **g16)
+
     # ---- optional: full-size live comparison oracle vs reference --------------------------
     if args.full_size_report:
         sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
