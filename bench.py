@@ -7,13 +7,19 @@
 One "step" = one CFG denoising step for a batch of 32 samples (reference loop body
 avdiff/models/infer/sample_clip.py:359-389: tokenise -> adapters -> t-emb -> MMDiT x2 (cond+null, stacked to 2B) ->
 noise head -> CFG -> un-patch -> DDIM), workload C3 of BASELINE.json (256x256 -> 384 video + 37 audio tokens,
-mvp.yaml model dims d=512 L=8 H=8), fp32, synthetic inputs, random-init weights, inputs resident in HBM.
+mvp.yaml model dims d=512 L=8 H=8), fp32 results, synthetic inputs, random-init weights, inputs resident in HBM.
 Weak scaling: every rank steps its own 32 samples; the only collective is one RCCL broadcast of the
 conditioning latents before the loop.  Rank 0 prints ONE JSON line.
+
+Matrix-pipe modes (--matmul): "bf16x3" (default since round 2: every fp32 operand split exactly into three bf16 planes, six
+product terms, fp32 accumulation — the error of an fp32 FMA chain, tests/test_gpu_parity.py bf16x3 suites), "f32" (fp32 MFMA,
+the round-1 default, measured in the same run as "alt"), "bf16x3_strict" (nine terms), "bf16" (one term: reduced precision,
+BASELINE config C2 — never the default, its error is reported, not gated).
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -25,6 +31,20 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 import torch
+
+PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
+PEAK_HBM_GBS = 8000.0
+# split-operand matmul: one product costs TERMS bf16 MFMAs, so the dense bf16 peak (2,516.6 TFLOP/s) prices ALGORITHMIC fp32
+# flops at 2516.6 / TERMS (the chip holds well under 2.4 GHz on this load; that is not priced in)
+PEAK_BF16_MATRIX_TFLOPS = 2516.6
+MODE_TERMS = {"f32": 0, "bf16x3": 6, "bf16x3_strict": 9, "bf16": 1}
+MODE_DTYPE = {
+    "f32": "f32",
+    "bf16x3": "f32 via 3xbf16 split operands (6-term products, f32 accumulate; fp32-level error)",
+    "bf16x3_strict": "f32 via 3xbf16 split operands (all 9 product terms, f32 accumulate)",
+    "bf16": "bf16 operands, f32 accumulate (reduced precision; error reported, not a parity path)",
+}
+
 
 def host_cores() -> int:
     """CPU threads this process may actually use (cgroup quota / affinity), not the machine's core count."""
@@ -42,26 +62,36 @@ def host_cores() -> int:
     return int(os.environ.get("AVD_CPU_THREADS", min(n, 16 * max(1, torch.cuda.device_count()) if n > 64 else n)))
 
 
-PEAK_F32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32 matrix peak
-PEAK_HBM_GBS = 8000.0
-# bf16x3 matmul: one fp32-accurate product term set costs 6 bf16 MFMAs, so the dense bf16 peak (2,516.6 TFLOP/s) prices
-# ALGORITHMIC fp32 flops at 2516.6 / 6 (the chip holds well under 2.4 GHz on this load; that is not priced in)
-PEAK_BF16_MATRIX_TFLOPS = 2516.6
-PEAK_BF16X3_EQUIV_TFLOPS = PEAK_BF16_MATRIX_TFLOPS / 6.0
+def csrc_hash() -> str:
+    """Identity of the kernel sources a profile was taken at (sha256 over csrc/*.hip, *.h and the C header, first 16 hex)."""
+    h = hashlib.sha256()
+    files = sorted((ROOT / "multimodal_diffusion_amd" / "csrc").glob("*.hip")) + \
+        sorted((ROOT / "multimodal_diffusion_amd" / "csrc").glob("*.h")) + [ROOT / "include" / "avdiff_hip.h"]
+    for f in files:
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel_tag: str):
-    """HBM-side bytes per launch of `kernel_tag` from the newest committed PMC pass (tools/pmc_traffic.py), or None.
-    The PMC passes cannot run inside this process (rocprofv3 wraps the command), so the figure is read back."""
-    for f in sorted((ROOT / "profiles").glob("r*_traffic*.json"), reverse=True):      # newest round first
+def pmc_traffic(kernel_tag: str, matmul: str):
+    """(bytes beyond L2 per launch, source) of `kernel_tag` from the newest committed PMC pass (tools/pmc_traffic.py) taken at
+    THESE kernel sources, else (None, reason).  The PMC passes cannot run inside this process (rocprofv3 wraps the command),
+    so the figure is read back — and dropped as soon as csrc/ differs from what was profiled."""
+    want = csrc_hash()
+    pat = "r*_traffic.json" if matmul == "f32" else f"r*_traffic_{matmul}.json"
+    for f in sorted((ROOT / "profiles").glob(pat), reverse=True):      # newest round first
         try:
-            ks = json.loads(f.read_text())["kernels"]
+            doc = json.loads(f.read_text())
+            ks = doc["kernels"]
         except (OSError, ValueError, KeyError):
             continue
+        if doc.get("csrc_sha16") != want:
+            return None, f"stale: {f.name} was taken at csrc {doc.get('csrc_sha16', 'unknown')}, tree is {want}"
         for name, v in ks.items():
-            if kernel_tag in name:
-                return v["traffic_bytes_per_launch"]
-    return None
+            if kernel_tag.replace(" ", "") in name.replace(" ", ""):
+                return v["traffic_bytes_per_launch"], f"profiles/{f.name}@csrc:{want}"
+        return None, f"kernel not in profiles/{f.name}"
+    return None, "no PMC profile committed for this mode"
 
 
 def step_flops_per_sample(nv: int, na: int, d: int = 512, L: int = 8, hid: int = 2048, tok: int = 256,
@@ -103,7 +133,7 @@ def cpu_state(mods):
     return dict(adapt_v=f(av), adapt_a=f(aa), core=f(core), head=f(head))
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -114,54 +144,109 @@ def main():
     ap.add_argument("--guidance", type=float, default=3.5)
     ap.add_argument("--graph", action="store_true", help="replay a captured 2-step HIP graph instead of eager launches")
     ap.add_argument("--split-streams", type=int, default=0, help="run the cond/null halves on two HIP streams")
-    ap.add_argument("--matmul", default="f32", choices=["f32", "bf16x3"],
-                    help="f32: fp32 MFMA everywhere; bf16x3: block projections on the bf16 matrix pipe with exactly split "
-                         "fp32 operands (same fp32-level error, see csrc/gemm_bf16x3.hip)")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed-region) measurement of the other matmul mode")
+    ap.add_argument("--matmul", default="bf16x3", choices=sorted(MODE_TERMS),
+                    help="bf16x3 (default): block projections + attention on the bf16 matrix pipe with exactly split fp32 "
+                         "operands (fp32-level error); f32: fp32 MFMA everywhere; bf16x3_strict: all nine product terms; "
+                         "bf16: plain bf16 operands (reduced precision, reported error)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed-region) measurements of the other matmul modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse N > 1 on a 1-GPU box)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (with --backend gloo)")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    from multimodal_diffusion_amd import dist as D, schedule_utils as su, _lib as L
-    import multimodal_diffusion_amd as A
 
+def setup_run(args, need_gpu: bool = True):
+    """Everything bench.py does BEFORE its first GPU call, as one function: rank / world / device from torchrun's env,
+    process-group init, geometry, the ONE broadcast of the conditioning latents and this rank's shard, the per-rank initial
+    latent and the schedule tables.  `need_gpu=False` lets the CPU test suite run exactly this path under gloo."""
+    from multimodal_diffusion_amd import dist as D, schedule_utils as su
     multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
-    if multi and args.backend == "nccl" and not args.share_device:
+    if need_gpu and multi and args.backend == "nccl" and not args.share_device:
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
     rank, world, local = D.init_from_env(args.backend if multi else None)
     if args.share_device:
         local = 0
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
-    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
-
+    if need_gpu:
+        assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+    else:
+        dev = torch.device("cpu")
+    comm_dev = dev if (need_gpu and args.backend == "nccl") else torch.device("cpu")
     B, size, S = args.batch, args.size, args.sampler_steps
     lat = (B, 8, 12, size // 8, size // 8)
     nv, na = 6 * (size // 32) ** 2, 37
-    mods, tdim = build_modules(dev)
-    av, aa, core, head = mods
     abar = su.alphas_cumprod_from_betas(su.make_beta_schedule(1000, "cosine", 1e-4, 0.02))[1]
     sched = su.make_sampling_schedule(1000, S)
-
     # conditioning: root draws the global batch of prompt latents, ONE broadcast, each rank keeps its shard
     gshape = (B * world, 8, 150)
     cond = torch.randn(gshape, generator=torch.Generator().manual_seed(2)) if rank == 0 else None
-    cond_all = D.broadcast_conditioning(cond, gshape, dev if args.backend == "nccl" else torch.device("cpu")).to(dev)
+    cond_all = D.broadcast_conditioning(cond, gshape, comm_dev).to(dev)
     z_a0 = D.local_conditioning(cond_all, rank, world)
     z0 = torch.randn(lat, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
+    return dict(rank=rank, world=world, local=local, dev=dev, comm_dev=comm_dev, B=B, size=size, S=S, lat=lat, nv=nv, na=na,
+                abar=abar, sched=sched, z_a0=z_a0, z0=z0, global_batch=B * world)
 
-    eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=tdim, target="video",
-                          latent_shape=lat, prompt_tokens=na, alpha_bar=abar, guidance=args.guidance,
-                          split_streams=bool(args.split_streams), matmul=args.matmul)
-    eng.set_prompt(z_a0)
-    eng.begin(sched)
+
+def roofline_of(rep, matmul: str, n_steps: int):
+    """dominant-kernel roofline object + per-kernel table from the library's per-launch HIP-event records"""
+    dom = max((k for k in rep if k.startswith("gemm")), key=lambda k: rep[k][1])   # most time => dominant
+    n, ms, work = rep[dom]
+    achieved = work / (ms * 1e-3) / 1e12
+
+    def peak_of(name):
+        if name.startswith(("gemm_bf16x3", "attn_bf16x3")):
+            terms = int(name.rstrip(">").split(",")[-1].split("<")[-1])
+            return PEAK_BF16_MATRIX_TFLOPS / terms
+        return PEAK_F32_MATRIX_TFLOPS
+
+    traffic, source = pmc_traffic(dom, matmul)
+    roof = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": peak_of(dom), "unit": "TFLOP/s",
+            "frac": achieved / peak_of(dom), "traffic": traffic, "traffic_source": source,
+            "launches": n, "avg_launch_us": 1e3 * ms / max(n, 1), "flops_per_launch": work / max(n, 1)}
+    tot_ms = sum(v[1] for v in rep.values())
+    kern = {}
+    for k, (cnt, kms, w) in rep.items():
+        if cnt == 0:
+            continue
+        e = {"launches_per_step": cnt / n_steps, "ms_per_step": kms / n_steps, "share": kms / tot_ms}
+        if k.startswith(("gemm", "attn")):
+            e["tflops"] = w / (kms * 1e-3) / 1e12
+            e["frac_of_mfma_peak_for_its_dtype"] = e["tflops"] / peak_of(k)
+        else:
+            e["gbs"] = w / (kms * 1e-3) / 1e9
+            e["frac_of_hbm_peak"] = e["gbs"] / PEAK_HBM_GBS
+        kern[k] = e
+    return roof, kern
+
+
+def main():
+    args = parse_args()
+    from multimodal_diffusion_amd import dist as D, _lib as L
+    import multimodal_diffusion_amd as A
+
+    ctx = setup_run(args)
+    rank, world, dev = ctx["rank"], ctx["world"], ctx["dev"]
+    B, size, S, lat, nv, na = ctx["B"], ctx["size"], ctx["S"], ctx["lat"], ctx["nv"], ctx["na"]
+    abar, sched, z_a0, z0 = ctx["abar"], ctx["sched"], ctx["z_a0"], ctx["z0"]
+    mods, tdim = build_modules(dev)
+    av, aa, core, head = mods
+
+    def make_engine(mode):
+        e = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=tdim, target="video",
+                            latent_shape=lat, prompt_tokens=na, alpha_bar=abar, guidance=args.guidance,
+                            split_streams=bool(args.split_streams), matmul=mode)
+        e.set_prompt(z_a0)
+        e.begin(sched)
+        return e
+
+    eng = make_engine(args.matmul)
     za, zb = z0.clone(), torch.empty_like(z0)
 
     graph = None
@@ -203,27 +288,33 @@ def main():
     run_steps(args.steps)
     torch.cuda.synchronize()
     D.barrier()
-    dt = D.max_over_ranks(time.perf_counter() - t0, dev if args.backend == "nccl" else torch.device("cpu"))
+    dt = D.max_over_ranks(time.perf_counter() - t0, ctx["comm_dev"])
     assert torch.isfinite(za).all(), "non-finite latent after the timed region"
 
     out = None
     if rank == 0:
         fl = step_flops_per_sample(nv, na) * B
+        per_gpu = args.steps / dt
         out = {
             "metric": "denoising steps/sec @256x256 multimodal-cond batch=32",
-            "value": world * args.steps / dt,
+            # whole-job aggregate under weak scaling: every rank steps its own batch of 32, so N ranks complete N batch-32 steps
+            # per step time.  The global-batch (32 N samples) step rate is per_gpu_steps_per_s.
+            "value": world * per_gpu,
             "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.matmul == "f32" else "f32 via 3xbf16 split operands (6-term products, f32 accumulate)",
+            "dtype": MODE_DTYPE[args.matmul],
             "data": "synthetic",
             "config": {"workload": f"C3: {size}x{size} audio->video CFG denoising step (cond+null MMDiT d512 L8 H8 + noise head + "
                                    f"DDIM), {nv}+{na} tokens, batch {B} per GPU, DDIM {S} steps, guidance {args.guidance}",
                        "global_batch": B * world, "tokens": nv + na, "sampler_steps": S,
                        "parallelism": f"dp{world}", "launch": "hipgraph" if args.graph else "eager", "matmul": args.matmul},
-            "sample_steps_per_s": world * B * args.steps / dt,
-            "algorithmic_tflops": fl * world * args.steps / dt / 1e12,
+            "per_gpu_steps_per_s": per_gpu,
+            "value_is": "sum over ranks of batch-32 steps/s (weak scaling); per_gpu_steps_per_s is the global-batch step rate",
+            "sample_steps_per_s": world * B * per_gpu,
+            "algorithmic_tflops_per_gpu": fl * per_gpu / 1e12,
+            "algorithmic_tflops_total": fl * world * per_gpu / 1e12,
         }
 
     # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream, separate instrumented pass
@@ -236,34 +327,10 @@ def main():
         graph = saved
         torch.cuda.synchronize()
         L.prof_enable(False)
-        rep = L.prof_report()
-        dom = max((k for k in rep if k.startswith("gemm")), key=lambda k: rep[k][1])   # most time => dominant
-        n, ms, work = rep[dom]
-        achieved = work / (ms * 1e-3) / 1e12
-        peak = PEAK_BF16X3_EQUIV_TFLOPS if dom.startswith("gemm_bf16x3") else PEAK_F32_MATRIX_TFLOPS
-        out["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": peak,
-                           "unit": "TFLOP/s", "frac": achieved / peak, "traffic": pmc_traffic(dom),
-                           "launches": n, "avg_launch_us": 1e3 * ms / max(n, 1),
-                           "flops_per_launch": work / max(n, 1)}
-        tot_ms = sum(v[1] for v in rep.values())
-        kern = {}
-        for k, (cnt, kms, w) in rep.items():
-            if cnt == 0:
-                continue
-            e = {"launches_per_step": cnt / 5, "ms_per_step": kms / 5, "share": kms / tot_ms}
-            if k.startswith("gemm") or k.startswith("attn"):
-                e["tflops"] = w / (kms * 1e-3) / 1e12
-                if k.startswith("gemm_bf16x3"):
-                    e["frac_of_bf16_mfma_peak_div6"] = e["tflops"] / PEAK_BF16X3_EQUIV_TFLOPS
-                else:
-                    e["frac_of_f32_mfma_peak"] = e["tflops"] / PEAK_F32_MATRIX_TFLOPS
-            else:
-                e["gbs"] = w / (kms * 1e-3) / 1e9
-                e["frac_of_hbm_peak"] = e["gbs"] / PEAK_HBM_GBS
-            kern[k] = e
-        out["kernels"] = kern
+        out["roofline"], out["kernels"] = roofline_of(L.prof_report(), args.matmul, 5)
 
     # ---- CPU baseline: the oracle (a from-scratch torch port of the reference step) on this host's cores
+    tn = tp = cpu_ref = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import ref_cpu as R
         cores = host_cores()
@@ -276,64 +343,57 @@ def main():
         kw = dict(adapt_v=W["adapt_v"], adapt_a=W["adapt_a"], core=W["core"], head=W["head"], n_layers=8, n_heads=8,
                   guidance=args.guidance)
         with torch.no_grad():
-            ref = R.denoise_step_a2v(zc, zac, tn, tp, abar, **kw)           # warm-up, also the parity reference
+            cpu_ref = R.denoise_step_a2v(zc, zac, tn, tp, abar, **kw)           # warm-up, also the parity reference
             c0 = time.perf_counter()
             for _ in range(args.cpu_steps):
                 R.denoise_step_a2v(zc, zac, tn, tp, abar, **kw)
             cdt = (time.perf_counter() - c0) / args.cpu_steps
         got = eng.step(z0, tn.to(dev), tp.to(dev)).cpu()
-        err = float((got - ref).abs().max() / max(1.0, float(ref.abs().max())))
-        cpu_ref = ref
+        err = float((got - cpu_ref).abs().max() / max(1.0, float(cpu_ref.abs().max())))
         out["cpu_baseline"] = {"value": 1.0 / cdt, "unit": "steps/s", "cores": cores, "kind": "port",
                                "sample": f"{args.cpu_steps} timed steps (+1 warm-up) of the same batch-{B} {size}x{size} step, "
                                          f"fp32 torch CPU oracle, {cores} threads",
                                "ms_per_step": 1e3 * cdt}
         out["parity_rel_err_vs_cpu_oracle"] = err
 
-    # ---- the other matmul mode, measured the same way right after (N=1 only; never part of `value`)
+    # ---- the other matmul modes, measured the same way right after (N=1 only; never part of `value`)
     if rank == 0 and world == 1 and not args.no_alt:
-        other = "bf16x3" if args.matmul == "f32" else "f32"
-        eng2 = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=tdim, target="video",
-                               latent_shape=lat, prompt_tokens=na, alpha_bar=abar, guidance=args.guidance,
-                               split_streams=bool(args.split_streams), matmul=other)
-        eng2.set_prompt(z_a0)
-        eng2.begin(sched)
-        za2, zb2 = z0.clone(), torch.empty_like(z0)
+        alts = []
+        for other in ("f32", "bf16x3", "bf16x3_strict"):
+            if other == args.matmul:
+                continue
+            eng2 = make_engine(other)
+            za2, zb2 = z0.clone(), torch.empty_like(z0)
 
-        def run2(k):
-            nonlocal za2, zb2
-            for i in range(k):
-                if i % S == 0:
-                    eng2.rewind()
-                    za2.copy_(z0)
-                eng2.advance(za2, zb2)
-                za2, zb2 = zb2, za2
+            def run2(k):
+                nonlocal za2, zb2
+                for i in range(k):
+                    if i % S == 0:
+                        eng2.rewind()
+                        za2.copy_(z0)
+                    eng2.advance(za2, zb2)
+                    za2, zb2 = zb2, za2
 
-        run2(args.warmup)
-        torch.cuda.synchronize()
-        a0 = time.perf_counter()
-        run2(args.steps)
-        torch.cuda.synchronize()
-        adt = time.perf_counter() - a0
-        alt = {"matmul": other, "value": args.steps / adt, "unit": "steps/s", "ms_per_step": 1e3 * adt / args.steps,
-               "algorithmic_tflops": step_flops_per_sample(nv, na) * B * args.steps / adt / 1e12,
-               "dtype": "f32" if other == "f32" else "f32 via 3xbf16 split operands (6-term products, f32 accumulate)"}
-        if not args.no_roofline:
-            L.prof_enable(True)
-            run2(5)
+            run2(args.warmup)
             torch.cuda.synchronize()
-            L.prof_enable(False)
-            rep = L.prof_report()
-            dom = max((k for k in rep if k.startswith("gemm")), key=lambda k: rep[k][1])
-            n, ms, work = rep[dom]
-            ach = work / (ms * 1e-3) / 1e12
-            peak = PEAK_BF16X3_EQUIV_TFLOPS if dom.startswith("gemm_bf16x3") else PEAK_F32_MATRIX_TFLOPS
-            alt["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": pmc_traffic(dom), "avg_launch_us": 1e3 * ms / max(n, 1)}
-        if "cpu_baseline" in out:
-            got2 = eng2.step(z0, tn.to(dev), tp.to(dev)).cpu()
-            alt["parity_rel_err_vs_cpu_oracle"] = float((got2 - cpu_ref).abs().max() / max(1.0, float(cpu_ref.abs().max())))
-        out["alt"] = alt
+            a0 = time.perf_counter()
+            run2(args.steps)
+            torch.cuda.synchronize()
+            adt = time.perf_counter() - a0
+            alt = {"matmul": other, "value": args.steps / adt, "unit": "steps/s", "ms_per_step": 1e3 * adt / args.steps,
+                   "algorithmic_tflops": step_flops_per_sample(nv, na) * B * args.steps / adt / 1e12, "dtype": MODE_DTYPE[other]}
+            if not args.no_roofline and other != "bf16x3_strict":
+                L.prof_enable(True)
+                run2(5)
+                torch.cuda.synchronize()
+                L.prof_enable(False)
+                alt["roofline"], _ = roofline_of(L.prof_report(), other, 5)
+            if cpu_ref is not None:
+                got2 = eng2.step(z0, tn.to(dev), tp.to(dev)).cpu()
+                alt["parity_rel_err_vs_cpu_oracle"] = float((got2 - cpu_ref).abs().max() / max(1.0, float(cpu_ref.abs().max())))
+            alts.append(alt)
+            del eng2
+        out["alt"] = alts
 
     if rank == 0:
         print(json.dumps(out))

@@ -54,3 +54,22 @@ def test_broadcast_and_shard_world2():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert res == [(0, True, 2.0), (1, True, 2.0)]
+
+
+def test_bench_setup_under_torchrun(tmp_path):
+    """bench.py's own N > 1 setup, launched the way the driver launches it (torch.distributed.run, one process per rank),
+    with gloo on CPU: env handling, group init, the conditioning broadcast and shards, per-rank latents, max-over-ranks."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    out = tmp_path / "res"
+    env = dict(os.environ, AVD_TEST_OUT=str(out), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "tests" / "_bench_setup_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = [json.loads(Path(f"{out}.{k}").read_text()) for k in range(2)]
+    assert [x["rank"] for x in res] == [0, 1] and all(x["ok"] and x["world"] == 2 for x in res)
+    assert all(x["slow"] == 1.5 and x["global_batch"] == 6 and x["nv"] == 24 for x in res)

@@ -51,7 +51,10 @@ for k, v in res.items():
                   "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
                   "raw_fetch_kib": v["FETCH_SIZE"]["avg_kib"], "raw_write_kib": v["WRITE_SIZE"]["avg_kib"]}
 os.makedirs(os.path.dirname(os.path.join(root, args.out)), exist_ok=True)
-json.dump({"note": "bytes beyond L2 per launch; FETCH_SIZE doubled per the gfx950 correction; KiB units", "kernels": out},
+sys.path.insert(0, root)
+from bench import csrc_hash      # noqa: E402  (identity of the kernel sources this profile belongs to; bench.py drops it when they change)
+json.dump({"note": "bytes beyond L2 per launch; FETCH_SIZE doubled per the gfx950 correction; KiB units",
+           "csrc_sha16": csrc_hash(), "bench_args": extra, "kernels": out},
           open(os.path.join(root, args.out), "w"), indent=1)
 for k, v in sorted(out.items(), key=lambda kv: -kv[1]["traffic_bytes_per_launch"])[:12]:
     print(f"{v['traffic_bytes_per_launch'] / 1e6:10.1f} MB/launch  (fetch {v['fetch_bytes_per_launch'] / 1e6:8.1f} write {v['write_bytes_per_launch'] / 1e6:8.1f})  {k[:90]}")
