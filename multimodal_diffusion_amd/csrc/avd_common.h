@@ -193,11 +193,14 @@ int split3_f32(const float* x, int64_t ld, void* out, int64_t rows, int K, hipSt
 int rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t rows, int d, float eps, hipStream_t st);
 bool gemm_bf16x3_supported(int64_t M, int N, int K);
 int attn_f32_split3(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st);
+// sk_ws / sk_floats: optional scratch for the stream-K launch (gemm_bf16x3_sk_floats() floats); null = plain tiling
+int64_t gemm_bf16x3_sk_floats();
+extern int g_s3_streamk;
 int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* img, int64_t M, int tokens, int heads, int K, float qscale,
-                     int terms, hipStream_t st);
+                     int terms, hipStream_t st, float* sk_ws = nullptr, int64_t sk_floats = 0);
 int64_t qkv3_bytes(int B, int N, int H);
 int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms, hipStream_t st);
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
-                int act, int terms, hipStream_t st);
+                int act, int terms, hipStream_t st, float* sk_ws = nullptr, int64_t sk_floats = 0);
 
 }  // namespace avd

@@ -136,7 +136,7 @@ static int64_t core_ws_bytes(const avd_core_weights* w, int B, int N) {
     if (!core_use_split(w, M)) return fp32_path;
     // + split3 image of the norm / attention output, and the wide buffer must also hold the split3 image of the MLP hidden
     const int64_t wide_b = core_split_wide_bytes(w, B, N);
-    const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d));
+    const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d)) + align_up(gemm_bf16x3_sk_floats() * 4);
     return split_path > fp32_path ? split_path : fp32_path;
 }
 
@@ -183,18 +183,20 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
         float* qkv = cs.take((wide_b + 3) / 4);
         void* wide3 = qkv;
         void* hs = cs.take((split3_bytes(M, d) + 3) / 4);
+        const int64_t skf = gemm_bf16x3_sk_floats();
+        float* skw = cs.take(skf);            // parked partial tiles of the stream-K launches
         for (int l = 0; l < w->n_layers; ++l) {
             const avd_block_weights& b = w->blocks[l];
             const bool last = l == w->n_layers - 1;
             const int nq = (last && out_row0 == 0) ? n_out_rows : N;
             if (int rc = rmsnorm_split3_f32(cur, b.norm1_scale, hs, M, d, w->norm_eps, st)) return rc;
-            if (int rc = gemm_bf16x3_qkv3(hs, b.in_proj_weight3, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, terms, st)) return rc;
+            if (int rc = gemm_bf16x3_qkv3(hs, b.in_proj_weight3, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, terms, st, skw, skf)) return rc;
             if (int rc = attn_bf16x3(qkv, nullptr, hs, B, N, H, nq, terms, st)) return rc;
-            if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, nullptr, M, d, d, AVD_ACT_NONE, terms, st)) return rc;
+            if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, nullptr, M, d, d, AVD_ACT_NONE, terms, st, skw, skf)) return rc;
             cur = y;
             if (int rc = rmsnorm_split3_f32(y, b.norm2_scale, hs, M, d, w->norm_eps, st)) return rc;
-            if (int rc = gemm_bf16x3(hs, b.fc1_weight3, b.fc1_bias, nullptr, nullptr, wide3, M, hid, d, AVD_ACT_GELU, terms, st)) return rc;
-            if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, nullptr, M, d, hid, AVD_ACT_NONE, terms, st)) return rc;
+            if (int rc = gemm_bf16x3(hs, b.fc1_weight3, b.fc1_bias, nullptr, nullptr, wide3, M, hid, d, AVD_ACT_GELU, terms, st, skw, skf)) return rc;
+            if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, nullptr, M, d, hid, AVD_ACT_NONE, terms, st, skw, skf)) return rc;
         }
         return rmsnorm_f32(y, rd, w->final_norm_scale, y, rd, M, d, w->norm_eps, st);
     }
@@ -380,6 +382,7 @@ extern "C" const char* avd_last_error(void) { return g_err; }
 
 extern "C" int avd_tune_set(const char* key, int64_t value) {
     AVD_REQUIRE(key, AVD_EINVAL, "tune_set: null key");
+    if (!strcmp(key, "s3_streamk")) { g_s3_streamk = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_tile")) { g_gemm_force_tile = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_persist")) { g_gemm_persist = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_stages")) { g_gemm_stages = (int)value; return AVD_OK; }

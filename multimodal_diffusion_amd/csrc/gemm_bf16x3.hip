@@ -103,7 +103,94 @@ struct S3Args {
     int tokN, tokNpad, heads;   // EPI_QKV3: tokens per sample, padded tokens per sample, heads (N == 3 * heads * 64)
     float qscale;               // EPI_QKV3: factor folded into q before it is split (softmax scale * log2 e)
     int terms;                  // 6 (default), 9 (strict) or 1 (plain bf16 operands)
+    // stream-K (sk_partial != null): the grid is one resident block per slot; XCD x owns a contiguous range of tiles and its
+    // blocks split that range's (tile, K-step) sequence evenly.  A block whose range ends inside a tile parks its accumulators
+    // in sk_partial[blockIdx] and raises sk_flags[blockIdx]; the block whose range reaches the tile's end adds the parked
+    // parts in ascending block order (fixed, so results are deterministic), lowers the flags and runs the epilogue.
+    float* sk_partial;
+    unsigned int* sk_flags;
+    int ntiles;
+    int64_t sk_floats;          // host only: floats available at sk_partial
 };
+
+// flags of the stream-K launches: zero at module load, every launch leaves its slot zeroed (each flag has one consumer)
+constexpr int S3_SK_SLOTS = 32, S3_SK_FLAGS = 512;
+__device__ unsigned int g_s3_sk_flags[S3_SK_SLOTS * S3_SK_FLAGS];
+
+// segment of work of a stream-K block: tile (bm, bn), K-steps [k0, k1)
+struct SkRange {
+    int steps_lo, steps_hi, tile_base, J, j, S;
+    __device__ __forceinline__ int hi_of(int jj) const { return (int)(((int64_t)(jj + 1) * S) / J); }
+};
+__device__ __forceinline__ SkRange sk_range(int ntiles, int nk) {
+    SkRange r;
+    const int x = blockIdx.x & 7;
+    r.j = blockIdx.x >> 3;
+    r.J = gridDim.x >> 3;
+    const int q = ntiles >> 3, rem = ntiles & 7;
+    r.tile_base = x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q;
+    r.S = (q + (x < rem ? 1 : 0)) * nk;
+    r.steps_lo = (int)(((int64_t)r.j * r.S) / r.J);
+    r.steps_hi = r.hi_of(r.j);
+    return r;
+}
+
+// Segments of a block's step range [lo, hi), in the order they are PROCESSED: first the part that starts a tile it cannot
+// finish (parked and published at once, so the block that finishes that tile never waits long), then the whole tiles, last
+// the part that finishes a tile an earlier block started (by then that block's flag has long been raised).  Processing order
+// does not touch the summation order of any tile.  phase: 0 head, 1 whole tiles, 2 tail, 3 done; s = first step of the segment.
+__device__ __forceinline__ bool sk_next(const SkRange& r, int nk, int& phase, int& s, int& k0, int& k1) {
+    const int lo = r.steps_lo, hi = r.steps_hi;
+    if (lo >= hi) return false;
+    const int beg_full = (lo + nk - 1) / nk * nk;       // end of the partial tail (== lo when lo starts a tile)
+    const int end_full = hi / nk * nk;                  // start of the partial head (== hi when hi ends a tile)
+    if (beg_full > hi) {                                 // the whole range lies inside one tile and reaches neither end
+        if (phase != 0) return false;
+        phase = 3; s = lo; k0 = lo % nk; k1 = k0 + (hi - lo);
+        return true;
+    }
+    if (phase == 0) {
+        phase = 1;
+        s = beg_full - nk;                               // whole tiles start at beg_full (s is advanced before use)
+        if (hi > end_full) { s = end_full; k0 = 0; k1 = hi - end_full; phase = -1; return true; }
+    }
+    if (phase == -1) { phase = 1; s = beg_full - nk; }
+    if (phase == 1) {
+        s += nk;
+        if (s + nk <= end_full && s >= beg_full) { k0 = 0; k1 = nk; return true; }
+        phase = 2;
+    }
+    if (phase == 2) {
+        phase = 3;
+        if (beg_full > lo) { s = lo; k0 = lo % nk; k1 = nk; return true; }
+    }
+    return false;
+}
+
+// contributor side: all stores of the block retired, then one agent-scope release and the flag (cdna guide, Guideline 16)
+__device__ __forceinline__ void sk_publish(unsigned int* flag, int tid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// owner side: one lane polls (bounded: a block only ever waits on LOWER block ids of its own XCD, which are dispatched first),
+// one agent-scope acquire, barrier, then the whole block may read the parked data with plain loads
+__device__ __forceinline__ void sk_await(unsigned int* flag, int tid) {
+    if (tid == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && spins < (1 << 24)) {
+            __builtin_amdgcn_s_sleep(8);
+            ++spins;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
 
 template <int N> __device__ __forceinline__ void wait_vm() {
     static_assert(N >= 0 && N < 64, "vmcnt range");
@@ -112,8 +199,47 @@ template <int N> __device__ __forceinline__ void wait_vm() {
 
 // epilogue shared by both tile configurations: the wave's 128 x 64 accumulator tile goes through a private LDS slab in two
 // 64-row passes and is streamed out as whole 16-byte segments (mwave0 = first output row of the wave, nbase = first column)
+// Stream-K: up to three parked partial tiles (fp32 [BM][bnt] row-major, see s3_park) of the blocks that started this tile are
+// added while the tile streams out — in the fixed order p0, p1, p2 after the finishing block's own sums — so the gather costs
+// no registers beyond one float4.  tile_m0 / tile_n0: first row / column of the block tile; bnt: its width.
+struct SkParts {
+    const float* p0;
+    const float* p1;
+    const float* p2;
+    int64_t tile_m0;
+    int tile_n0, bnt;
+};
+__device__ __forceinline__ void sk_add4(const SkParts& sp, int64_t m, int n, f32x4& v) {
+    const int64_t off = (m - sp.tile_m0) * sp.bnt + (n - sp.tile_n0);
+    if (sp.p0) v += *reinterpret_cast<const f32x4*>(sp.p0 + off);
+    if (sp.p1) v += *reinterpret_cast<const f32x4*>(sp.p1 + off);
+    if (sp.p2) v += *reinterpret_cast<const f32x4*>(sp.p2 + off);
+}
+
+// park the wave's 128 x 64 accumulator tile (raw sums, no bias) in the block's partial buffer through the same LDS slab
+template <int BNT>
+__device__ __forceinline__ void s3_park(f32x16 (&acc)[4][2], float* slab, float* part, int row0, int col0, int lane) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    constexpr int CLD = 64 + 4;
+    const int cr = lane >> 4, cc = (lane & 15) * 4;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab[(i * 32 + mfma32_row(r, hi)) * CLD + j * 32 + l31] = acc[ps * 2 + i][j][r];
+        float* dst = part + (int64_t)(row0 + ps * 64 + cr) * BNT + col0 + cc;
+#pragma unroll
+        for (int it = 0; it < 16; ++it)
+            *reinterpret_cast<f32x4*>(dst + (int64_t)it * 4 * BNT) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 4) * CLD + cc);
+    }
+}
+
 template <int EPI>
-__device__ __forceinline__ void s3_epilogue(const S3Args& g, f32x16 (&acc)[4][2], float* slab, int64_t mwave0, int nbase, int lane) {
+__device__ __forceinline__ void s3_epilogue(const S3Args& g, f32x16 (&acc)[4][2], float* slab, int64_t mwave0, int nbase, int lane,
+                                            const SkParts& sp) {
     const int l31 = lane & 31, hi = lane >> 5;
     // epilogue: two 64-row passes per wave through a private LDS slab, streamed out as whole 16-byte segments
     constexpr int CLD = 64 + 4, TN = 2;
@@ -144,6 +270,10 @@ __device__ __forceinline__ void s3_epilogue(const S3Args& g, f32x16 (&acc)[4][2]
                 float v[8];
                 *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + c * 8);
                 *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + c * 8 + 4);
+                if (sp.p0) {
+                    sk_add4(sp, m, n, *reinterpret_cast<f32x4*>(v));
+                    sk_add4(sp, m, n + 4, *reinterpret_cast<f32x4*>(v + 4));
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * mul;
                 if (m < g.M) {
@@ -169,6 +299,10 @@ __device__ __forceinline__ void s3_epilogue(const S3Args& g, f32x16 (&acc)[4][2]
                 float v[8];
                 *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + cc);
                 *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + cc + 4);
+                if (sp.p0) {
+                    sk_add4(sp, m, n, *reinterpret_cast<f32x4*>(v));
+                    sk_add4(sp, m, n + 4, *reinterpret_cast<f32x4*>(v + 4));
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e] + bv[e]);
                 if (m < g.M) store_split8(g.C3, m, n, g.N, v);
@@ -194,6 +328,7 @@ __device__ __forceinline__ void s3_epilogue(const S3Args& g, f32x16 (&acc)[4][2]
                 for (int u = 0; u < 8; ++u) {
                     const int it = c0 + u;
                     f32x4 v = *reinterpret_cast<const f32x4*>(slab + (cr + it * 4) * CLD + cc);
+                    if (sp.p0) sk_add4(sp, m0 + cr + it * 4, n, v);
                     v += bv;
                     if constexpr (EPI == S3_EPI_RES) v += rv[u];
                     if (m0 + cr + it * 4 < g.M) *reinterpret_cast<f32x4*>(cptr + (int64_t)it * 4 * g.N) = v;
@@ -216,7 +351,7 @@ constexpr int S3_BM = 256, S3_BN = 256, S3_NST = 3;
 constexpr int S3_STAGE = (S3_BM + S3_BN) * 96;          // 48 KiB
 constexpr int S3_LDS = S3_NST * S3_STAGE;                // 144 KiB (the epilogue slabs, 8 x 64 x 68 floats, fit inside)
 
-template <int EPI, int TERMS>
+template <int EPI, int TERMS, bool SK>
 __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
     constexpr int BM = S3_BM, BN = S3_BN, WM = 128, WN = 64;
     constexpr int TM = 4, TN = 2, NST = S3_NST, STAGE = S3_STAGE;
@@ -225,56 +360,32 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
     constexpr int PPW = 4 * PPR / 8;                      // 4 regions per stage / 8 waves
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
-    int wg;
-    {
-        const int b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
-        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    constexpr bool sk = SK;
+    int bm, bn;
+    SkRange skr{};
+    int sk_s = 0, sk_phase = 0;
+    if (!sk) {
+        int wg;
+        {
+            const int b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+            wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        }
+        // super-tiles of sm x sn blocks: the blocks an XCD runs together share sm A panels and sn W panels
+        const int per_row = g.sm * g.nbn, per_st = g.sm * g.sn;
+        const int srow = wg / per_row, rem = wg % per_row;
+        const int sc = rem / per_st, rem2 = rem % per_st;
+        bm = srow * g.sm + rem2 / g.sn;
+        bn = sc * g.sn + rem2 % g.sn;
+        if ((int64_t)bm * BM >= g.M) return;
+    } else {
+        skr = sk_range(g.ntiles, g.K >> 4);
+        bm = bn = 0;
     }
-    // super-tiles of sm x sn blocks: the blocks an XCD runs together share sm A panels and sn W panels
-    const int per_row = g.sm * g.nbn, per_st = g.sm * g.sn;
-    const int srow = wg / per_row, rem = wg % per_row;
-    const int sc = rem / per_st, rem2 = rem % per_st;
-    const int bm = srow * g.sm + rem2 / g.sn;
-    const int bn = sc * g.sn + rem2 % g.sn;
-    if ((int64_t)bm * BM >= g.M) return;
-
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave >> 2, wn = wave & 3;
     const int ng = g.K >> 4;
     const int nrtA = (int)((g.M + 127) >> 7);
-
-    // DMA: the stage image is [A row-tile 0 | A row-tile 1 | W row-tile 0 | W row-tile 1], each a 12 KiB chunk of which the
-    // first NPL planes (4 KiB each) are moved
-    const unsigned char* src[PPW];
-    int dst_off[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int q = wave * PPW + i;
-        const int region = q / PPR, within = (q % PPR) * 1024;
-        dst_off[i] = region * S3_CHUNK + within;
-        if (region < 2) {
-            int rt = bm * 2 + region;
-            rt = rt < nrtA ? rt : nrtA - 1;
-            src[i] = g.A + (int64_t)rt * ng * S3_CHUNK + within + lane * 16;
-        } else {
-            src[i] = g.W + (int64_t)(bn * 2 + region - 2) * ng * S3_CHUNK + within + lane * 16;
-        }
-    }
-    auto issue = [&](int kt, int buf) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i)
-            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(src[i] + (int64_t)kt * S3_CHUNK),
-                                             AVD_LDS_PTR(smem3 + buf * STAGE + dst_off[i]), 16, 0, 0);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     int a_off[TM], b_off[TN];
 #pragma unroll
@@ -287,40 +398,107 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
         const int r = BM + wn * WN + j * 32 + l31;
         b_off[j] = (r >> 7) * S3_CHUNK + (r & 127) * 32 + ((hi ^ ((r >> 3) & 1)) << 4);
     }
-
-    const int nk = ng;
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
-    int cur = 0, nxt = NST - 1;
     using TT = S3Terms<TERMS>;
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + NST - 1 <= nk) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>();
-        asm volatile("s_barrier" ::: "memory");   // no fence: a fence would drain vmcnt and with it the tiles in flight
-        if (kt + NST - 1 < nk) issue(kt + NST - 1, nxt);
-        const unsigned char* st = smem3 + cur * STAGE;
-        cur = cur + 1 == NST ? 0 : cur + 1;
-        nxt = nxt + 1 == NST ? 0 : nxt + 1;
-        bf16x8 af[TM][NPL], bf[TN][NPL];
+    constexpr int CLD = WN + 4;
+
+    for (;;) {      // segments of a stream-K block; exactly one pass otherwise
+        int k0 = 0, k1 = ng;
+        if (sk) {
+            if (!sk_next(skr, ng, sk_phase, sk_s, k0, k1)) break;
+            const int t = skr.tile_base + sk_s / ng;
+            bm = __builtin_amdgcn_readfirstlane(t / g.nbn);
+            bn = __builtin_amdgcn_readfirstlane(t % g.nbn);
+            k0 = __builtin_amdgcn_readfirstlane(k0);
+            k1 = __builtin_amdgcn_readfirstlane(k1);
+        }
+        // DMA: the stage image is [A row-tile 0 | A row-tile 1 | W row-tile 0 | W row-tile 1], each a 12 KiB chunk of which the
+        // first NPL planes (4 KiB each) are moved
+        const unsigned char* src[PPW];
+        int dst_off[PPW];
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int q = wave * PPW + i;
+            const int region = q / PPR, within = (q % PPR) * 1024;
+            dst_off[i] = region * S3_CHUNK + within;
+            if (region < 2) {
+                int rt = bm * 2 + region;
+                rt = rt < nrtA ? rt : nrtA - 1;
+                src[i] = g.A + ((int64_t)rt * ng + k0) * S3_CHUNK + within + lane * 16;
+            } else {
+                src[i] = g.W + ((int64_t)(bn * 2 + region - 2) * ng + k0) * S3_CHUNK + within + lane * 16;
+            }
+        }
+        auto issue = [&](int kt, int buf) {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i)
+                __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(src[i] + (int64_t)kt * S3_CHUNK),
+                                                 AVD_LDS_PTR(smem3 + buf * STAGE + dst_off[i]), 16, 0, 0);
+        };
+
+        f32x16 acc[TM][TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int p = 0; p < NPL; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + S3_PLANE * p);
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + S3_PLANE * p);
-#pragma unroll
-        for (int t = 0; t < TT::N; ++t)
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        const int nk = k1 - k0;
+        issue(0, 0);
+        if (nk > 1) issue(1, 1);
+        int cur = 0, nxt = NST - 1;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + NST - 1 <= nk) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>();
+            asm volatile("s_barrier" ::: "memory");   // no fence: a fence would drain vmcnt and with it the tiles in flight
+            if (kt + NST - 1 < nk) issue(kt + NST - 1, nxt);
+            const unsigned char* st = smem3 + cur * STAGE;
+            cur = cur + 1 == NST ? 0 : cur + 1;
+            nxt = nxt + 1 == NST ? 0 : nxt + 1;
+            bf16x8 af[TM][NPL], bf[TN][NPL];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TT::PA[t]], bf[j][TT::PB[t]], acc[i][j], 0, 0, 0);
-    }
-    __syncthreads();
+                for (int p = 0; p < NPL; ++p) af[i][p] = *reinterpret_cast<const bf16x8*>(st + a_off[i] + S3_PLANE * p);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int p = 0; p < NPL; ++p) bf[j][p] = *reinterpret_cast<const bf16x8*>(st + b_off[j] + S3_PLANE * p);
+#pragma unroll
+            for (int t = 0; t < TT::N; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TT::PA[t]], bf[j][TT::PB[t]], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
 
-    constexpr int CLD = WN + 4;
-    s3_epilogue<EPI>(g, acc, reinterpret_cast<float*>(smem3) + wave * 64 * CLD, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane);
+        float* slab = reinterpret_cast<float*>(smem3) + wave * 64 * CLD;
+        SkParts sp{nullptr, nullptr, nullptr, (int64_t)bm * BM, bn * BN, BN};
+        if (sk && k1 < ng) {
+            // the range ends inside this tile: park the partial sums for the block that finishes the tile
+            s3_park<BN>(acc, slab, g.sk_partial + (int64_t)blockIdx.x * (BM * BN), wm * WM, wn * WN, lane);
+            sk_publish(g.sk_flags + blockIdx.x, tid);
+            continue;
+        }
+        if (sk && k0 > 0) {
+            // this block finishes a tile other blocks of its XCD started: their parts are added in ascending block order
+            const int T0 = (sk_s / ng) * ng;                     // first step of the tile in the XCD's step sequence
+            int first = skr.j - 1;
+            while (first > 0 && skr.hi_of(first - 1) > T0) --first;
+            int np = 0;
+            for (int jj = first; jj < skr.j; ++jj, ++np) {
+                const int bid = jj * 8 + (blockIdx.x & 7);
+                sk_await(g.sk_flags + bid, tid);
+                if (tid == 0) __hip_atomic_store(g.sk_flags + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float* pp = g.sk_partial + (int64_t)bid * (BM * BN);
+                if (np == 0) sp.p0 = pp; else if (np == 1) sp.p1 = pp; else sp.p2 = pp;
+            }
+        }
+        s3_epilogue<EPI>(g, acc, slab, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane, sp);
+        if (!sk) break;
+        __syncthreads();      // slabs drained before the next segment's DMA lands on them
+    }
 }
 
 // Second tile configuration: 256 x 128 block, 4 waves (same 128 x 64 wave tile), TWO blocks per CU so that one block's
@@ -332,7 +510,7 @@ constexpr int S3B_BM = 256, S3B_BN = 128;
 constexpr int S3B_STAGE = (S3B_BM + S3B_BN) * 96;        // 36 KiB
 constexpr int S3B_LDS = 2 * S3B_STAGE;                    // 72 KiB (4 epilogue slabs of 64 x 68 floats fit inside)
 
-template <int EPI, int TERMS>
+template <int EPI, int TERMS, bool SK>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
     constexpr int BM = S3B_BM, BN = S3B_BN, WM = 128, WN = 64;
     constexpr int TM = 4, TN = 2, STAGE = S3B_STAGE;
@@ -341,54 +519,32 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
     constexpr int PPW = 3 * PPR / 4;                      // 3 regions per stage / 4 waves
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
-    int wg;
-    {
-        const int b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
-        wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    constexpr bool sk = SK;
+    int bm, bn;
+    SkRange skr{};
+    int sk_s = 0, sk_phase = 0;
+    if (!sk) {
+        int wg;
+        {
+            const int b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+            wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        }
+        const int per_row = g.sm * g.nbn, per_st = g.sm * g.sn;
+        const int srow = wg / per_row, rem = wg % per_row;
+        const int sc = rem / per_st, rem2 = rem % per_st;
+        bm = srow * g.sm + rem2 / g.sn;
+        bn = sc * g.sn + rem2 % g.sn;
+        if ((int64_t)bm * BM >= g.M) return;
+    } else {
+        skr = sk_range(g.ntiles, g.K >> 4);
+        bm = bn = 0;
     }
-    const int per_row = g.sm * g.nbn, per_st = g.sm * g.sn;
-    const int srow = wg / per_row, rem = wg % per_row;
-    const int sc = rem / per_st, rem2 = rem % per_st;
-    const int bm = srow * g.sm + rem2 / g.sn;
-    const int bn = sc * g.sn + rem2 % g.sn;
-    if ((int64_t)bm * BM >= g.M) return;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int ng = g.K >> 4;
     const int nrtA = (int)((g.M + 127) >> 7);
-
-    // stage image [A row-tile 0 | A row-tile 1 | W row-tile], 12 KiB chunks of which the first NPL planes are moved
-    const unsigned char* src[PPW];
-    int dst_off[PPW];
-#pragma unroll
-    for (int i = 0; i < PPW; ++i) {
-        const int q = wave * PPW + i;
-        const int region = q / PPR, within = (q % PPR) * 1024;
-        dst_off[i] = region * S3_CHUNK + within;
-        if (region < 2) {
-            int rt = bm * 2 + region;
-            rt = rt < nrtA ? rt : nrtA - 1;
-            src[i] = g.A + (int64_t)rt * ng * S3_CHUNK + within + lane * 16;
-        } else {
-            src[i] = g.W + (int64_t)bn * ng * S3_CHUNK + within + lane * 16;
-        }
-    }
-    auto issue = [&](int kt, int buf) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i)
-            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(src[i] + (int64_t)kt * S3_CHUNK),
-                                             AVD_LDS_PTR(smem3 + buf * STAGE + dst_off[i]), 16, 0, 0);
-    };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     int a_off[TM], b_off[TN];
 #pragma unroll
@@ -406,7 +562,48 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
 #define S3_MM(A_, B_) _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][j], 0, 0, 0)
 
-    const int nk = ng;
+    for (;;) {      // segments of a stream-K block; exactly one pass otherwise
+    int k0 = 0, k1 = ng;
+    if (sk) {
+        if (!sk_next(skr, ng, sk_phase, sk_s, k0, k1)) break;
+        const int t = skr.tile_base + sk_s / ng;
+        bm = __builtin_amdgcn_readfirstlane(t / g.nbn);
+        bn = __builtin_amdgcn_readfirstlane(t % g.nbn);
+        k0 = __builtin_amdgcn_readfirstlane(k0);
+        k1 = __builtin_amdgcn_readfirstlane(k1);
+    }
+    // stage image [A row-tile 0 | A row-tile 1 | W row-tile], 12 KiB chunks of which the first NPL planes are moved
+    const unsigned char* src[PPW];
+    int dst_off[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int q = wave * PPW + i;
+        const int region = q / PPR, within = (q % PPR) * 1024;
+        dst_off[i] = region * S3_CHUNK + within;
+        if (region < 2) {
+            int rt = bm * 2 + region;
+            rt = rt < nrtA ? rt : nrtA - 1;
+            src[i] = g.A + ((int64_t)rt * ng + k0) * S3_CHUNK + within + lane * 16;
+        } else {
+            src[i] = g.W + ((int64_t)bn * ng + k0) * S3_CHUNK + within + lane * 16;
+        }
+    }
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(src[i] + (int64_t)kt * S3_CHUNK),
+                                             AVD_LDS_PTR(smem3 + buf * STAGE + dst_off[i]), 16, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = k1 - k0;
     issue(0, 0);
     wait_vm<0>();
     asm volatile("s_barrier" ::: "memory");
@@ -471,12 +668,35 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) ah[i] = ah_n[i];
     }
+    __syncthreads();
+    constexpr int CLD = WN + 4;
+    float* slab = reinterpret_cast<float*>(smem3) + wave * 64 * CLD;
+    SkParts sp{nullptr, nullptr, nullptr, (int64_t)bm * BM, bn * BN, BN};
+    if (sk && k1 < ng) {
+        s3_park<BN>(acc, slab, g.sk_partial + (int64_t)blockIdx.x * (BM * BN), wm * WM, wn * WN, lane);
+        sk_publish(g.sk_flags + blockIdx.x, tid);
+        continue;
+    }
+    if (sk && k0 > 0) {
+        const int T0 = (sk_s / ng) * ng;
+        int first = skr.j - 1;
+        while (first > 0 && skr.hi_of(first - 1) > T0) --first;
+        int np = 0;
+        for (int jj = first; jj < skr.j; ++jj, ++np) {
+            const int bid = jj * 8 + (blockIdx.x & 7);
+            sk_await(g.sk_flags + bid, tid);
+            if (tid == 0) __hip_atomic_store(g.sk_flags + bid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float* pp = g.sk_partial + (int64_t)bid * (BM * BN);
+            if (np == 0) sp.p0 = pp; else if (np == 1) sp.p1 = pp; else sp.p2 = pp;
+        }
+    }
+    s3_epilogue<EPI>(g, acc, slab, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane, sp);
+    if (!sk) break;
+    __syncthreads();      // slabs drained before the next segment's DMA lands on them
+    }   // segments
 #undef S3_LDA
 #undef S3_LDB
 #undef S3_MM
-    __syncthreads();
-    constexpr int CLD = WN + 4;
-    s3_epilogue<EPI>(g, acc, reinterpret_cast<float*>(smem3) + wave * 64 * CLD, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -534,16 +754,74 @@ static int s3_tile_for(int epi, int64_t M, int N) {
     return (M + 255) / 256 * (N / 256) >= 192 ? 0 : 1;
 }
 
+int g_s3_streamk = getenv("AVD_S3_STREAMK") ? atoi(getenv("AVD_S3_STREAMK")) : 1;
+
+static int sk_cu_count() {                 // CUs of the current device (looked up once per device)
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int n = dev < 64 ? cache[dev].load(std::memory_order_acquire) : 0;
+    if (!n) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        n = prop.multiProcessorCount;
+        if (dev < 64) cache[dev].store(n, std::memory_order_release);
+    }
+    return n;
+}
+static int sk_flags_base(unsigned int** out) {
+    static std::atomic<unsigned int*> cache[64];
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return set_error(AVD_ELAUNCH, "stream-K flags: hipGetDevice: %s", hipGetErrorString(e));
+    unsigned int* p = dev < 64 ? cache[dev].load(std::memory_order_acquire) : nullptr;
+    if (!p) {
+        e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_s3_sk_flags));
+        if (e != hipSuccess) return set_error(AVD_ELAUNCH, "stream-K flags: %s", hipGetErrorString(e));
+        if (dev < 64) cache[dev].store(p, std::memory_order_release);
+    }
+    *out = p;
+    return AVD_OK;
+}
+
 template <int EPI, int TERMS>
 static int launch_s3t(const S3Args& a, hipStream_t st) {
     const int tile = s3_tile_for(EPI, a.M, a.N);
     const int BMt = tile ? S3B_BM : S3_BM, BNt = tile ? S3B_BN : S3_BN, lds = tile ? S3B_LDS : S3_LDS;
     static LdsAttr attr[2];
-    const void* kern = tile ? reinterpret_cast<const void*>(gemm_bf16x3_b_kernel<EPI, TERMS>)
-                            : reinterpret_cast<const void*>(gemm_bf16x3_kernel<EPI, TERMS>);
+    const void* kern = tile ? reinterpret_cast<const void*>(gemm_bf16x3_b_kernel<EPI, TERMS, false>)
+                            : reinterpret_cast<const void*>(gemm_bf16x3_kernel<EPI, TERMS, false>);
     if (int rc = attr[tile].ensure(kern, lds, "gemm_bf16x3")) return rc;
     S3Args g = a;
     g.nbn = a.N / BNt;
+    // stream-K when the caller lent scratch for the parked partial tiles and plain tiling would leave a ragged last round
+    {
+        const int64_t nbm_ = (a.M + BMt - 1) / BMt;
+        const int64_t ntiles = nbm_ * g.nbn;
+        const int G = (tile ? 2 : 1) * sk_cu_count();
+        const bool ragged = ntiles % G != 0;
+        if (g_s3_streamk && a.sk_partial && G > 0 && G % 8 == 0 && G <= S3_SK_FLAGS && ntiles >= G / 2 && ntiles < (1 << 20) && ragged &&
+            a.sk_floats >= (int64_t)G * BMt * BNt) {
+            static std::atomic<unsigned> seq{0};
+            unsigned int* fbase = nullptr;
+            if (int rc = sk_flags_base(&fbase)) return rc;
+            g.sk_flags = fbase + (seq.fetch_add(1) % S3_SK_SLOTS) * S3_SK_FLAGS;
+            g.ntiles = (int)ntiles;
+            g.sm = g.sn = 1;
+            static const int tagk0 = prof_tag_id("gemm_bf16x3_kernel<%d, %d>", EPI, TERMS), tagk1 = prof_tag_id("gemm_bf16x3_b_kernel<%d, %d>", EPI, TERMS);
+            ProfScope prof(tile ? tagk1 : tagk0, 2.0 * (double)a.M * a.N * a.K, st);
+            static LdsAttr attrk[2];
+            const void* kk = tile ? reinterpret_cast<const void*>(gemm_bf16x3_b_kernel<EPI, TERMS, true>)
+                                  : reinterpret_cast<const void*>(gemm_bf16x3_kernel<EPI, TERMS, true>);
+            if (int rc = attrk[tile].ensure(kk, lds, "gemm_bf16x3 (stream-K)")) return rc;
+            if (tile) hipLaunchKernelGGL((gemm_bf16x3_b_kernel<EPI, TERMS, true>), dim3((unsigned)G), dim3(256), lds, st, g);
+            else hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI, TERMS, true>), dim3((unsigned)G), dim3(512), lds, st, g);
+            AVD_CHECK_LAUNCH("gemm_bf16x3 (stream-K)");
+            return AVD_OK;
+        }
+        g.sk_partial = nullptr;
+        g.sk_flags = nullptr;
+    }
     int sn = 8;
     while (g.nbn % sn) sn >>= 1;
     // 256x128 tiles: whole block rows per super-tile, so the 12-16 column blocks that share an A panel run together and the panel
@@ -563,8 +841,8 @@ static int launch_s3t(const S3Args& a, hipStream_t st) {
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
     static const int tag0 = prof_tag_id("gemm_bf16x3_kernel<%d, %d>", EPI, TERMS), tag1 = prof_tag_id("gemm_bf16x3_b_kernel<%d, %d>", EPI, TERMS);
     ProfScope prof(tile ? tag1 : tag0, 2.0 * (double)a.M * a.N * a.K, st);
-    if (tile) hipLaunchKernelGGL((gemm_bf16x3_b_kernel<EPI, TERMS>), dim3((unsigned)nwg), dim3(256), lds, st, g);
-    else hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI, TERMS>), dim3((unsigned)nwg), dim3(512), lds, st, g);
+    if (tile) hipLaunchKernelGGL((gemm_bf16x3_b_kernel<EPI, TERMS, false>), dim3((unsigned)nwg), dim3(256), lds, st, g);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI, TERMS, false>), dim3((unsigned)nwg), dim3(512), lds, st, g);
     AVD_CHECK_LAUNCH("gemm_bf16x3");
     return AVD_OK;
 }
@@ -581,15 +859,17 @@ static int launch_s3(const S3Args& a, hipStream_t st) {
 
 // C = act(A W^T + bias) (+ residual).  C3 != null: the output is written as a split3 image (act must be GELU);
 // otherwise fp32 row-major into C (act NONE; residual optional, may alias C).
+int64_t gemm_bf16x3_sk_floats() { return (int64_t)2 * (sk_cu_count() > 0 ? sk_cu_count() : 256) * S3B_BM * S3B_BN; }
+
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
-                int act, int terms, hipStream_t st) {
+                int act, int terms, hipStream_t st, float* sk_ws, int64_t sk_floats) {
     AVD_REQUIRE(A3 && W3 && (C || C3), AVD_EINVAL, "gemm_bf16x3: null pointer");
     AVD_REQUIRE(gemm_bf16x3_supported(M, N, K), AVD_EUNSUPPORTED, "gemm_bf16x3: need N %% 256 == 0 and K %% 16 == 0 (M=%lld N=%d K=%d)",
                 (long long)M, N, K);
     AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(C) && aligned16(C3) && aligned16(bias) && aligned16(R), AVD_EUNSUPPORTED,
                 "gemm_bf16x3: pointers must be 16-byte aligned");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, R, C,
-             static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0, 0, 0, 0, 0.f, terms};
+             static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0, 0, 0, 0, 0.f, terms, sk_ws, nullptr, 0, sk_floats};
     if (C3) {
         AVD_REQUIRE(act == AVD_ACT_GELU && !R && bias, AVD_EUNSUPPORTED, "gemm_bf16x3: split3 output implies bias + GELU, no residual");
         return launch_s3<S3_EPI_GELU_SPLIT>(a, st);
@@ -601,7 +881,7 @@ int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* 
 
 // in_proj for the bf16x3 attention: qkv = A W^T + bias written as the qkv3 image (q pre-multiplied by qscale)
 int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* img, int64_t M, int tokens, int heads, int K, float qscale,
-                     int terms, hipStream_t st) {
+                     int terms, hipStream_t st, float* sk_ws, int64_t sk_floats) {
     AVD_REQUIRE(A3 && W3 && bias && img, AVD_EINVAL, "gemm_bf16x3_qkv3: null pointer");
     const int N = 3 * heads * 64;
     AVD_REQUIRE(tokens > 0 && heads > 0 && M > 0 && M % tokens == 0, AVD_EINVAL, "gemm_bf16x3_qkv3: rows %lld not a multiple of tokens %d",
@@ -609,7 +889,7 @@ int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* im
     AVD_REQUIRE(gemm_bf16x3_supported(M, N, K), AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: need 3*heads*64 %% 256 == 0 and K %% 16 == 0");
     AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(bias) && aligned16(img), AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: alignment");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, nullptr, nullptr,
-             static_cast<unsigned char*>(img), M, N, K, 0, 0, 0, tokens, qkv3_npad(tokens), heads, qscale, terms};
+             static_cast<unsigned char*>(img), M, N, K, 0, 0, 0, tokens, qkv3_npad(tokens), heads, qscale, terms, sk_ws, nullptr, 0, sk_floats};
     return launch_s3<S3_EPI_QKV3>(a, st);
 }
 
@@ -630,9 +910,9 @@ extern "C" int avd_rmsnorm_split3_f32(const float* x, const float* scale, void* 
 }
 extern "C" int avd_gemm_bf16x3_f32(const void* A3, const void* W3, const float* bias, const float* residual, float* C, void* C3,
                                    int64_t M, int N, int K, int act, int terms, avd_stream_t stream) {
-    return gemm_bf16x3(A3, W3, bias, residual, C, C3, M, N, K, act, terms, static_cast<hipStream_t>(stream));
+    return gemm_bf16x3(A3, W3, bias, residual, C, C3, M, N, K, act, terms, static_cast<hipStream_t>(stream), nullptr, 0);
 }
 extern "C" int avd_gemm_bf16x3_qkv3_f32(const void* A3, const void* W3, const float* bias, void* qkv3, int64_t M, int tokens, int heads,
                                         int K, float qscale, int terms, avd_stream_t stream) {
-    return gemm_bf16x3_qkv3(A3, W3, bias, qkv3, M, tokens, heads, K, qscale, terms, static_cast<hipStream_t>(stream));
+    return gemm_bf16x3_qkv3(A3, W3, bias, qkv3, M, tokens, heads, K, qscale, terms, static_cast<hipStream_t>(stream), nullptr, 0);
 }
