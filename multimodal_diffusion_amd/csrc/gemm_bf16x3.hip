@@ -754,7 +754,7 @@ static int s3_tile_for(int epi, int64_t M, int N) {
     return (M + 255) / 256 * (N / 256) >= 192 ? 0 : 1;
 }
 
-int g_s3_streamk = getenv("AVD_S3_STREAMK") ? atoi(getenv("AVD_S3_STREAMK")) : 1;
+int g_s3_streamk = getenv("AVD_S3_STREAMK") ? atoi(getenv("AVD_S3_STREAMK")) : 0;   // measured slower than plain tiling: off
 
 static int sk_cu_count() {                 // CUs of the current device (looked up once per device)
     static std::atomic<int> cache[64];

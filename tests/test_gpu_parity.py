@@ -1283,3 +1283,34 @@ def test_attention_key_padding_mask(dev):
     assert rel_err(out.cpu(), ref) < 2e-5
     assert torch.equal(Fn.attention(qkv.to(dev), H, key_padding_mask=torch.zeros(B, N, dtype=torch.bool, device=dev)),
                        Fn.attention(qkv.to(dev), H))
+
+
+def test_optional_launch_modes_agree(dev, full):
+    """The two launch modes that are kept as measured experiments (off by default) compute the same results: the persistent
+    tile-queue fp32 GEMM (bit-identical: same tiles, same k order) and the stream-K bf16x3 GEMMs (fixed part order: deterministic,
+    equal to plain tiling within rounding of the re-associated K split)."""
+    from multimodal_diffusion_amd import functional as Fn
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(26944, 512, generator=g).to(dev)
+    w = (torch.randn(1536, 512, generator=g) / 22.6).to(dev)
+    b = torch.randn(1536, generator=g).to(dev)
+    y0 = Fn.linear(x, w, b)
+    _tune("gemm_persist", 1)
+    try:
+        y1 = Fn.linear(x, w, b)
+        y2 = Fn.linear(x, w, b)
+    finally:
+        _tune("gemm_persist", 0)
+    assert torch.equal(y0, y1) and torch.equal(y1, y2)
+    ws, _ = full
+    outs = []
+    for sk in (0, 1, 1):
+        mods = _full_modules(dev, ws)
+        _tune("s3_streamk", sk)
+        try:
+            out, ref = _one_step(dev, mods, ws, 256, 20, 2, matmul="bf16x3", seed=5)
+        finally:
+            _tune("s3_streamk", 0)
+        assert rel_err(out[:2], ref) < TOL
+        outs.append(out)
+    assert torch.equal(outs[1], outs[2]) and rel_err(outs[1], outs[0]) < 1e-5
