@@ -201,9 +201,10 @@ def roofline_of(rep, matmul: str, n_steps: int):
     achieved = work / (ms * 1e-3) / 1e12
 
     def peak_of(name):
-        if name.startswith(("gemm_bf16x3", "attn_bf16x3")):
-            terms = int(name.rstrip(">").split(",")[-1].split("<")[-1])
-            return PEAK_BF16_MATRIX_TFLOPS / terms
+        if name.startswith("gemm_bf16x3"):            # <EPI, TERMS, ...>
+            return PEAK_BF16_MATRIX_TFLOPS / int(name.split("<")[1].split(",")[1].strip(" >"))
+        if name.startswith("attn_bf16x3"):            # <TERMS>
+            return PEAK_BF16_MATRIX_TFLOPS / int(name.split("<")[1].strip(" >"))
         return PEAK_F32_MATRIX_TFLOPS
 
     traffic, source = pmc_traffic(dom, matmul)

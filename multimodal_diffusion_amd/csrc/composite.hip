@@ -101,7 +101,8 @@ static int64_t g_s3_min_rows = [] { const char* e = getenv("AVD_S3_MIN_ROWS"); r
 static bool g_no_fold = getenv("AVD_NO_FOLD") != nullptr;
 static int64_t split_min_rows() { return g_s3_min_rows; }      // avd_tune_set "s3_min_rows": measurement aid
 static bool core_use_split(const avd_core_weights* w, int64_t M) {
-    if (M < split_min_rows() || w->norm_kind != 0) return false;
+    // (the reduced-precision one-term mode is an explicit request, not a speed heuristic: it takes the split kernels at any size)
+    if ((M < split_min_rows() && w->split_terms != 1) || w->norm_kind != 0) return false;
     if (!gemm_bf16x3_supported(M, 3 * w->d, w->d) || !gemm_bf16x3_supported(M, w->d, w->d) ||
         !gemm_bf16x3_supported(M, w->mlp_hidden, w->d) || !gemm_bf16x3_supported(M, w->d, w->mlp_hidden))
         return false;

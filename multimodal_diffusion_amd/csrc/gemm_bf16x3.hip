@@ -808,7 +808,7 @@ static int launch_s3t(const S3Args& a, hipStream_t st) {
             g.sk_flags = fbase + (seq.fetch_add(1) % S3_SK_SLOTS) * S3_SK_FLAGS;
             g.ntiles = (int)ntiles;
             g.sm = g.sn = 1;
-            static const int tagk0 = prof_tag_id("gemm_bf16x3_kernel<%d, %d>", EPI, TERMS), tagk1 = prof_tag_id("gemm_bf16x3_b_kernel<%d, %d>", EPI, TERMS);
+            static const int tagk0 = prof_tag_id("gemm_bf16x3_kernel<%d, %d, true>", EPI, TERMS), tagk1 = prof_tag_id("gemm_bf16x3_b_kernel<%d, %d, true>", EPI, TERMS);
             ProfScope prof(tile ? tagk1 : tagk0, 2.0 * (double)a.M * a.N * a.K, st);
             static LdsAttr attrk[2];
             const void* kk = tile ? reinterpret_cast<const void*>(gemm_bf16x3_b_kernel<EPI, TERMS, true>)
@@ -839,7 +839,8 @@ static int launch_s3t(const S3Args& a, hipStream_t st) {
     const int64_t nbm = (a.M + BMt - 1) / BMt;
     const int64_t nwg = (nbm + g.sm - 1) / g.sm * g.sm * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
-    static const int tag0 = prof_tag_id("gemm_bf16x3_kernel<%d, %d>", EPI, TERMS), tag1 = prof_tag_id("gemm_bf16x3_b_kernel<%d, %d>", EPI, TERMS);
+    // tags = the kernel names as rocprofv3 prints their template arguments (EPI, TERMS, stream-K)
+    static const int tag0 = prof_tag_id("gemm_bf16x3_kernel<%d, %d, false>", EPI, TERMS), tag1 = prof_tag_id("gemm_bf16x3_b_kernel<%d, %d, false>", EPI, TERMS);
     ProfScope prof(tile ? tag1 : tag0, 2.0 * (double)a.M * a.N * a.K, st);
     if (tile) hipLaunchKernelGGL((gemm_bf16x3_b_kernel<EPI, TERMS, false>), dim3((unsigned)nwg), dim3(256), lds, st, g);
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<EPI, TERMS, false>), dim3((unsigned)nwg), dim3(512), lds, st, g);

@@ -1314,3 +1314,18 @@ def test_optional_launch_modes_agree(dev, full):
         assert rel_err(out[:2], ref) < TOL
         outs.append(out)
     assert torch.equal(outs[1], outs[2]) and rel_err(outs[1], outs[0]) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------- reduced-precision variants
+@pytest.mark.parametrize("size,B,n_ref", [(64, 32, 2), (512, 8, 1)])
+def test_bf16_mode_reported_error(dev, full, size, B, n_ref):
+    """BASELINE configs C2 (64x64, B=32) and C5 geometry (512x512, B=8) with matmul="bf16": plain bf16 operands, fp32
+    accumulation, in the block projections and the attention.  NOT a parity path — the reference has no reduced-precision
+    inference (sample_clip.py:399-411 never reads mixed_precision).  The test states the error against the fp32 oracle: one
+    CFG step stays within 3e-2 of the oracle relative to max|z|, and is measurably different from the fp32 path (so the
+    mode really ran)."""
+    ws, mods = full
+    out, ref = _one_step(dev, mods, ws, size, B, n_ref, matmul="bf16")
+    err = rel_err(out[:n_ref], ref)
+    print(f"bf16 mode {size}x{size} B={B}: rel err vs fp32 oracle {err:.3e}")
+    assert 1e-5 < err < 3e-2
