@@ -74,6 +74,8 @@ int tube_patch_f32(const float* z, float* tok, int B, int C, int T, int H, int W
 int audio_tokens_f32(const float* z, float* tok, int B, int Ca, int F, int len, int stride, hipStream_t st);
 int assemble_f32(float* X2, const float* temb, const float* Xp, int B, int N, int d, int tdim, int Nt, int Np,
                  int target_first, hipStream_t st);
+int assemble_rows_f32(float* X2, const int64_t* t_now, const float* freqs, const float* Xp, float* ss, int B, int N, int d, int tdim,
+                      int Nt, int Np, int target_first, float max_period, hipStream_t st);
 int cfg_unpatch_ddim_f32(const float* eps2, const float* z, const int64_t* t_now, const int64_t* t_prev,
                          const float* abar, int T_train, float guidance, float eta, const float* noise, float* z_out,
                          int B, int C, int T, int H, int W, int t, int h, int w, hipStream_t st);
@@ -162,7 +164,8 @@ static int core_norm(const avd_core_weights* w, const float* x, const float* sca
 }
 
 static int core_forward(const avd_core_weights* w, const float* x, float* y, int B, int N, int out_row0,
-                        int n_out_rows, const unsigned char* kpm, void* ws, int64_t ws_bytes, hipStream_t st) {
+                        int n_out_rows, const unsigned char* kpm, void* ws, int64_t ws_bytes, hipStream_t st,
+                        const float* ss_first = nullptr) {
     if (int rc = check_core(w)) return rc;
     AVD_REQUIRE(x && y && B > 0 && N > 0, AVD_EINVAL, "core: bad input");
     AVD_REQUIRE(out_row0 >= 0 && n_out_rows > 0 && out_row0 + n_out_rows <= N, AVD_EINVAL, "core: bad output row window");
@@ -207,14 +210,18 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
         float* ssA = cv.take(M * (d / 32 + 1));     // sums of squares of the stream entering norm1
         float* ssB = cv.take(M * (d / 32 + 1));     // ... entering norm2
         const float sqrt_d = (float)sqrt((double)d);
-        if (int rc = rowss_f32(cur, ssA, M, d, st)) return rc;
+        const float* ssA_in = ss_first;                // the front end may already have the rows' sums of squares
+        if (!ssA_in) {
+            if (int rc = rowss_f32(cur, ssA, M, d, st)) return rc;
+            ssA_in = ssA;
+        }
         int colsA = 1;
         for (int l = 0; l < w->n_layers; ++l) {
             const avd_block_weights& b = w->blocks[l];
             const bool last = l == w->n_layers - 1;
             const int nq = (last && out_row0 == 0) ? n_out_rows : N;
-            if (int rc = gemm_f32_fold(cur, rd, b.in_proj_weight_n, b.in_proj_bias, nullptr, rd, wide, r3, M, 3 * d, d, AVD_ACT_NONE, ssA,
-                                       colsA, sqrt_d, w->norm_eps, nullptr, st)) return rc;
+            if (int rc = gemm_f32_fold(cur, rd, b.in_proj_weight_n, b.in_proj_bias, nullptr, rd, wide, r3, M, 3 * d, d, AVD_ACT_NONE,
+                                       l == 0 ? ssA_in : ssA, colsA, sqrt_d, w->norm_eps, nullptr, st)) return rc;
             if (int rc = attn_f32(wide, hbuf, B, N, H, d / H, scale, nq, kpm, st)) return rc;
             if (int rc = gemm_f32_fold(hbuf, rd, b.out_proj_weight, b.out_proj_bias, cur, rd, y, rd, M, d, d, AVD_ACT_NONE, nullptr, 0,
                                        1.f, 0.f, ssB, st)) return rc;
@@ -294,8 +301,9 @@ static int64_t embed_ws_floats(const avd_embed_desc* e) {
     return align_up((int64_t)e->B * e->Nt * embed_tok_dim(e) * 4) / 4 + align_up((int64_t)e->B * (e->tdim > 0 ? e->tdim : 1) * 4) / 4;
 }
 
+// ss_out (optional, concat mode): per-row sums of squares of the finished X2, [2B*N] — spares MMDiT's first folded norm its pass
 static int embed_cfg_pair(const avd_embed_desc* e, const float* z, const float* Wt, const float* bt,
-                          const int64_t* t_now, const float* Xp, float* tok_ws, float* X2, hipStream_t st) {
+                          const int64_t* t_now, const float* Xp, float* tok_ws, float* X2, hipStream_t st, float* ss_out = nullptr) {
     if (int rc = check_embed(e)) return rc;
     AVD_REQUIRE(z && Wt && t_now && tok_ws && X2 && (e->Np == 0 || Xp), AVD_EINVAL, "embed: null pointer");
     const int B = e->B, d = e->d, N = e->Nt + e->Np, D = embed_tok_dim(e);
@@ -306,7 +314,7 @@ static int embed_cfg_pair(const avd_embed_desc* e, const float* z, const float* 
     } else {
         if (int rc = audio_tokens_f32(z, tok, B, e->C, e->T, e->p0, e->p1, st)) return rc;
     }
-    if (e->tdim > 0)
+    if (e->tdim > 0 && e->temb_add)
         if (int rc = temb_f32(t_now, e->temb_freqs, temb, B, e->tdim, 10000.f, st)) return rc;
     // adapter GEMM straight into the cond half's target rows (segmented C: one segment per sample)
     float* c0 = X2 + (e->target_first ? 0 : (int64_t)e->Np * d);
@@ -319,7 +327,8 @@ static int embed_cfg_pair(const avd_embed_desc* e, const float* z, const float* 
         return assemble_f32(X2, temb, Xp, B, N, d, 0, e->Nt, e->Np, e->target_first, st);
     }
     if (int rc = gemm_f32(tok, RowMap{D, 0, 0}, Wt, bt, nullptr, cm, c0, cm, (int64_t)B * e->Nt, d - e->tdim, D, AVD_ACT_NONE, st)) return rc;
-    return assemble_f32(X2, temb, Xp, B, N, d, e->tdim, e->Nt, e->Np, e->target_first, st);
+    // timestep columns, null-half copies, prompt rows and the rows' sums of squares in one pass
+    return assemble_rows_f32(X2, t_now, e->temb_freqs, Xp, ss_out, B, N, d, e->tdim, e->Nt, e->Np, e->target_first, 10000.f, st);
 }
 
 // ---------------------------------------------------------------- one CFG denoising step
@@ -349,7 +358,7 @@ static int ensure_aux(hipStream_t st, AuxState& out) {
 }
 
 struct StepPlan {
-    int64_t x2, tok, core, head, eps, total;
+    int64_t x2, tok, core, head, eps, ss, total;
     int N, D;
     int64_t rows;     // 2B*Nt
 };
@@ -370,7 +379,8 @@ static int plan_step(const avd_step_desc* s, StepPlan& p) {
     p.core = halves > whole ? halves : whole;
     p.head = 2 * head_ws_bytes(s->head, p.rows / 2);
     p.eps = align_up(p.rows * p.D * 4);
-    p.total = p.x2 + p.tok + p.core + p.head + p.eps;
+    p.ss = align_up((int64_t)2 * e.B * p.N * 4);
+    p.total = p.x2 + p.tok + p.core + p.head + p.ss + p.eps;      // eps stays last (DenoiseEngine.eps_tokens reads the tail)
     return AVD_OK;
 }
 
@@ -460,14 +470,16 @@ extern "C" int avd_denoise_step_f32(const avd_step_desc* s, const float* z, cons
     float* tok = reinterpret_cast<float*>(w + p.x2);
     void* core_ws = w + p.x2 + p.tok;
     void* head_ws = w + p.x2 + p.tok + p.core;
-    float* eps2 = reinterpret_cast<float*>(w + p.x2 + p.tok + p.core + p.head);
+    float* ssx = reinterpret_cast<float*>(w + p.x2 + p.tok + p.core + p.head);
+    float* eps2 = reinterpret_cast<float*>(w + p.x2 + p.tok + p.core + p.head + p.ss);
+    const bool have_ss = !e.temb_add;      // the fused concat front end leaves the rows' sums of squares behind
 
-    if (int rc = embed_cfg_pair(&e, z, s->adapt_w, s->adapt_b, t_now, Xp, tok, X2, st)) return rc;
+    if (int rc = embed_cfg_pair(&e, z, s->adapt_w, s->adapt_b, t_now, Xp, tok, X2, st, ssx)) return rc;
     const int row0 = e.target_first ? 0 : e.Np;
     // head over the target rows only (per-token independent, so skipping prompt rows is exact)
     const RowMap hm{e.d, e.Nt, (int64_t)p.N * e.d};
     if (!s->split_streams) {
-        if (int rc = core_forward(s->core, X2, X2, 2 * e.B, p.N, row0, e.Nt, nullptr, core_ws, p.core, st)) return rc;
+        if (int rc = core_forward(s->core, X2, X2, 2 * e.B, p.N, row0, e.Nt, nullptr, core_ws, p.core, st, have_ss ? ssx : nullptr)) return rc;
         if (int rc = head_forward(s->head, X2 + (int64_t)row0 * e.d, hm, p.rows, eps2, head_ws, p.head, st)) return rc;
     } else {
         // the cond and null halves are independent until the CFG combine: run them as two kernel chains on two
@@ -483,7 +495,8 @@ extern "C" int avd_denoise_step_f32(const avd_step_desc* s, const float* z, cons
         for (int half = 0; half < 2; ++half) {
             hipStream_t hs = half ? g_aux : st;
             float* xh = X2 + half * half_rows;
-            if (int rc = core_forward(s->core, xh, xh, e.B, p.N, row0, e.Nt, nullptr, static_cast<char*>(core_ws) + half * hc, hc, hs)) return rc;
+            if (int rc = core_forward(s->core, xh, xh, e.B, p.N, row0, e.Nt, nullptr, static_cast<char*>(core_ws) + half * hc, hc, hs,
+                                      have_ss ? ssx + (int64_t)half * e.B * p.N : nullptr)) return rc;
             if (int rc = head_forward(s->head, xh + (int64_t)row0 * e.d, hm, p.rows / 2, eps2 + half * (p.rows / 2) * p.D,
                                       static_cast<char*>(head_ws) + half * hh, hh, hs)) return rc;
         }

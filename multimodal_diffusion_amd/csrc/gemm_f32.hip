@@ -637,7 +637,7 @@ extern "C" void lab_set_dbg(unsigned long long* p) { g_gemm_dbg = p; }
 extern "C" void lab_set_tile(int t);
 #endif
 int g_gemm_persist = getenv("AVD_GEMM_PERSIST") ? atoi(getenv("AVD_GEMM_PERSIST")) : 0;   // persistent tile queue for big grids
-int g_gemm_stages = getenv("AVD_GEMM_STAGES") ? atoi(getenv("AVD_GEMM_STAGES")) : 3;      // LDS ring depth of the 128x64 / 64x64 tiles
+int g_gemm_stages = getenv("AVD_GEMM_STAGES") ? atoi(getenv("AVD_GEMM_STAGES")) : 0;      // LDS ring depth of the 128x64 / 64x64 tiles: 0 = by size
 int g_gemm_stagger_pct = getenv("AVD_GEMM_STAGGER") ? atoi(getenv("AVD_GEMM_STAGGER")) : 0;
 int g_gemm_force_tile = getenv("AVD_GEMM_TILE") ? atoi(getenv("AVD_GEMM_TILE")) : -1;
 
@@ -684,10 +684,14 @@ int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, 
         // N = 512 projections so the last round is not half empty; 64x64 for small problems
         int tile = (N >= 128 && mb128 * ((N + 127) / 128) >= 1536) ? 0 : (mb128 * ((N + 63) / 64) >= 512) ? 1 : 2;
         if (force >= 0 && force <= 2) tile = force;
-        const bool ring3 = g_gemm_stages == 3;
+        // LDS ring depth (g_gemm_stages: 0 = by size, 2 / 3 = forced).  Measured: three stages pay for the 128x64 tile once the grid is
+        // several rounds deep (C3: +2 % on the step) and for the 64x64 tile only on latency-bound grids of a few blocks per CU
+        // (32x32 / B4: +2.5 %); in between two stages with one more resident block win (64x64 / B32: +3.6 %).
+        const bool ring3_t1 = g_gemm_stages ? g_gemm_stages == 3 : M >= 16384;
+        const bool ring3_t2 = g_gemm_stages ? g_gemm_stages == 3 : M <= 2048;
         if (tile == 0) return launch_dma_epi<128, 128, 64, 64, 2, 2>(g, st);
-        if (tile == 1) return ring3 ? launch_dma_epi<128, 64, 64, 32, 2, 3>(g, st) : launch_dma_epi<128, 64, 64, 32, 2, 2>(g, st);
-        return ring3 ? launch_dma_epi<64, 64, 32, 32, 3, 3>(g, st) : launch_dma_epi<64, 64, 32, 32, 4, 2>(g, st);
+        if (tile == 1) return ring3_t1 ? launch_dma_epi<128, 64, 64, 32, 2, 3>(g, st) : launch_dma_epi<128, 64, 64, 32, 2, 2>(g, st);
+        return ring3_t2 ? launch_dma_epi<64, 64, 32, 32, 3, 3>(g, st) : launch_dma_epi<64, 64, 32, 32, 4, 2>(g, st);
     }
     if (N <= 32) return launch_reg_k<128, 32, 32, 32>(g, st);
     if (N >= 128 && mb128 * ((N + 127) / 128) >= 512) return launch_reg_k<128, 128, 64, 64>(g, st);

@@ -377,6 +377,68 @@ int assemble_f32(float* X2, const float* temb, const float* Xp, int B, int N, in
     return AVD_OK;
 }
 
+// Fused form for the sampler's concat embedding (sample_clip.py:59-70, 371, 377): one wave per row of X2 fills everything the
+// adapter GEMM did not write — the sinusoidal timestep columns are computed in place (no [B, tdim] buffer, no separate
+// kernel), the null half's target rows are copied from the cond half, prompt rows come from Xp / zeros — and, while the row
+// is in registers, its sum of squares goes to ss[row] (the table the first folded RMSNorm reads: no rowss pass).
+__global__ __launch_bounds__(256) void assemble_rows_kernel(float* __restrict__ X2, const int64_t* __restrict__ t_now,
+                                                            const float* __restrict__ freqs, const float* __restrict__ Xp,
+                                                            float* __restrict__ ss, int B, int N, int d, int tdim, int Nt, int Np,
+                                                            int target_first, float neg_log_mp) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (int64_t)2 * B * N) return;
+    const int n = (int)(row % N);
+    const int bb = (int)(row / N);
+    const int half = bb >= B, b = half ? bb - B : bb;
+    const int t0 = target_first ? 0 : Np;
+    const bool is_t = n >= t0 && n < t0 + Nt;
+    const int da = d - tdim, th = tdim >> 1;
+    const float tf = is_t ? (float)t_now[b] : 0.f;
+    float acc = 0.f;
+    for (int col = lane * 4; col < d; col += 256) {
+        f32x4 v;
+        bool store = true;
+        if (is_t) {
+            if (col >= da) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = col - da + e;
+                    float x = 0.f;
+                    if (c < 2 * th) {
+                        const int k = c < th ? c : c - th;
+                        const float f = freqs ? freqs[k] : expf(neg_log_mp * (float)k / (float)th);
+                        const float a = tf * f;
+                        x = c < th ? cosf(a) : sinf(a);
+                    }
+                    v[e] = x;
+                }
+            } else {
+                v = *reinterpret_cast<const f32x4*>(X2 + ((int64_t)b * N + n) * d + col);      // the adapter GEMM's output (cond half)
+                store = half != 0;
+            }
+        } else {
+            const int np = target_first ? n - Nt : n;
+            v = half ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(Xp + ((int64_t)b * Np + np) * d + col);
+        }
+        if (store) *reinterpret_cast<f32x4*>(X2 + row * d + col) = v;
+        acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    acc = wave_sum(acc);
+    if (ss && lane == 0) ss[row] = acc;
+}
+
+int assemble_rows_f32(float* X2, const int64_t* t_now, const float* freqs, const float* Xp, float* ss, int B, int N, int d, int tdim,
+                      int Nt, int Np, int target_first, float max_period, hipStream_t st) {
+    const int64_t rows = (int64_t)2 * B * N;
+    static const int tag = prof_tag_id("assemble_rows_kernel");
+    ProfScope prof(tag, 4.0 * (2.0 * B * N * d + (double)B * Nt * (d - tdim) + (double)B * Np * d), st);
+    hipLaunchKernelGGL(assemble_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, X2, t_now, freqs, Xp, ss, B, N, d, tdim,
+                       Nt, Np, target_first, -(float)log((double)max_period));
+    AVD_CHECK_LAUNCH("assemble_rows");
+    return AVD_OK;
+}
+
 // ------------------------------------------------------------------ device-side schedule cursor
 __global__ void sched_advance_kernel(const int64_t* __restrict__ sched, int n_sched, int32_t* cursor,
                                      int64_t* __restrict__ t_now, int64_t* __restrict__ t_prev, int B) {

@@ -308,8 +308,14 @@ class DenoiseEngine:
         self._captured = True
         return g
 
-    def run(self, z: torch.Tensor, sched: torch.Tensor, graph: bool = False) -> torch.Tensor:
-        """Apply len(sched)-1 steps.  ``graph=True`` replays a captured two-step HIP graph."""
+    GRAPH_BELOW_ROWS = 6144      # 2B*N under which a step's ~60-95 launches are host-bound: replay them from a HIP graph
+
+    def run(self, z: torch.Tensor, sched: torch.Tensor, graph: Optional[bool] = None) -> torch.Tensor:
+        """Apply len(sched)-1 steps.  ``graph=True`` replays a captured two-step HIP graph; ``None`` (default) does so when the
+        batch is small enough for the step to be launch-bound (2B*N < 6,144 rows, eta == 0) — results are bit-identical either
+        way (tests: test_chained_sampler_golden)."""
+        if graph is None:
+            graph = self.eta == 0 and 2 * self.embed.B * self.N < self.GRAPH_BELOW_ROWS
         self.begin(sched)
         za = L.dev_f32(z, "z").clone()
         zb = torch.empty_like(za)
