@@ -203,6 +203,8 @@ typedef struct {                       /* avdiff/models/mmdt.py:116-149 (MMDiT) 
     const float* final_norm_bias;      /* final_norm.bias [d] for norm_kind 1, else NULL */
     int split_terms;                   /* bf16x3 path only: product terms kept per k — 0 or 6: default (fp32-level error), 9: strict
                                         * (nothing dropped), 1: plain bf16 operands (reduced precision, BASELINE config C2) */
+    int attn_mode;                     /* bf16x3 path only: 0 = attention follows split_terms; 1 = fp8 (OCP e4m3) QK^T and PV with fp32
+                                        * accumulation (csrc/attn_fp8.hip) — reduced precision, BASELINE config C5, reported error */
 } avd_core_weights;
 
 typedef struct {                       /* avdiff/models/heads/noise_heads.py:94-229, one modality path */
@@ -249,6 +251,13 @@ int avd_gemm_bf16x3_qkv3_f32(const void* A3, const void* W3, const float* bias, 
  * Rows >= n_query of every sample are not computed and left untouched. */
 int avd_attn_fwd_qkv3_f32(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms,
                           avd_stream_t stream);
+/* fp8 (OCP e4m3) attention from the same qkv3 image (csrc/attn_fp8.hip): both contractions on v_mfma_f32_32x32x16_fp8_fp8 with
+ * fp32 accumulation and fp32 softmax.  Reduced precision — BASELINE config C5 names it; the reference has no such path
+ * (infer/sample_clip.py:399-411), so its error is reported against the fp32 result, never gated as parity.
+ * workspace: avd_attn_fp8_workspace_bytes(B, N, H) bytes (the quantised, tile-major Q / K / V^T images). */
+int64_t avd_attn_fp8_workspace_bytes(int B, int N, int H);
+int avd_attn_fwd_fp8_f32(const void* qkv3, void* workspace, int64_t workspace_bytes, float* out, void* out3, int B, int N, int H,
+                         int n_query, avd_stream_t stream);
 /* C = act(A W^T + bias) (+ residual), A3/W3 split3 images of A [M,K] and W [N,K]; N % 256 == 0, K % 16 == 0.
  * C3 == NULL: fp32 row-major C [M,N], act AVD_ACT_NONE, residual optional (may alias C).
  * C3 != NULL: the result is written as the split3 image of [M,N] instead (bias + AVD_ACT_GELU, no residual). */

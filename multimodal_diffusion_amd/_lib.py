@@ -43,7 +43,7 @@ class BlockWeights(C.Structure):
 class CoreWeights(C.Structure):
     _fields_ = [("d", C.c_int), ("n_layers", C.c_int), ("n_heads", C.c_int), ("mlp_hidden", C.c_int),
                 ("norm_eps", C.c_float), ("blocks", C.POINTER(BlockWeights)), ("final_norm_scale", C.c_void_p),
-                ("norm_kind", C.c_int), ("final_norm_bias", C.c_void_p), ("split_terms", C.c_int)]
+                ("norm_kind", C.c_int), ("final_norm_bias", C.c_void_p), ("split_terms", C.c_int), ("attn_mode", C.c_int)]
 
 
 class HeadWeights(C.Structure):
@@ -121,6 +121,8 @@ SIGNATURES = {
     "avd_qkv3_bytes": (_L, [_I, _I, _I]),
     "avd_gemm_bf16x3_qkv3_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _F, _I, _P]),
     "avd_attn_fwd_qkv3_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "avd_attn_fp8_workspace_bytes": (_L, [_I, _I, _I]),
+    "avd_attn_fwd_fp8_f32": (_I, [_P, _P, _L, _P, _P, _I, _I, _I, _I, _P]),
     "avd_gemm_bf16x3_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "avd_conv3_weight_bytes": (_L, []),
     "avd_conv3_weight_f32": (_I, [_P, _P, _P]),

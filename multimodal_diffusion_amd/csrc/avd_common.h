@@ -199,6 +199,9 @@ extern int g_s3_streamk;
 int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* img, int64_t M, int tokens, int heads, int K, float qscale,
                      int terms, hipStream_t st, float* sk_ws = nullptr, int64_t sk_floats = 0);
 int64_t qkv3_bytes(int B, int N, int H);
+// fp8 attention (attn_fp8.hip): reads the same qkv3 image, needs attn_fp8_ws_bytes(B, N, H) of scratch
+int64_t attn_fp8_ws_bytes(int B, int N, int H);
+int attn_fp8(const void* qkv3, void* ws, int64_t ws_bytes, float* out, void* out3, int B, int N, int H, int n_query, hipStream_t st);
 int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms, hipStream_t st);
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
                 int act, int terms, hipStream_t st, float* sk_ws = nullptr, int64_t sk_floats = 0);

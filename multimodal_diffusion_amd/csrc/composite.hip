@@ -104,7 +104,7 @@ static bool g_no_fold = getenv("AVD_NO_FOLD") != nullptr;
 static int64_t split_min_rows() { return g_s3_min_rows; }      // avd_tune_set "s3_min_rows": measurement aid
 static bool core_use_split(const avd_core_weights* w, int64_t M) {
     // (the reduced-precision one-term mode is an explicit request, not a speed heuristic: it takes the split kernels at any size)
-    if ((M < split_min_rows() && w->split_terms != 1) || w->norm_kind != 0) return false;
+    if ((M < split_min_rows() && w->split_terms != 1 && w->attn_mode != 1) || w->norm_kind != 0) return false;
     if (!gemm_bf16x3_supported(M, 3 * w->d, w->d) || !gemm_bf16x3_supported(M, w->d, w->d) ||
         !gemm_bf16x3_supported(M, w->mlp_hidden, w->d) || !gemm_bf16x3_supported(M, w->d, w->mlp_hidden))
         return false;
@@ -139,7 +139,9 @@ static int64_t core_ws_bytes(const avd_core_weights* w, int B, int N) {
     if (!core_use_split(w, M)) return fp32_path;
     // + split3 image of the norm / attention output, and the wide buffer must also hold the split3 image of the MLP hidden
     const int64_t wide_b = core_split_wide_bytes(w, B, N);
-    const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d)) + align_up(gemm_bf16x3_sk_floats() * 4);
+    // third region: parked stream-K tiles, or (attn_mode 1) the fp8 attention's operand images — never both at once
+    const int64_t sk_b = gemm_bf16x3_sk_floats() * 4, f8_b = w->attn_mode == 1 ? attn_fp8_ws_bytes(B, N, w->n_heads) : 0;
+    const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d)) + align_up(sk_b > f8_b ? sk_b : f8_b);
     return split_path > fp32_path ? split_path : fp32_path;
 }
 
@@ -147,6 +149,7 @@ static int check_core(const avd_core_weights* w) {
     AVD_REQUIRE(w && w->blocks && w->final_norm_scale, AVD_EINVAL, "core: null weight table");
     AVD_REQUIRE(w->d > 0 && w->n_layers > 0 && w->n_heads > 0 && w->mlp_hidden > 0, AVD_EINVAL, "core: bad dims");
     AVD_REQUIRE(w->d % w->n_heads == 0, AVD_EINVAL, "core: d_model %d not divisible by n_heads %d", w->d, w->n_heads);
+    AVD_REQUIRE(w->attn_mode == 0 || w->attn_mode == 1, AVD_EINVAL, "core: attn_mode must be 0 (follow the matmul mode) or 1 (fp8)");
     AVD_REQUIRE(w->norm_kind == 0 || w->norm_kind == 1, AVD_EINVAL, "core: norm_kind must be 0 (RMSNorm) or 1 (LayerNorm)");
     AVD_REQUIRE(w->d / w->n_heads == 64, AVD_EUNSUPPORTED, "core: head_dim %d unsupported (64 only)", w->d / w->n_heads);
     AVD_REQUIRE(w->d % 4 == 0 && w->mlp_hidden % 4 == 0, AVD_EUNSUPPORTED, "core: widths must be multiples of 4");
@@ -187,15 +190,21 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
         float* qkv = cs.take((wide_b + 3) / 4);
         void* wide3 = qkv;
         void* hs = cs.take((split3_bytes(M, d) + 3) / 4);
-        const int64_t skf = gemm_bf16x3_sk_floats();
-        float* skw = cs.take(skf);            // parked partial tiles of the stream-K launches
+        const int64_t f8_b = w->attn_mode == 1 ? attn_fp8_ws_bytes(B, N, H) : 0;
+        int64_t skf = gemm_bf16x3_sk_floats();
+        if (f8_b > skf * 4) skf = (f8_b + 3) / 4;
+        float* skw = cs.take(skf);            // parked partial tiles of the stream-K launches / fp8 attention operands
         for (int l = 0; l < w->n_layers; ++l) {
             const avd_block_weights& b = w->blocks[l];
             const bool last = l == w->n_layers - 1;
             const int nq = (last && out_row0 == 0) ? n_out_rows : N;
             if (int rc = rmsnorm_split3_f32(cur, b.norm1_scale, hs, M, d, w->norm_eps, st)) return rc;
             if (int rc = gemm_bf16x3_qkv3(hs, b.in_proj_weight3, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, terms, st, skw, skf)) return rc;
-            if (int rc = attn_bf16x3(qkv, nullptr, hs, B, N, H, nq, terms, st)) return rc;
+            if (w->attn_mode == 1) {
+                if (int rc = attn_fp8(qkv, skw, skf * 4, nullptr, hs, B, N, H, nq, st)) return rc;
+            } else {
+                if (int rc = attn_bf16x3(qkv, nullptr, hs, B, N, H, nq, terms, st)) return rc;
+            }
             if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, nullptr, M, d, d, AVD_ACT_NONE, terms, st, skw, skf)) return rc;
             cur = y;
             if (int rc = rmsnorm_split3_f32(y, b.norm2_scale, hs, M, d, w->norm_eps, st)) return rc;

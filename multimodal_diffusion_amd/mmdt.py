@@ -157,6 +157,9 @@ class MMDiT(nn.Module):
         # pipe with exactly split operands (fp32-level error, csrc/gemm_bf16x3.hip) whenever the batch is large enough;
         # "bf16x3_strict" keeps all nine product terms; "bf16" keeps one (plain bf16 operands — reduced precision, config C2).
         self.matmul = "f32"
+        # "default": the attention follows `matmul`.  "fp8": QK^T and PV take e4m3 operands (csrc/attn_fp8.hip; needs a split matmul
+        # mode) — reduced precision, BASELINE config C5, never the default.
+        self.attn = "default"
         self.fold_norms = True        # fp32 path: fold norm1 / norm2 into the neighbouring Linear epilogues (same math, one pass less)
         self._split3: dict = {}
         self._folded: dict = {}
@@ -182,6 +185,13 @@ class MMDiT(nn.Module):
             hit = (key, Fn.split3(p.detach(), out=old))      # same storage when the shape is unchanged
             self._split3[name] = hit
         return hit[1]
+
+    def _attn_code(self) -> int:
+        if self.attn not in ("default", "fp8"):
+            raise ValueError(f"attn must be 'default' or 'fp8', got {self.attn!r}")
+        if self.attn == "fp8" and self.matmul == "f32":
+            raise ValueError("attn='fp8' reads the qkv3 image of the split matmul modes: use matmul='bf16x3' (or 'bf16')")
+        return 1 if self.attn == "fp8" else 0
 
     # ---- pointer table for the composite (rebuilt per call: parameters may have moved) ----
     def weight_table(self):
@@ -225,7 +235,7 @@ class MMDiT(nn.Module):
         hidden = self.blocks[0].mlp.fc1.weight.shape[0]
         cw = L.CoreWeights(self.cfg.d_model, len(self.blocks), self.cfg.n_heads, hidden, self.final_norm.eps,
                            C.cast(arr, C.POINTER(L.BlockWeights)), fin.data_ptr(), 1 if ln else 0, L.ptr(fin_b),
-                           L.MATMUL_TERMS[self.matmul])
+                           L.MATMUL_TERMS[self.matmul], self._attn_code())
         return cw, (arr, keep)
 
     def forward(self, x: torch.Tensor, key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:

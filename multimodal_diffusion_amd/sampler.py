@@ -111,7 +111,7 @@ class DenoiseEngine:
     def __init__(self, *, adapt_v: LinearAdapter, adapt_a: LinearAdapter, core: MMDiT, head: MultiModalNoiseHead,
                  tstep_dim: int, target: str, latent_shape: Tuple[int, ...], prompt_tokens: int, alpha_bar: torch.Tensor,
                  guidance: float, eta: float = 0.0, tube=(2, 4, 4), chunk=(4, 4), split_streams: bool = False,
-                 temb_mode: str = "concat", matmul: Optional[str] = None):
+                 temb_mode: str = "concat", matmul: Optional[str] = None, attn: Optional[str] = None):
         if target not in ("video", "audio"):
             raise ValueError("target must be 'video' or 'audio'")
         if eta < 0:
@@ -162,6 +162,7 @@ class DenoiseEngine:
 
         # matrix-pipe mode of this engine ("f32" | "bf16x3", default: the core's own setting); the core module keeps its setting
         self.matmul = core.matmul if matmul is None else matmul
+        self.attn = core.attn if attn is None else attn
         self._split_streams = bool(split_streams)
         self._captured = False
         self.workspace: Optional[torch.Tensor] = None
@@ -178,12 +179,12 @@ class DenoiseEngine:
 
     def _bind_weights(self) -> None:
         core, head = self.core, self.head
-        prev = core.matmul
-        core.matmul = self.matmul
+        prev = core.matmul, core.attn
+        core.matmul, core.attn = self.matmul, self.attn
         try:
             self._core_tab, self._keep_core = core.weight_table()
         finally:
-            core.matmul = prev
+            core.matmul, core.attn = prev
         self._head_tab, self._keep_head = head.weight_table(self.target)
         self._aw = L.dev_f32(self.adapt_t.proj.weight.detach(), "adapter weight")
         self._ab = L.dev_f32(self.adapt_t.proj.bias.detach(), "adapter bias")
