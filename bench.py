@@ -148,6 +148,8 @@ def parse_args(argv=None):
                     help="bf16x3 (default): block projections + attention on the bf16 matrix pipe with exactly split fp32 "
                          "operands (fp32-level error); f32: fp32 MFMA everywhere; bf16x3_strict: all nine product terms; "
                          "bf16: plain bf16 operands (reduced precision, reported error)")
+    ap.add_argument("--attn", default="default", choices=["default", "fp8"],
+                    help="fp8: e4m3 QK^T / PV in the attention (reduced precision, BASELINE C5; needs a split matmul mode; never the default)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed-region) measurements of the other matmul modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -242,7 +244,8 @@ def main():
     def make_engine(mode):
         e = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=tdim, target="video",
                             latent_shape=lat, prompt_tokens=na, alpha_bar=abar, guidance=args.guidance,
-                            split_streams=bool(args.split_streams), matmul=mode)
+                            split_streams=bool(args.split_streams), matmul=mode,
+                            attn=args.attn if mode != "f32" else "default")
         e.set_prompt(z_a0)
         e.begin(sched)
         return e
@@ -305,12 +308,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": MODE_DTYPE[args.matmul],
+            "dtype": MODE_DTYPE[args.matmul] + ("; attention in fp8 e4m3 (reduced precision)" if args.attn == "fp8" else ""),
             "data": "synthetic",
             "config": {"workload": f"C3: {size}x{size} audio->video CFG denoising step (cond+null MMDiT d512 L8 H8 + noise head + "
                                    f"DDIM), {nv}+{na} tokens, batch {B} per GPU, DDIM {S} steps, guidance {args.guidance}",
                        "global_batch": B * world, "tokens": nv + na, "sampler_steps": S,
-                       "parallelism": f"dp{world}", "launch": "hipgraph" if args.graph else "eager", "matmul": args.matmul},
+                       "parallelism": f"dp{world}", "launch": "hipgraph" if args.graph else "eager", "matmul": args.matmul, "attn": args.attn},
             "per_gpu_steps_per_s": per_gpu,
             "value_is": "sum over ranks of batch-32 steps/s (weak scaling); per_gpu_steps_per_s is the global-batch step rate",
             "sample_steps_per_s": world * B * per_gpu,
