@@ -37,12 +37,13 @@ PEAK_HBM_GBS = 8000.0
 # split-operand matmul: one product costs TERMS bf16 MFMAs, so the dense bf16 peak (2,516.6 TFLOP/s) prices ALGORITHMIC fp32
 # flops at 2516.6 / TERMS (the chip holds well under 2.4 GHz on this load; that is not priced in)
 PEAK_BF16_MATRIX_TFLOPS = 2516.6
-MODE_TERMS = {"f32": 0, "bf16x3": 6, "bf16x3_strict": 9, "bf16": 1}
+MODE_TERMS = {"f32": 0, "bf16x3": 6, "bf16x3_strict": 9, "bf16": 1, "f16x2": 3}
 MODE_DTYPE = {
     "f32": "f32",
     "bf16x3": "f32 via 3xbf16 split operands (6-term products, f32 accumulate; fp32-level error)",
     "bf16x3_strict": "f32 via 3xbf16 split operands (all 9 product terms, f32 accumulate)",
     "bf16": "bf16 operands, f32 accumulate (reduced precision; error reported, not a parity path)",
+    "f16x2": "f32 via 2xfp16 split operands (22-bit operands, 3-term products, f32 accumulate)",
 }
 
 
@@ -363,7 +364,7 @@ def main():
     # ---- the other matmul modes, measured the same way right after (N=1 only; never part of `value`)
     if rank == 0 and world == 1 and not args.no_alt:
         alts = []
-        for other in ("f32", "bf16x3", "bf16x3_strict"):
+        for other in ("f32", "bf16x3", "bf16x3_strict", "f16x2"):
             if other == args.matmul:
                 continue
             eng2 = make_engine(other)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AVD_ABI_VERSION 3
+#define AVD_ABI_VERSION 4
 
 #define AVD_OK            0
 #define AVD_EINVAL       -1   /* bad shape / argument (reference: AssertionError / ValueError) */
@@ -192,6 +192,11 @@ typedef struct {                       /* avdiff/models/mmdt.py:88-99 (Block) st
     const void* fc2_weight3;
     const float* norm1_bias;           /* norm="layernorm" only: blocks.{i}.norm1.bias / norm2.bias [d]; NULL for RMSNorm */
     const float* norm2_bias;
+    /* split_terms == 3 ("f16x2") only: power-of-two scales of the fp16 operand images (see "f16x2" below).
+     * [0..3] the weight images in_proj, out_proj, fc1, fc2 (the *_weight3 pointers then hold avd_split_f16x2_f32 images);
+     * [4..7] the activation images: norm1 output, q|k|v (and the attention output), norm2 output, GELU(fc1) output.  Each
+     * activation scale must satisfy scale * bound <= 2^15 for a bound on the magnitudes the image can hold. */
+    float f16x2_scale[8];
 } avd_block_weights;
 
 typedef struct {                       /* avdiff/models/mmdt.py:116-149 (MMDiT) */
@@ -202,7 +207,9 @@ typedef struct {                       /* avdiff/models/mmdt.py:116-149 (MMDiT) 
     int norm_kind;                     /* 0: RMSNorm (every shipped config); 1: nn.LayerNorm (build_norm, mmdt.py:44-45) — fp32 path only */
     const float* final_norm_bias;      /* final_norm.bias [d] for norm_kind 1, else NULL */
     int split_terms;                   /* bf16x3 path only: product terms kept per k — 0 or 6: default (fp32-level error), 9: strict
-                                        * (nothing dropped), 1: plain bf16 operands (reduced precision, BASELINE config C2) */
+                                        * (nothing dropped), 1: plain bf16 operands (reduced precision, BASELINE config C2),
+                                        * 3: f16x2 — two scaled fp16 planes per operand, three terms (22-bit operands, fp32
+                                        * accumulation; needs avd_block_weights.f16x2_scale) */
     int attn_mode;                     /* bf16x3 path only: 0 = attention follows split_terms; 1 = fp8 (OCP e4m3) QK^T and PV with fp32
                                         * accumulation (csrc/attn_fp8.hip) — reduced precision, BASELINE config C5, reported error */
 } avd_core_weights;
@@ -263,6 +270,26 @@ int avd_attn_fwd_fp8_f32(const void* qkv3, void* workspace, int64_t workspace_by
  * C3 != NULL: the result is written as the split3 image of [M,N] instead (bias + AVD_ACT_GELU, no residual). */
 int avd_gemm_bf16x3_f32(const void* A3, const void* W3, const float* bias, const float* residual, float* C, void* C3,
                         int64_t M, int N, int K, int act, int terms, avd_stream_t stream);
+
+/* ---- "f16x2": the same Linear / attention (mmdt.py:51-61,77-83) with every operand held as TWO fp16 planes, x ~ (h + l) / s
+ * with h = rn_f16(s x), l = rn_f16(s x - h), and three product terms hh + hl + lh accumulated in fp32 on
+ * v_mfma_f32_32x32x16_f16: half the matrix-pipe work of bf16x3.  An operand carries 22 significant bits (error <= 2^-22
+ * relative) and the dropped ll term is <= 2^-22 relative, so a product is accurate to ~7e-7 against fp32's 6e-8 rounding;
+ * over a dot product these errors add like the fp32 accumulation rounding both modes share (measured error in DESIGN.md).
+ * fp16 has 5 exponent bits, so an image is stored at a power-of-two `scale` with |scale * x| <= 2^15 for every element:
+ * the CALLER supplies the scale from a bound on |x| (for the MMDiT core the bounds follow from the weights alone, see
+ * multimodal_diffusion_amd/mmdt.py `_f16x2_scales`); a value past the range turns its output rows into NaN, never into a
+ * silently saturated number.  Images have the split3 / qkv3 geometry (same byte counts; the third plane is unused).
+ * ab_scale = (A image scale) * (W image scale); c_scale / qkv_scale / out_scale = scale of the image being written. */
+int avd_split_f16x2_f32(const float* x, void* out, int64_t rows, int K, float scale, avd_stream_t stream);
+int avd_rmsnorm_split_f16x2_f32(const float* x, const float* gamma, void* out, int64_t rows, int d, float eps, float scale,
+                                avd_stream_t stream);
+int avd_gemm_f16x2_f32(const void* A2, const void* W2, const float* bias, const float* residual, float* C, void* C2,
+                       int64_t M, int N, int K, int act, float ab_scale, float c_scale, avd_stream_t stream);
+int avd_gemm_f16x2_qkv_f32(const void* A2, const void* W2, const float* bias, void* qkv, int64_t M, int tokens, int heads,
+                           int K, float qscale, float ab_scale, float qkv_scale, avd_stream_t stream);
+int avd_attn_fwd_qkv_f16x2_f32(const void* qkv, float* out, void* out2, int B, int N, int H, int n_query, float qkv_scale,
+                               float out_scale, avd_stream_t stream);
 
 /* bytes of scratch avd_core_forward_f32 needs for a [B,N,d] input */
 int64_t avd_core_workspace_bytes(const avd_core_weights* w, int B, int N);

@@ -37,7 +37,7 @@ class BlockWeights(C.Structure):
         "norm2_scale", "fc1_weight", "fc1_bias", "fc2_weight", "fc2_bias",
         "in_proj_weight_n", "fc1_weight_n",
         "in_proj_weight3", "out_proj_weight3", "fc1_weight3", "fc2_weight3",
-        "norm1_bias", "norm2_bias")]
+        "norm1_bias", "norm2_bias")] + [("f16x2_scale", C.c_float * 8)]
 
 
 class CoreWeights(C.Structure):
@@ -83,7 +83,7 @@ class VaeEncodeDesc(C.Structure):
                 ("conv_w3", C.POINTER(C.c_void_p))]
 
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); must list every symbol include/avdiff_hip.h declares
@@ -124,6 +124,11 @@ SIGNATURES = {
     "avd_attn_fp8_workspace_bytes": (_L, [_I, _I, _I]),
     "avd_attn_fwd_fp8_f32": (_I, [_P, _P, _L, _P, _P, _I, _I, _I, _I, _P]),
     "avd_gemm_bf16x3_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    "avd_split_f16x2_f32": (_I, [_P, _P, _L, _I, _F, _P]),
+    "avd_rmsnorm_split_f16x2_f32": (_I, [_P, _P, _P, _L, _I, _F, _F, _P]),
+    "avd_gemm_f16x2_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _P]),
+    "avd_gemm_f16x2_qkv_f32": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _F, _F, _F, _P]),
+    "avd_attn_fwd_qkv_f16x2_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "avd_conv3_weight_bytes": (_L, []),
     "avd_conv3_weight_f32": (_I, [_P, _P, _P]),
     "avd_vae_decode_workspace_bytes": (_L, [C.POINTER(VaeDecodeDesc)]),
@@ -193,7 +198,7 @@ def stream_ptr(device: torch.device) -> int:
 
 
 # matrix-pipe modes of the MMDiT core / engine -> product terms of the split-operand kernels (avd_core_weights.split_terms)
-MATMUL_TERMS = {"f32": 0, "bf16x3": 6, "bf16x3_strict": 9, "bf16": 1}
+MATMUL_TERMS = {"f32": 0, "bf16x3": 6, "bf16x3_strict": 9, "bf16": 1, "f16x2": 3}
 
 
 def dev_f32(t: torch.Tensor, name: str = "tensor") -> torch.Tensor:

@@ -30,11 +30,17 @@ template <int TERMS> struct A3Terms;
 template <> struct A3Terms<6> { static constexpr int N = 6; static constexpr int PA[6] = {2, 0, 1, 1, 0, 0}; static constexpr int PB[6] = {0, 2, 1, 0, 1, 0}; };
 template <> struct A3Terms<9> { static constexpr int N = 9; static constexpr int PA[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}; static constexpr int PB[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}; };
 template <> struct A3Terms<1> { static constexpr int N = 1; static constexpr int PA[1] = {0}; static constexpr int PB[1] = {0}; };
+template <> struct A3Terms<3> { static constexpr int N = 3; static constexpr int PA[3] = {0, 1, 0}; static constexpr int PB[3] = {1, 0, 0}; };   // f16x2
 
 template <bool SPLIT_OUT, int TERMS>   // SPLIT_OUT: the [B*N, H*64] result is written as a split3 image (A operand of out_proj)
 __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsigned char* __restrict__ img, float* __restrict__ out,
-                                                                    int Bt, int N, int Npad, int H, int n_query, int nqb) {
+                                                                    int Bt, int N, int Npad, int H, int n_query, int nqb,
+                                                                    float s_inv2, float v_inv, float o_scale) {
+    // TERMS == 3 (f16x2 image of scale s): s_inv2 = 1 / s^2 takes the scores back to the exp2 domain, the probabilities are split
+    // at scale 2^15 (p <= 1), v_inv = 1 / s undoes V's scale, o_scale is the scale of the image written (SPLIT_OUT)
     constexpr int NW = A3_NW, ROWB = QKV3_ROWB;
+    constexpr bool F16 = TERMS == 3;
+    constexpr int NPL = s3_planes(TERMS);
     constexpr int PPW = 24 / NW;                       // 1-KiB DMA pieces per wave per 24 KiB operand tile
     __shared__ __attribute__((aligned(16))) unsigned char Ks[A3_KT * ROWB];
     __shared__ __attribute__((aligned(16))) unsigned char Vs[A3_KT * ROWB];
@@ -63,7 +69,7 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) qf[s][p] = *reinterpret_cast<const bf16x8*>(src + p * 128 + s * 32);
+            for (int p = 0; p < NPL; ++p) qf[s][p] = *reinterpret_cast<const bf16x8*>(src + p * 128 + s * 32);
     }
 
     // DMA of tile kt: linear, except that rows past the last token are fetched from token N-1 (finite filler: the scores
@@ -119,7 +125,6 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
         // (K plane, Q plane) resp. (V plane, P plane), small terms first
         using TT = A3Terms<TERMS>;
-        constexpr int NPL = TERMS == 1 ? 1 : 3;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             bf16x8 ka[3], kb2[3];
@@ -131,8 +136,8 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
             }
 #pragma unroll
             for (int t = 0; t < TT::N; ++t) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[TT::PA[t]], qf[s][TT::PB[t]], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb2[TT::PA[t]], qf[s][TT::PB[t]], s1, 0, 0, 0);
+                s0 = mma16<F16>(ka[TT::PA[t]], qf[s][TT::PB[t]], s0);
+                s1 = mma16<F16>(kb2[TT::PA[t]], qf[s][TT::PB[t]], s1);
             }
         }
         // K is free once every wave is here; V(kt) (issued a phase ago) has landed after the wait
@@ -140,6 +145,10 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
         __syncthreads();
         if (more) dma(Kb, Ks, kt + 1);
 
+        if constexpr (F16) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s0[r] *= s_inv2; s1[r] *= s_inv2; }
+        }
         if (!more && (N & (A3_KT - 1))) {   // ragged last tile: keys >= N contribute nothing
             const int kbase = kt * A3_KT;
 #pragma unroll
@@ -158,11 +167,12 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
         for (int r = 0; r < 16; ++r) mt = fmaxf(mt, s1[r]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
+        const float m_sub = F16 ? m_new - 15.0f : m_new;    // f16x2: probabilities are kept at scale 2^15 (sum and planes alike)
         float ps = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
-            s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+            s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_sub);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_sub);
             ps += s0[r] + s1[r];
         }
         if (__any(m_new > m_run)) {
@@ -184,10 +194,11 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pv[j] = kb ? s1[8 * t + j] : s0[8 * t + j];
                 u32x4 P[3];
-                split8<false>(pv, P[0], P[1], P[2]);
+                if constexpr (F16) split8_h2(pv, 1.0f, P[0], P[1]);
+                else split8<false>(pv, P[0], P[1], P[2]);
                 bf16x8 pf[3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) pf[p] = __builtin_bit_cast(bf16x8, P[p]);
+                for (int p = 0; p < NPL; ++p) pf[p] = __builtin_bit_cast(bf16x8, P[p]);
                 const int key0 = 32 * kb + 16 * t + 4 * hi + v_q;     // this lane's ADDRESS row of the first 4-key block
                 const int sw = ((key0 >> 1) & 1) << 2;                // same for key0 + 8
 #pragma unroll
@@ -206,8 +217,8 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
                     }
 #pragma unroll
                     for (int tt = 0; tt < TT::N; ++tt) {
-                        if (db == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[TT::PA[tt]], pf[TT::PB[tt]], o0, 0, 0, 0);
-                        else o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[TT::PA[tt]], pf[TT::PB[tt]], o1, 0, 0, 0);
+                        if (db == 0) o0 = mma16<F16>(vf[TT::PA[tt]], pf[TT::PB[tt]], o0);
+                        else o1 = mma16<F16>(vf[TT::PA[tt]], pf[TT::PB[tt]], o1);
                     }
                 }
             }
@@ -220,7 +231,8 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
 
     // ---- normalise and store: lane (q, hi) holds O[q][8 g + 4 hi + (0..3)] in regs 4g..4g+3 of o0 (d < 32) / o1 ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
+    // f16x2: o carries 2^15 s_v, l_tot carries 2^15
+    const float inv = F16 ? v_inv / l_tot : 1.0f / l_tot;
     const int d = H * A3_DH;
     if constexpr (SPLIT_OUT) {
         float ch[8][4];
@@ -242,7 +254,10 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
                 v[e] = hi ? recv : ch[c][e];
                 v[4 + e] = hi ? ch[c + 1][e] : recv;
             }
-            if (q_row < n_query) store_split8(o3, (int64_t)b * N + q_row, h * A3_DH + 8 * (c + hi), d, v);
+            if (q_row < n_query) {
+                if constexpr (F16) store_split8_h2(o3, (int64_t)b * N + q_row, h * A3_DH + 8 * (c + hi), d, v, o_scale);
+                else store_split8(o3, (int64_t)b * N + q_row, h * A3_DH + 8 * (c + hi), d, v);
+            }
         }
     } else if (q_row < n_query) {
         float* dst = out + ((int64_t)b * N + q_row) * d + h * A3_DH + 4 * hi;
@@ -260,16 +275,22 @@ int64_t qkv3_bytes(int B, int N, int H) { return (int64_t)3 * B * H * qkv3_npad(
 
 // out3 != null: split3 image of the [B*N, H*64] result; otherwise fp32 out [B, N, H*64]
 template <int TERMS>
-static void attn3_launch(const unsigned char* img, float* out, void* out3, int B, int N, int Npad, int H, int n_query, int nqb, hipStream_t st) {
+static void attn3_launch(const unsigned char* img, float* out, void* out3, int B, int N, int Npad, int H, int n_query, int nqb, hipStream_t st,
+                         float img_scale, float out_scale) {
+    const float s_inv2 = 1.0f / (img_scale * img_scale), v_inv = 1.0f / img_scale;
     if (out3)
         hipLaunchKernelGGL((attn_bf16x3_kernel<true, TERMS>), dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, static_cast<float*>(out3), B, N,
-                           Npad, H, n_query, nqb);
+                           Npad, H, n_query, nqb, s_inv2, v_inv, out_scale);
     else
-        hipLaunchKernelGGL((attn_bf16x3_kernel<false, TERMS>), dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, out, B, N, Npad, H, n_query, nqb);
+        hipLaunchKernelGGL((attn_bf16x3_kernel<false, TERMS>), dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, out, B, N, Npad, H, n_query, nqb,
+                           s_inv2, v_inv, out_scale);
 }
 
-int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms, hipStream_t st) {
-    AVD_REQUIRE(terms == 0 || terms == 6 || terms == 9 || terms == 1, AVD_EINVAL, "attn_bf16x3: terms must be 6, 9 or 1, got %d", terms);
+int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms, hipStream_t st, float img_scale,
+                float out_scale) {
+    AVD_REQUIRE(terms == 0 || terms == 6 || terms == 9 || terms == 1 || terms == 3, AVD_EINVAL, "attn_bf16x3: terms must be 6, 9, 1 or 3, got %d", terms);
+    AVD_REQUIRE(img_scale > 0.f && img_scale < __builtin_inff() && out_scale > 0.f && out_scale < __builtin_inff() &&
+                    img_scale * img_scale < __builtin_inff(), AVD_EINVAL, "attn_bf16x3: image scales must be positive and finite");
     AVD_REQUIRE(qkv3 && (out || out3), AVD_EINVAL, "attn_bf16x3: null pointer");
     AVD_REQUIRE(B > 0 && N > 0 && H > 0, AVD_EINVAL, "attn_bf16x3: bad dims B=%d N=%d H=%d", B, N, H);
     AVD_REQUIRE(n_query >= 0 && n_query <= N, AVD_EINVAL, "attn_bf16x3: n_query=%d outside [0,%d]", n_query, N);
@@ -282,9 +303,10 @@ int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, i
     ProfScope prof(tag, 4.0 * (double)B * H * (double)n_query * N * A3_DH, st);
     const int Npad = qkv3_npad(N);
     const auto* img = static_cast<const unsigned char*>(qkv3);
-    if (terms == 9) attn3_launch<9>(img, out, out3, B, N, Npad, H, n_query, nqb, st);
-    else if (terms == 1) attn3_launch<1>(img, out, out3, B, N, Npad, H, n_query, nqb, st);
-    else attn3_launch<6>(img, out, out3, B, N, Npad, H, n_query, nqb, st);
+    if (terms == 9) attn3_launch<9>(img, out, out3, B, N, Npad, H, n_query, nqb, st, 1.f, 1.f);
+    else if (terms == 1) attn3_launch<1>(img, out, out3, B, N, Npad, H, n_query, nqb, st, 1.f, 1.f);
+    else if (terms == 3) attn3_launch<3>(img, out, out3, B, N, Npad, H, n_query, nqb, st, img_scale, out_scale);
+    else attn3_launch<6>(img, out, out3, B, N, Npad, H, n_query, nqb, st, 1.f, 1.f);
     AVD_CHECK_LAUNCH("attn_bf16x3");
     return AVD_OK;
 }
@@ -294,6 +316,10 @@ int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, i
 extern "C" int64_t avd_qkv3_bytes(int B, int N, int H) {
     if (B <= 0 || N <= 0 || H <= 0) return -1;
     return avd::qkv3_bytes(B, N, H);
+}
+extern "C" int avd_attn_fwd_qkv_f16x2_f32(const void* qkv, float* out, void* out2, int B, int N, int H, int n_query, float qkv_scale,
+                                          float out_scale, avd_stream_t stream) {
+    return avd::attn_bf16x3(qkv, out, out2, B, N, H, n_query, 3, static_cast<hipStream_t>(stream), qkv_scale, out_scale);
 }
 extern "C" int avd_attn_fwd_qkv3_f32(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms,
                                      avd_stream_t stream) {

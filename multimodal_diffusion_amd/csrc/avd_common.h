@@ -147,6 +147,53 @@ __device__ __forceinline__ void store_split8(unsigned char* img, int64_t r, int 
     *reinterpret_cast<u32x4*>(dst + 2 * S3_PLANE) = Lo;
 }
 
+// ---- "f16x2" operand images (matmul mode with two fp16 planes and three product terms) -------------------------------------
+// Same geometry as the split3 / qkv3 images; plane 0 holds h = rn_f16(s x), plane 1 holds l = rn_f16(s x - h), plane 2 is unused
+// (never written, never moved).  s is a power of two chosen by the caller from a bound on |x| so that |s x| <= 2^15: fp16 has
+// only 5 exponent bits, so unlike bf16x3 the image is scaled; the consumer divides the scales out of its fp32 accumulators,
+// which is exact.  h + l carries 22 significant bits of s x (|error| <= 2^-22 |x|, or 2^-25 / s absolute for elements more than
+// 17 binades below the top of the range), and a product keeps hh + hl + lh (ll <= 2^-22 relative is dropped).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned int pk_f16(float a, float b) {      // v_cvt_pk_f16_f32, round to nearest even
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(v, f16x2));
+}
+__device__ __forceinline__ f32x2 unpk_f16(unsigned int p) { return __builtin_convertvector(__builtin_bit_cast(f16x2, p), f32x2); }
+
+// A value past the fp16 range (the caller's bound was wrong, or x is inf / NaN) becomes inf in h and NaN in l: the rows it
+// touches come out NaN instead of silently saturated.
+__device__ __forceinline__ void split8_h2(const float* v, float s, u32x4& H, u32x4& L) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float a = v[2 * e] * s, b = v[2 * e + 1] * s;
+        const unsigned int h = pk_f16(a, b);
+        const f32x2 u = unpk_f16(h);
+        H[e] = h;
+        L[e] = pk_f16(a - u[0], b - u[1]);
+    }
+}
+__device__ __forceinline__ void store_split8_h2(unsigned char* img, int64_t r, int k, int K, const float* v, float s) {
+    u32x4 H, L;
+    split8_h2(v, s, H, L);
+    const int rr = (int)(r & 127), half = (k >> 3) & 1;
+    unsigned char* dst = img + ((r >> 7) * (K >> 4) + (k >> 4)) * (int64_t)S3_CHUNK + rr * 32 + ((half ^ ((rr >> 3) & 1)) << 4);
+    *reinterpret_cast<u32x4*>(dst) = H;
+    *reinterpret_cast<u32x4*>(dst + S3_PLANE) = L;
+}
+
+// one 32x32x16 MFMA on 16-bit operands held as bf16x8 bit patterns: bf16 planes, or (F16) the fp16 planes of an f16x2 image
+template <bool F16>
+__device__ __forceinline__ f32x16 mma16(bf16x8 a, bf16x8 b, f32x16 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// planes a matmul mode moves and reads: terms 1 -> h; 3 (f16x2) -> h, l; 6 / 9 -> h, m, l
+__host__ __device__ constexpr int s3_planes(int terms) { return terms == 1 ? 1 : terms == 3 ? 2 : 3; }
+
 // ---- qkv3 image of the bf16x3 attention (attn_bf16x3.hip): for part in {q,k,v}, sample b, head h, rows n in [0,Npad) of
 // 384 B = [plane h | m | l][64 d bf16]; the 16-byte chunk c (8 d) of a row sits at slot c ^ qkv3_swizzle(part, n) ----
 constexpr int QKV3_ROWB = 384;
@@ -189,21 +236,25 @@ int layernorm_act_f32(const float* x, const float* gamma, const float* beta, flo
 
 // bf16x3 path (gemm_bf16x3.hip)
 int64_t split3_bytes(int64_t rows, int K);
-int split3_f32(const float* x, int64_t ld, void* out, int64_t rows, int K, hipStream_t st);
-int rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t rows, int d, float eps, hipStream_t st);
+// h2_scale > 0: write the f16x2 image with that scale instead of the three bf16 planes
+int split3_f32(const float* x, int64_t ld, void* out, int64_t rows, int K, hipStream_t st, float h2_scale = 0.f);
+int rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t rows, int d, float eps, hipStream_t st, float h2_scale = 0.f);
 bool gemm_bf16x3_supported(int64_t M, int N, int K);
 int attn_f32_split3(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st);
 // sk_ws / sk_floats: optional scratch for the stream-K launch (gemm_bf16x3_sk_floats() floats); null = plain tiling
 int64_t gemm_bf16x3_sk_floats();
 extern int g_s3_streamk;
+// terms == 3 (f16x2): ab_scale = (A image scale) x (W image scale), c_scale = scale of the image written (if one is written)
 int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* img, int64_t M, int tokens, int heads, int K, float qscale,
-                     int terms, hipStream_t st, float* sk_ws = nullptr, int64_t sk_floats = 0);
+                     int terms, hipStream_t st, float* sk_ws = nullptr, int64_t sk_floats = 0, float ab_scale = 1.f, float c_scale = 1.f);
 int64_t qkv3_bytes(int B, int N, int H);
 // fp8 attention (attn_fp8.hip): reads the same qkv3 image, needs attn_fp8_ws_bytes(B, N, H) of scratch
 int64_t attn_fp8_ws_bytes(int B, int N, int H);
 int attn_fp8(const void* qkv3, void* ws, int64_t ws_bytes, float* out, void* out3, int B, int N, int H, int n_query, hipStream_t st);
-int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms, hipStream_t st);
+// terms == 3: img_scale = scale of the qkv image, out_scale = scale of the image written to out3
+int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms, hipStream_t st,
+                float img_scale = 1.f, float out_scale = 1.f);
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
-                int act, int terms, hipStream_t st, float* sk_ws = nullptr, int64_t sk_floats = 0);
+                int act, int terms, hipStream_t st, float* sk_ws = nullptr, int64_t sk_floats = 0, float ab_scale = 1.f, float c_scale = 1.f);
 
 }  // namespace avd

@@ -153,8 +153,16 @@ static int check_core(const avd_core_weights* w) {
     AVD_REQUIRE(w->norm_kind == 0 || w->norm_kind == 1, AVD_EINVAL, "core: norm_kind must be 0 (RMSNorm) or 1 (LayerNorm)");
     AVD_REQUIRE(w->d / w->n_heads == 64, AVD_EUNSUPPORTED, "core: head_dim %d unsupported (64 only)", w->d / w->n_heads);
     AVD_REQUIRE(w->d % 4 == 0 && w->mlp_hidden % 4 == 0, AVD_EUNSUPPORTED, "core: widths must be multiples of 4");
-    AVD_REQUIRE(w->split_terms == 0 || w->split_terms == 6 || w->split_terms == 9 || w->split_terms == 1, AVD_EINVAL,
-                "core: split_terms must be 0/6 (default), 9 (strict) or 1 (plain bf16), got %d", w->split_terms);
+    AVD_REQUIRE(w->split_terms == 0 || w->split_terms == 6 || w->split_terms == 9 || w->split_terms == 1 || w->split_terms == 3, AVD_EINVAL,
+                "core: split_terms must be 0/6 (default), 9 (strict), 1 (plain bf16) or 3 (f16x2), got %d", w->split_terms);
+    if (w->split_terms == 3) {
+        AVD_REQUIRE(w->attn_mode == 0, AVD_EUNSUPPORTED, "core: the fp8 attention reads bf16 planes; it cannot follow split_terms 3 (f16x2)");
+        for (int l = 0; l < w->n_layers; ++l)
+            for (int i = 0; i < 8; ++i) {
+                const float s = w->blocks[l].f16x2_scale[i];
+                AVD_REQUIRE(s > 0.f && s < __builtin_inff(), AVD_EINVAL, "core: blocks[%d].f16x2_scale[%d] must be positive and finite", l, i);
+            }
+    }
     return AVD_OK;
 }
 
@@ -198,18 +206,27 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
             const avd_block_weights& b = w->blocks[l];
             const bool last = l == w->n_layers - 1;
             const int nq = (last && out_row0 == 0) ? n_out_rows : N;
-            if (int rc = rmsnorm_split3_f32(cur, b.norm1_scale, hs, M, d, w->norm_eps, st)) return rc;
-            if (int rc = gemm_bf16x3_qkv3(hs, b.in_proj_weight3, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, terms, st, skw, skf)) return rc;
+            // f16x2 (terms 3): the images carry the block's power-of-two scales; every other mode ignores them
+            const bool h2 = terms == 3;
+            const float* fs = b.f16x2_scale;
+            const float s_n1 = h2 ? fs[4] : 0.f, s_qkv = h2 ? fs[5] : 1.f, s_n2 = h2 ? fs[6] : 0.f, s_fc1 = h2 ? fs[7] : 1.f;
+            const float w_in = h2 ? fs[0] : 1.f, w_out = h2 ? fs[1] : 1.f, w_fc1 = h2 ? fs[2] : 1.f, w_fc2 = h2 ? fs[3] : 1.f;
+            if (int rc = rmsnorm_split3_f32(cur, b.norm1_scale, hs, M, d, w->norm_eps, st, s_n1)) return rc;
+            if (int rc = gemm_bf16x3_qkv3(hs, b.in_proj_weight3, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, terms, st, skw, skf,
+                                          h2 ? s_n1 * w_in : 1.f, s_qkv)) return rc;
             if (w->attn_mode == 1) {
                 if (int rc = attn_fp8(qkv, skw, skf * 4, nullptr, hs, B, N, H, nq, st)) return rc;
             } else {
-                if (int rc = attn_bf16x3(qkv, nullptr, hs, B, N, H, nq, terms, st)) return rc;
+                if (int rc = attn_bf16x3(qkv, nullptr, hs, B, N, H, nq, terms, st, s_qkv, s_qkv)) return rc;
             }
-            if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, nullptr, M, d, d, AVD_ACT_NONE, terms, st, skw, skf)) return rc;
+            if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, nullptr, M, d, d, AVD_ACT_NONE, terms, st, skw, skf,
+                                     h2 ? s_qkv * w_out : 1.f, 1.f)) return rc;
             cur = y;
-            if (int rc = rmsnorm_split3_f32(y, b.norm2_scale, hs, M, d, w->norm_eps, st)) return rc;
-            if (int rc = gemm_bf16x3(hs, b.fc1_weight3, b.fc1_bias, nullptr, nullptr, wide3, M, hid, d, AVD_ACT_GELU, terms, st, skw, skf)) return rc;
-            if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, nullptr, M, d, hid, AVD_ACT_NONE, terms, st, skw, skf)) return rc;
+            if (int rc = rmsnorm_split3_f32(y, b.norm2_scale, hs, M, d, w->norm_eps, st, s_n2)) return rc;
+            if (int rc = gemm_bf16x3(hs, b.fc1_weight3, b.fc1_bias, nullptr, nullptr, wide3, M, hid, d, AVD_ACT_GELU, terms, st, skw, skf,
+                                     h2 ? s_n2 * w_fc1 : 1.f, s_fc1)) return rc;
+            if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, nullptr, M, d, hid, AVD_ACT_NONE, terms, st, skw, skf,
+                                     h2 ? s_fc1 * w_fc2 : 1.f, 1.f)) return rc;
         }
         return rmsnorm_f32(y, rd, w->final_norm_scale, y, rd, M, d, w->norm_eps, st);
     }

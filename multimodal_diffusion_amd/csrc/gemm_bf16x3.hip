@@ -36,8 +36,9 @@ namespace avd {
 // producers
 // ---------------------------------------------------------------------------------------------------------
 // x [rows][K] (row stride ld) -> split3 image; rows in [rows, rows_pad) are written as zeros
+template <bool F16>   // F16: f16x2 image with scale s (avd_common.h)
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int64_t ld, unsigned char* __restrict__ out,
-                                                     int64_t rows, int64_t rows_pad, int K) {
+                                                     int64_t rows, int64_t rows_pad, int K, float s) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int per_row = K >> 3;
     if (i >= rows_pad * per_row) return;
@@ -48,14 +49,15 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
         *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(x + r * ld + k);
         *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(x + r * ld + k + 4);
     }
-    store_split8(out, r, k, K, v);
+    if constexpr (F16) store_split8_h2(out, r, k, K, v, s);
+    else store_split8(out, r, k, K, v);
 }
 
 // RMSNorm (mmdt.py:39-42, eps outside the sqrt) writing the split3 image of its output; one wave per row
-template <int NC>   // 8-element chunks per lane: d <= 512 * NC
+template <int NC, bool F16>   // 8-element chunks per lane: d <= 512 * NC
 __global__ __launch_bounds__(256) void rmsnorm_split3_kernel(const float* __restrict__ x, const float* __restrict__ scale,
                                                              unsigned char* __restrict__ out, int64_t rows, int d, float eps,
-                                                             float sqrt_d) {
+                                                             float sqrt_d, float s) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -81,7 +83,8 @@ __global__ __launch_bounds__(256) void rmsnorm_split3_kernel(const float* __rest
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = scale[c + e] * v[i][e] / den;
-            store_split8(out, row, c, d, o);
+            if constexpr (F16) store_split8_h2(out, row, c, d, o, s);
+            else store_split8(out, row, c, d, o);
         }
     }
 }
@@ -102,7 +105,8 @@ struct S3Args {
     int N, K, nbn, sm, sn;
     int tokN, tokNpad, heads;   // EPI_QKV3: tokens per sample, padded tokens per sample, heads (N == 3 * heads * 64)
     float qscale;               // EPI_QKV3: factor folded into q before it is split (softmax scale * log2 e)
-    int terms;                  // 6 (default), 9 (strict) or 1 (plain bf16 operands)
+    int terms;                  // 6 (default), 9 (strict), 1 (plain bf16 operands) or 3 (f16x2 images)
+    float ab_inv, c_scale;      // terms 3: 1 / (A image scale x W image scale) applied to the sums; scale of the image written
     // stream-K (sk_partial != null): the grid is one resident block per slot; XCD x owns a contiguous range of tiles and its
     // blocks split that range's (tile, K-step) sequence evenly.  A block whose range ends inside a tile parks its accumulators
     // in sk_partial[blockIdx] and raises sk_flags[blockIdx]; the block whose range reaches the tile's end adds the parked
@@ -237,7 +241,7 @@ __device__ __forceinline__ void s3_park(f32x16 (&acc)[4][2], float* slab, float*
     }
 }
 
-template <int EPI>
+template <int EPI, bool F16>
 __device__ __forceinline__ void s3_epilogue(const S3Args& g, f32x16 (&acc)[4][2], float* slab, int64_t mwave0, int nbase, int lane,
                                             const SkParts& sp) {
     const int l31 = lane & 31, hi = lane >> 5;
@@ -275,15 +279,22 @@ __device__ __forceinline__ void s3_epilogue(const S3Args& g, f32x16 (&acc)[4][2]
                     sk_add4(sp, m, n + 4, *reinterpret_cast<f32x4*>(v + 4));
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[e]) * mul;
+                for (int e = 0; e < 8; ++e) v[e] = ((F16 ? v[e] * g.ab_inv : v[e]) + bv[e]) * mul;
                 if (m < g.M) {
                     const int b = (int)(m / g.tokN), tok = (int)(m - (int64_t)b * g.tokN);
-                    u32x4 Hh, Mi, Lo;
-                    split8(v, Hh, Mi, Lo);
                     unsigned char* dst = pbase + ((int64_t)b * g.heads * g.tokNpad + tok) * QKV3_ROWB + ((c ^ qkv3_swizzle(part, tok)) << 4);
-                    *reinterpret_cast<u32x4*>(dst) = Hh;
-                    *reinterpret_cast<u32x4*>(dst + 128) = Mi;
-                    *reinterpret_cast<u32x4*>(dst + 256) = Lo;
+                    if constexpr (F16) {
+                        u32x4 Hh, Lo;
+                        split8_h2(v, g.c_scale, Hh, Lo);
+                        *reinterpret_cast<u32x4*>(dst) = Hh;
+                        *reinterpret_cast<u32x4*>(dst + 128) = Lo;
+                    } else {
+                        u32x4 Hh, Mi, Lo;
+                        split8(v, Hh, Mi, Lo);
+                        *reinterpret_cast<u32x4*>(dst) = Hh;
+                        *reinterpret_cast<u32x4*>(dst + 128) = Mi;
+                        *reinterpret_cast<u32x4*>(dst + 256) = Lo;
+                    }
                 }
             }
         } else if constexpr (EPI == S3_EPI_GELU_SPLIT) {
@@ -304,8 +315,11 @@ __device__ __forceinline__ void s3_epilogue(const S3Args& g, f32x16 (&acc)[4][2]
                     sk_add4(sp, m, n + 4, *reinterpret_cast<f32x4*>(v + 4));
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e] + bv[e]);
-                if (m < g.M) store_split8(g.C3, m, n, g.N, v);
+                for (int e = 0; e < 8; ++e) v[e] = gelu_erf((F16 ? v[e] * g.ab_inv : v[e]) + bv[e]);
+                if (m < g.M) {
+                    if constexpr (F16) store_split8_h2(g.C3, m, n, g.N, v, g.c_scale);
+                    else store_split8(g.C3, m, n, g.N, v);
+                }
             }
         } else {
             // 16 lanes per row (4 columns each), 4 rows per wave instruction
@@ -329,6 +343,7 @@ __device__ __forceinline__ void s3_epilogue(const S3Args& g, f32x16 (&acc)[4][2]
                     const int it = c0 + u;
                     f32x4 v = *reinterpret_cast<const f32x4*>(slab + (cr + it * 4) * CLD + cc);
                     if (sp.p0) sk_add4(sp, m0 + cr + it * 4, n, v);
+                    if constexpr (F16) v *= g.ab_inv;
                     v += bv;
                     if constexpr (EPI == S3_EPI_RES) v += rv[u];
                     if (m0 + cr + it * 4 < g.M) *reinterpret_cast<f32x4*>(cptr + (int64_t)it * 4 * g.N) = v;
@@ -346,6 +361,8 @@ template <int TERMS> struct S3Terms;
 template <> struct S3Terms<6> { static constexpr int N = 6; static constexpr int PA[6] = {2, 0, 1, 1, 0, 0}; static constexpr int PB[6] = {0, 2, 1, 0, 1, 0}; };
 template <> struct S3Terms<9> { static constexpr int N = 9; static constexpr int PA[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0}; static constexpr int PB[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0}; };
 template <> struct S3Terms<1> { static constexpr int N = 1; static constexpr int PA[1] = {0}; static constexpr int PB[1] = {0}; };
+// 3: f16x2 images (two fp16 planes h, l with 11 significant bits each): hl, lh, hh; ll (2^-22 relative) is dropped
+template <> struct S3Terms<3> { static constexpr int N = 3; static constexpr int PA[3] = {0, 1, 0}; static constexpr int PB[3] = {1, 0, 0}; };
 
 constexpr int S3_BM = 256, S3_BN = 256, S3_NST = 3;
 constexpr int S3_STAGE = (S3_BM + S3_BN) * 96;          // 48 KiB
@@ -355,7 +372,8 @@ template <int EPI, int TERMS, bool SK>
 __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
     constexpr int BM = S3_BM, BN = S3_BN, WM = 128, WN = 64;
     constexpr int TM = 4, TN = 2, NST = S3_NST, STAGE = S3_STAGE;
-    constexpr int NPL = TERMS == 1 ? 1 : 3;               // planes moved and read
+    constexpr int NPL = s3_planes(TERMS);                 // planes moved and read
+    constexpr bool F16 = TERMS == 3;
     constexpr int PPR = 4 * NPL;                          // one-KiB pieces per 128-row region per stage
     constexpr int PPW = 4 * PPR / 8;                      // 4 regions per stage / 8 waves
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
@@ -469,7 +487,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TT::PA[t]], bf[j][TT::PB[t]], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mma16<F16>(af[i][TT::PA[t]], bf[j][TT::PB[t]], acc[i][j]);
         }
         __syncthreads();
 
@@ -495,7 +513,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
                 if (np == 0) sp.p0 = pp; else if (np == 1) sp.p1 = pp; else sp.p2 = pp;
             }
         }
-        s3_epilogue<EPI>(g, acc, slab, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane, sp);
+        s3_epilogue<EPI, F16>(g, acc, slab, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane, sp);
         if (!sk) break;
         __syncthreads();      // slabs drained before the next segment's DMA lands on them
     }
@@ -514,7 +532,8 @@ template <int EPI, int TERMS, bool SK>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
     constexpr int BM = S3B_BM, BN = S3B_BN, WM = 128, WN = 64;
     constexpr int TM = 4, TN = 2, STAGE = S3B_STAGE;
-    constexpr int NPL = TERMS == 1 ? 1 : 3;
+    constexpr int NPL = s3_planes(TERMS);
+    constexpr bool F16 = TERMS == 3;
     constexpr int PPR = 4 * NPL;                          // one-KiB pieces per 128-row region per stage
     constexpr int PPW = 3 * PPR / 4;                      // 3 regions per stage / 4 waves
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
@@ -560,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
 #define S3_LDA(dst, st, p) _Pragma("unroll") for (int i = 0; i < TM; ++i) dst[i] = *reinterpret_cast<const bf16x8*>((st) + a_off[i] + S3_PLANE * (p))
 #define S3_LDB(dst, st, p) _Pragma("unroll") for (int j = 0; j < TN; ++j) dst[j] = *reinterpret_cast<const bf16x8*>((st) + b_off[j] + S3_PLANE * (p))
 #define S3_MM(A_, B_) _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int j = 0; j < TN; ++j) \
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[i], B_[j], acc[i][j], 0, 0, 0)
+        acc[i][j] = mma16<F16>(A_[i], B_[j], acc[i][j])
 
     for (;;) {      // segments of a stream-K block; exactly one pass otherwise
     int k0 = 0, k1 = ng;
@@ -612,8 +631,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
     S3_LDA(ah, smem3, 0);
     S3_LDB(bh, smem3, 0);
     if constexpr (TERMS != 1) {
-        S3_LDA(am, smem3, 1); S3_LDA(al, smem3, 2);
-        S3_LDB(bmm, smem3, 1); S3_LDB(bl, smem3, 2);
+        S3_LDA(am, smem3, 1);
+        S3_LDB(bmm, smem3, 1);
+    }
+    if constexpr (TERMS == 6 || TERMS == 9) {
+        S3_LDA(al, smem3, 2);
+        S3_LDB(bl, smem3, 2);
     }
 
     for (int kt = 0; kt < nk; ++kt) {
@@ -627,6 +650,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
         if constexpr (TERMS == 1) {
             bf16x8 bh_n[TN];
             S3_LDA(ah_n, nx, 0);
+            S3_LDB(bh_n, nx, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            S3_MM(ah, bh);                     // (h,h)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bh[j] = bh_n[j];
+        } else if constexpr (TERMS == 3) {     // f16x2: plane 1 (am / bmm) is l
+            bf16x8 bh_n[TN];
+            S3_MM(ah, bmm);                    // (h,l)  -> bmm dead
+            S3_LDB(bmm, nx, 1);
+            S3_LDA(ah_n, nx, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            S3_MM(am, bh);                     // (l,h)  -> am dead
+            S3_LDA(am, nx, 1);
             S3_LDB(bh_n, nx, 0);
             __builtin_amdgcn_sched_barrier(0);
             S3_MM(ah, bh);                     // (h,h)
@@ -690,7 +727,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
             if (np == 0) sp.p0 = pp; else if (np == 1) sp.p1 = pp; else sp.p2 = pp;
         }
     }
-    s3_epilogue<EPI>(g, acc, slab, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane, sp);
+    s3_epilogue<EPI, F16>(g, acc, slab, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane, sp);
     if (!sk) break;
     __syncthreads();      // slabs drained before the next segment's DMA lands on them
     }   // segments
@@ -704,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
 // ---------------------------------------------------------------------------------------------------------
 int64_t split3_bytes(int64_t rows, int K) { return ((rows + 255) / 256 * 256) * (int64_t)K * 6; }
 
-int split3_f32(const float* x, int64_t ld, void* out, int64_t rows, int K, hipStream_t st) {
+int split3_f32(const float* x, int64_t ld, void* out, int64_t rows, int K, hipStream_t st, float h2_scale) {
     AVD_REQUIRE(x && out, AVD_EINVAL, "split3: null pointer");
     AVD_REQUIRE(rows > 0 && K > 0 && K % 16 == 0 && ld >= K && ld % 4 == 0, AVD_EUNSUPPORTED,
                 "split3: need rows > 0, K %% 16 == 0, ld %% 4 == 0 (rows=%lld K=%d ld=%lld)", (long long)rows, K, (long long)ld);
@@ -714,13 +751,18 @@ int split3_f32(const float* x, int64_t ld, void* out, int64_t rows, int K, hipSt
     AVD_REQUIRE((n + 255) / 256 < (1ll << 31), AVD_EUNSUPPORTED, "split3: grid too large");
     static const int tag = prof_tag_id("split3_kernel");
     ProfScope prof(tag, (double)rows * K * 10.0, st);
-    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ld,
-                       static_cast<unsigned char*>(out), rows, rows_pad, K);
+    AVD_REQUIRE(h2_scale >= 0.f && h2_scale < __builtin_inff(), AVD_EINVAL, "split3: f16x2 image scale must be positive and finite");
+    if (h2_scale > 0.f)
+        hipLaunchKernelGGL(split3_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ld,
+                           static_cast<unsigned char*>(out), rows, rows_pad, K, h2_scale);
+    else
+        hipLaunchKernelGGL(split3_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ld,
+                           static_cast<unsigned char*>(out), rows, rows_pad, K, 0.f);
     AVD_CHECK_LAUNCH("split3");
     return AVD_OK;
 }
 
-int rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t rows, int d, float eps, hipStream_t st) {
+int rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t rows, int d, float eps, hipStream_t st, float h2_scale) {
     AVD_REQUIRE(x && scale && out, AVD_EINVAL, "rmsnorm_split3: null pointer");
     AVD_REQUIRE(rows > 0 && d > 0 && d % 16 == 0 && d <= 2048, AVD_EUNSUPPORTED, "rmsnorm_split3: d=%d must be a multiple of 16, <= 2048", d);
     AVD_REQUIRE(aligned16(x) && aligned16(out), AVD_EUNSUPPORTED, "rmsnorm_split3: pointers must be 16-byte aligned");
@@ -729,12 +771,17 @@ int rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t ro
     const unsigned grid = (unsigned)((rows + 3) / 4);
     const float isd = (float)sqrt((double)d);
     unsigned char* o = static_cast<unsigned char*>(out);
+    AVD_REQUIRE(h2_scale >= 0.f && h2_scale < __builtin_inff(), AVD_EINVAL, "rmsnorm_split3: f16x2 image scale must be positive and finite");
+#define AVD_RMS3(NC)                                                                                                                  \
+    if (h2_scale > 0.f) hipLaunchKernelGGL((rmsnorm_split3_kernel<NC, true>), dim3(grid), dim3(256), 0, st, x, scale, o, rows, d, eps, isd, h2_scale); \
+    else hipLaunchKernelGGL((rmsnorm_split3_kernel<NC, false>), dim3(grid), dim3(256), 0, st, x, scale, o, rows, d, eps, isd, 0.f)
     switch ((d + 511) / 512) {
-        case 1: hipLaunchKernelGGL(rmsnorm_split3_kernel<1>, dim3(grid), dim3(256), 0, st, x, scale, o, rows, d, eps, isd); break;
-        case 2: hipLaunchKernelGGL(rmsnorm_split3_kernel<2>, dim3(grid), dim3(256), 0, st, x, scale, o, rows, d, eps, isd); break;
-        case 3: hipLaunchKernelGGL(rmsnorm_split3_kernel<3>, dim3(grid), dim3(256), 0, st, x, scale, o, rows, d, eps, isd); break;
-        default: hipLaunchKernelGGL(rmsnorm_split3_kernel<4>, dim3(grid), dim3(256), 0, st, x, scale, o, rows, d, eps, isd); break;
+        case 1: AVD_RMS3(1); break;
+        case 2: AVD_RMS3(2); break;
+        case 3: AVD_RMS3(3); break;
+        default: AVD_RMS3(4); break;
     }
+#undef AVD_RMS3
     AVD_CHECK_LAUNCH("rmsnorm_split3");
     return AVD_OK;
 }
@@ -854,7 +901,8 @@ static int launch_s3(const S3Args& a, hipStream_t st) {
         case 0: case 6: return launch_s3t<EPI, 6>(a, st);
         case 9: return launch_s3t<EPI, 9>(a, st);
         case 1: return launch_s3t<EPI, 1>(a, st);
-        default: return set_error(AVD_EINVAL, "gemm_bf16x3: terms must be 6 (default), 9 (strict) or 1 (plain bf16), got %d", a.terms);
+        case 3: return launch_s3t<EPI, 3>(a, st);
+        default: return set_error(AVD_EINVAL, "gemm_bf16x3: terms must be 6 (default), 9 (strict), 1 (plain bf16) or 3 (f16x2), got %d", a.terms);
     }
 }
 
@@ -863,14 +911,16 @@ static int launch_s3(const S3Args& a, hipStream_t st) {
 int64_t gemm_bf16x3_sk_floats() { return (int64_t)2 * (sk_cu_count() > 0 ? sk_cu_count() : 256) * S3B_BM * S3B_BN; }
 
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
-                int act, int terms, hipStream_t st, float* sk_ws, int64_t sk_floats) {
+                int act, int terms, hipStream_t st, float* sk_ws, int64_t sk_floats, float ab_scale, float c_scale) {
     AVD_REQUIRE(A3 && W3 && (C || C3), AVD_EINVAL, "gemm_bf16x3: null pointer");
+    AVD_REQUIRE(ab_scale > 0.f && ab_scale < __builtin_inff() && c_scale > 0.f && c_scale < __builtin_inff(), AVD_EINVAL,
+                "gemm_bf16x3: image scales must be positive and finite");
     AVD_REQUIRE(gemm_bf16x3_supported(M, N, K), AVD_EUNSUPPORTED, "gemm_bf16x3: need N %% 256 == 0 and K %% 16 == 0 (M=%lld N=%d K=%d)",
                 (long long)M, N, K);
     AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(C) && aligned16(C3) && aligned16(bias) && aligned16(R), AVD_EUNSUPPORTED,
                 "gemm_bf16x3: pointers must be 16-byte aligned");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, R, C,
-             static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0, 0, 0, 0, 0.f, terms, sk_ws, nullptr, 0, sk_floats};
+             static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0, 0, 0, 0, 0.f, terms, 1.0f / ab_scale, c_scale, sk_ws, nullptr, 0, sk_floats};
     if (C3) {
         AVD_REQUIRE(act == AVD_ACT_GELU && !R && bias, AVD_EUNSUPPORTED, "gemm_bf16x3: split3 output implies bias + GELU, no residual");
         return launch_s3<S3_EPI_GELU_SPLIT>(a, st);
@@ -882,15 +932,18 @@ int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* 
 
 // in_proj for the bf16x3 attention: qkv = A W^T + bias written as the qkv3 image (q pre-multiplied by qscale)
 int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* img, int64_t M, int tokens, int heads, int K, float qscale,
-                     int terms, hipStream_t st, float* sk_ws, int64_t sk_floats) {
+                     int terms, hipStream_t st, float* sk_ws, int64_t sk_floats, float ab_scale, float c_scale) {
     AVD_REQUIRE(A3 && W3 && bias && img, AVD_EINVAL, "gemm_bf16x3_qkv3: null pointer");
+    AVD_REQUIRE(ab_scale > 0.f && ab_scale < __builtin_inff() && c_scale > 0.f && c_scale < __builtin_inff(), AVD_EINVAL,
+                "gemm_bf16x3_qkv3: image scales must be positive and finite");
     const int N = 3 * heads * 64;
     AVD_REQUIRE(tokens > 0 && heads > 0 && M > 0 && M % tokens == 0, AVD_EINVAL, "gemm_bf16x3_qkv3: rows %lld not a multiple of tokens %d",
                 (long long)M, tokens);
     AVD_REQUIRE(gemm_bf16x3_supported(M, N, K), AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: need 3*heads*64 %% 256 == 0 and K %% 16 == 0");
     AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(bias) && aligned16(img), AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: alignment");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, nullptr, nullptr,
-             static_cast<unsigned char*>(img), M, N, K, 0, 0, 0, tokens, qkv3_npad(tokens), heads, qscale, terms, sk_ws, nullptr, 0, sk_floats};
+             static_cast<unsigned char*>(img), M, N, K, 0, 0, 0, tokens, qkv3_npad(tokens), heads, qscale, terms, 1.0f / ab_scale, c_scale,
+             sk_ws, nullptr, 0, sk_floats};
     return launch_s3<S3_EPI_QKV3>(a, st);
 }
 
@@ -916,4 +969,24 @@ extern "C" int avd_gemm_bf16x3_f32(const void* A3, const void* W3, const float* 
 extern "C" int avd_gemm_bf16x3_qkv3_f32(const void* A3, const void* W3, const float* bias, void* qkv3, int64_t M, int tokens, int heads,
                                         int K, float qscale, int terms, avd_stream_t stream) {
     return gemm_bf16x3_qkv3(A3, W3, bias, qkv3, M, tokens, heads, K, qscale, terms, static_cast<hipStream_t>(stream), nullptr, 0);
+}
+
+// f16x2 mode (two fp16 planes, three product terms; avd_common.h): the same images with a caller-chosen power-of-two scale
+extern "C" int avd_split_f16x2_f32(const float* x, void* out, int64_t rows, int K, float scale, avd_stream_t stream) {
+    AVD_REQUIRE(scale > 0.f, AVD_EINVAL, "avd_split_f16x2_f32: scale must be positive");
+    return split3_f32(x, K, out, rows, K, static_cast<hipStream_t>(stream), scale);
+}
+extern "C" int avd_rmsnorm_split_f16x2_f32(const float* x, const float* gamma, void* out, int64_t rows, int d, float eps, float scale,
+                                           avd_stream_t stream) {
+    AVD_REQUIRE(scale > 0.f, AVD_EINVAL, "avd_rmsnorm_split_f16x2_f32: scale must be positive");
+    return rmsnorm_split3_f32(x, gamma, out, rows, d, eps, static_cast<hipStream_t>(stream), scale);
+}
+extern "C" int avd_gemm_f16x2_f32(const void* A2, const void* W2, const float* bias, const float* residual, float* C, void* C2, int64_t M,
+                                  int N, int K, int act, float ab_scale, float c_scale, avd_stream_t stream) {
+    return gemm_bf16x3(A2, W2, bias, residual, C, C2, M, N, K, act, 3, static_cast<hipStream_t>(stream), nullptr, 0, ab_scale, c_scale);
+}
+extern "C" int avd_gemm_f16x2_qkv_f32(const void* A2, const void* W2, const float* bias, void* qkv, int64_t M, int tokens, int heads, int K,
+                                      float qscale, float ab_scale, float qkv_scale, avd_stream_t stream) {
+    return gemm_bf16x3_qkv3(A2, W2, bias, qkv, M, tokens, heads, K, qscale, 3, static_cast<hipStream_t>(stream), nullptr, 0, ab_scale,
+                            qkv_scale);
 }

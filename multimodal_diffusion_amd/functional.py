@@ -238,3 +238,63 @@ def linear_bf16x3(x3: Tensor, rows: int, w3: Tensor, n: int, k: int, bias: Optio
         c, c3 = out.data_ptr(), None
     L.check(L.lib().avd_gemm_bf16x3_f32(x3.data_ptr(), w3.data_ptr(), L.ptr(b), L.ptr(r), c, c3, rows, n, k, act, terms, _st(x3)))
     return out
+
+
+# ---- "f16x2": two scaled fp16 planes per operand, three product terms (include/avdiff_hip.h) ----
+def f16x2_scale(bound: float) -> float:
+    """Largest power of two s with s * bound <= 2^15 (fp16 tops out at 65504), for a bound on |x| over the image.
+    The bound is widened by 1 % first so that fp32 rounding of the values it covers cannot cross it."""
+    import math
+    bound = float(bound) * 1.01
+    if not math.isfinite(bound):
+        raise L.AvdError("f16x2: the bound on the operand's magnitude is not finite")
+    if bound <= 0.0:
+        return 1.0
+    e = 15 - math.ceil(math.log2(bound))
+    return float(2.0 ** max(-100, min(100, e)))
+
+
+def split_f16x2(x: Tensor, scale: Optional[float] = None, out: Optional[Tensor] = None):
+    """fp32 [rows, K] -> (f16x2 image, scale).  scale None: derived from max|x| (one device sync)."""
+    x = L.dev_f32(x, "x")
+    k = x.shape[-1]
+    rows = x.numel() // k
+    nbytes = L.lib().avd_split3_bytes(rows, k)
+    if nbytes < 0:
+        raise L.AvdError(f"split_f16x2: K={k} must be a multiple of 16")
+    if scale is None:
+        scale = f16x2_scale(float(x.abs().max()))
+    if out is None or out.numel() != nbytes or out.device != x.device:
+        out = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+    L.check(L.lib().avd_split_f16x2_f32(x.data_ptr(), out.data_ptr(), rows, k, scale, _st(x)))
+    return out, scale
+
+
+def rmsnorm_split_f16x2(x: Tensor, gamma: Tensor, eps: float = 1e-6, scale: Optional[float] = None):
+    """RMSNorm(x) written as an f16x2 image; the default scale uses |y_i| <= sqrt(d) max|gamma|."""
+    x = L.dev_f32(x, "x")
+    gamma = L.dev_f32(gamma, "scale")
+    d = x.shape[-1]
+    rows = x.numel() // d
+    if scale is None:
+        scale = f16x2_scale(float(gamma.abs().max()) * d ** 0.5)
+    out = torch.empty(L.lib().avd_split3_bytes(rows, d), dtype=torch.uint8, device=x.device)
+    L.check(L.lib().avd_rmsnorm_split_f16x2_f32(x.data_ptr(), gamma.data_ptr(), out.data_ptr(), rows, d, eps, scale, _st(x)))
+    return out, scale
+
+
+def linear_f16x2(x2: Tensor, rows: int, w2: Tensor, n: int, k: int, ab_scale: float, bias: Optional[Tensor] = None,
+                 residual: Optional[Tensor] = None, act: int = L.ACT_NONE, out_scale: Optional[float] = None) -> Tensor:
+    """act(x @ W.T + bias) + residual with both operands given as f16x2 images of scales s_x, s_w (ab_scale = s_x * s_w);
+    fp32 [rows, n] result, or — out_scale given — its f16x2 image at that scale (bias + GELU only)."""
+    b = None if bias is None else L.dev_f32(bias, "bias")
+    r = None if residual is None else L.dev_f32(residual, "residual")
+    if out_scale is not None:
+        out = torch.empty(L.lib().avd_split3_bytes(rows, n), dtype=torch.uint8, device=x2.device)
+        c, c2 = None, out.data_ptr()
+    else:
+        out = torch.empty(rows, n, dtype=torch.float32, device=x2.device)
+        c, c2 = out.data_ptr(), None
+    L.check(L.lib().avd_gemm_f16x2_f32(x2.data_ptr(), w2.data_ptr(), L.ptr(b), L.ptr(r), c, c2, rows, n, k, act, ab_scale,
+                                       1.0 if out_scale is None else out_scale, _st(x2)))
+    return out

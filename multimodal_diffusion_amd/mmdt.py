@@ -155,7 +155,9 @@ class MMDiT(nn.Module):
         self._ws: Optional[torch.Tensor] = None
         # "f32": fp32 MFMA everywhere.  "bf16x3": the four projections of every block and the attention run on the bf16 matrix
         # pipe with exactly split operands (fp32-level error, csrc/gemm_bf16x3.hip) whenever the batch is large enough;
-        # "bf16x3_strict" keeps all nine product terms; "bf16" keeps one (plain bf16 operands — reduced precision, config C2).
+        # "bf16x3_strict" keeps all nine product terms; "bf16" keeps one (plain bf16 operands — reduced precision, config C2);
+        # "f16x2" holds every operand as two scaled fp16 planes (22 significant bits) and keeps three terms: half the matrix-pipe
+        # work of bf16x3, scales derived from the weights (_f16x2_scales).
         self.matmul = "f32"
         # "default": the attention follows `matmul`.  "fp8": QK^T and PV take e4m3 operands (csrc/attn_fp8.hip; needs a split matmul
         # mode) — reduced precision, BASELINE config C5, never the default.
@@ -176,14 +178,43 @@ class MMDiT(nn.Module):
             self._folded[name] = hit
         return hit[1]
 
-    def _split3_image(self, name: str, p: torch.Tensor) -> torch.Tensor:
-        key = (p.data_ptr(), p._version, tuple(p.shape))
+    def _split3_image(self, name: str, p: torch.Tensor, h2_scale: float = 0.0) -> torch.Tensor:
+        """Operand image of a weight: three bf16 planes, or (h2_scale > 0) the two fp16 planes of the f16x2 mode."""
+        key = (p.data_ptr(), p._version, tuple(p.shape), float(h2_scale))
         hit = self._split3.get(name)
         if hit is None or hit[0] != key:
             from . import functional as Fn
             old = hit[1] if hit is not None and hit[0][2] == key[2] and hit[1].device == p.device else None
-            hit = (key, Fn.split3(p.detach(), out=old))      # same storage when the shape is unchanged
+            # same storage when the shape is unchanged
+            img = Fn.split_f16x2(p.detach(), h2_scale, out=old)[0] if h2_scale > 0 else Fn.split3(p.detach(), out=old)
+            hit = (key, img)
             self._split3[name] = hit
+        return hit[1]
+
+    def _f16x2_scales(self, i: int, ps: dict):
+        """Power-of-two scales of block i's f16x2 images, from bounds that hold for EVERY input (so fp16 can never overflow):
+        RMSNorm output  |y_j| <= sqrt(d) max|gamma|  and  ||y||_2 <= sqrt(d) max|gamma|   (|x_j| <= ||x||_2 = sqrt(d) rms);
+        a Linear output |o_n| <= ||a||_2 ||w_n||_2 + |b_n|  (Cauchy-Schwarz);  attention output rows are convex combinations of
+        V rows;  |GELU(x)| <= |x|.  Cached per parameter version (one device sync when a parameter changes)."""
+        names = ("norm1_scale", "in_proj_weight", "in_proj_bias", "out_proj_weight", "norm2_scale", "fc1_weight", "fc1_bias",
+                 "fc2_weight")
+        key = tuple((ps[k].data_ptr(), ps[k]._version) for k in names)
+        hit = self._split3.get(f"{i}.f16x2")
+        if hit is None or hit[0] != key:
+            from . import functional as Fn
+            d = self.cfg.d_model
+            with torch.no_grad():
+                q = torch.stack([ps["norm1_scale"].abs().max(), ps["in_proj_weight"].norm(dim=1).max(), ps["in_proj_bias"].abs().max(),
+                                 ps["norm2_scale"].abs().max(), ps["fc1_weight"].norm(dim=1).max(), ps["fc1_bias"].abs().max(),
+                                 ps["in_proj_weight"].abs().max(), ps["out_proj_weight"].abs().max(), ps["fc1_weight"].abs().max(),
+                                 ps["fc2_weight"].abs().max()]).double().cpu().tolist()
+            g1, win, bin_, g2, wfc1, bfc1, m_in, m_out, m_fc1, m_fc2 = q
+            n1 = d ** 0.5 * g1
+            n2 = d ** 0.5 * g2
+            sc = [Fn.f16x2_scale(m_in), Fn.f16x2_scale(m_out), Fn.f16x2_scale(m_fc1), Fn.f16x2_scale(m_fc2),
+                  Fn.f16x2_scale(n1), Fn.f16x2_scale(n1 * win + bin_), Fn.f16x2_scale(n2), Fn.f16x2_scale(n2 * wfc1 + bfc1)]
+            hit = (key, sc)
+            self._split3[f"{i}.f16x2"] = hit
         return hit[1]
 
     def _attn_code(self) -> int:
@@ -191,6 +222,8 @@ class MMDiT(nn.Module):
             raise ValueError(f"attn must be 'default' or 'fp8', got {self.attn!r}")
         if self.attn == "fp8" and self.matmul == "f32":
             raise ValueError("attn='fp8' reads the qkv3 image of the split matmul modes: use matmul='bf16x3' (or 'bf16')")
+        if self.attn == "fp8" and self.matmul == "f16x2":
+            raise ValueError("attn='fp8' reads bf16 planes: it cannot be combined with matmul='f16x2'")
         return 1 if self.attn == "fp8" else 0
 
     # ---- pointer table for the composite (rebuilt per call: parameters may have moved) ----
@@ -221,10 +254,14 @@ class MMDiT(nn.Module):
                     keep.append(t)
                     setattr(arr[i], k + "_n", t.data_ptr())
             if self.matmul != "f32" and not ln:
-                for k in ("in_proj_weight", "out_proj_weight", "fc1_weight", "fc2_weight"):
-                    img = self._split3_image(f"{i}.{k}", ps[k])
+                sc = self._f16x2_scales(i, ps) if self.matmul == "f16x2" else None
+                for j, k in enumerate(("in_proj_weight", "out_proj_weight", "fc1_weight", "fc2_weight")):
+                    img = self._split3_image(f"{i}.{k}", ps[k], sc[j] if sc else 0.0)
                     keep.append(img)
                     setattr(arr[i], k + "3", img.data_ptr())
+                if sc:
+                    for j in range(8):
+                        arr[i].f16x2_scale[j] = sc[j]
         ln = isinstance(self.final_norm, LayerNorm)
         fin = L.dev_f32((self.final_norm.weight if ln else self.final_norm.scale).detach(), "final_norm.scale")
         keep.append(fin)

@@ -1,0 +1,333 @@
+"""GPU tests of the "f16x2" matmul mode (two scaled fp16 planes per operand, three product terms — include/avdiff_hip.h,
+csrc/gemm_bf16x3.hip, csrc/attn_bf16x3.hip): accuracy against fp64 / the CPU oracle next to the fp32-MFMA path, the image
+format, the scale bounds under adversarial weights, and the behaviour at the edges of the fp16 range."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import ref_cpu as R
+from test_gpu_parity import TOL, _full_modules, dev, full  # noqa: F401  (dev / full are fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+def _h2_decode(img: np.ndarray, rows: int, K: int) -> np.ndarray:
+    """Independent reading of the f16x2 image (split3 geometry, planes 0 and 1 hold fp16): -> [2, rows, K] float64."""
+    r = np.arange(rows)[:, None]
+    k = np.arange(K)[None, :]
+    f = ((r & 127) >> 3) & 1
+    half = (k >> 3) & 1
+    base = ((r >> 7) * (K // 16) + (k >> 4)) * (128 * 96) + (r & 127) * 32 + ((half ^ f) * 16) + (k & 7) * 2
+    f16 = img.view(np.float16)
+    return np.stack([f16[(base + p * 4096) // 2].astype(np.float64) for p in range(2)])
+
+
+def _gemm(dev, x, w, b=None, r=None, sx=None, sw=None):
+    from multimodal_diffusion_amd import functional as Fn
+    M, K = x.shape
+    N = w.shape[0]
+    x2, sx = Fn.split_f16x2(x.to(dev), sx)
+    w2, sw = Fn.split_f16x2(w.to(dev), sw)
+    y2 = Fn.linear_f16x2(x2, M, w2, N, K, sx * sw, bias=None if b is None else b.to(dev),
+                         residual=None if r is None else r.to(dev)).cpu().double()
+    y32 = Fn.linear(x.to(dev), w.to(dev), None if b is None else b.to(dev), residual=None if r is None else r.to(dev)).cpu().double()
+    ref = x.double() @ w.double().t()
+    if b is not None:
+        ref = ref + b.double()
+    if r is not None:
+        ref = ref + r.double()
+    mag = x.double().abs() @ w.double().abs().t()
+    return y2, y32, ref, mag
+
+
+def test_f16x2_scale_rule():
+    from multimodal_diffusion_amd import functional as Fn
+    for bound in (1e-6, 0.04, 1.0, 22.6, 32768.0, 1e9):
+        s = Fn.f16x2_scale(bound)
+        assert math.log2(s) == int(math.log2(s)) and s * bound <= 2.0 ** 15 and 2 * s * bound * 1.01 > 2.0 ** 15
+    assert Fn.f16x2_scale(0.0) == 1.0
+
+
+@pytest.mark.parametrize("rows,K", [(5, 16), (300, 512), (1000, 2048)])
+def test_split_f16x2_image(dev, rows, K):
+    """(h + l) / s reproduces x to 22 bits (2^-22 relative, or 2^-25 / s absolute for elements far below the top of the
+    range); l is at most half an ulp of h."""
+    from multimodal_diffusion_amd import functional as Fn
+    g = torch.Generator().manual_seed(rows + K)
+    x = torch.randn(rows, K, generator=g) * torch.exp(torch.randn(rows, 1, generator=g) * 2.0)
+    img, s = Fn.split_f16x2(x.to(dev))
+    pl = _h2_decode(img.cpu().numpy(), rows, K)
+    assert np.isfinite(pl).all() and np.abs(pl[0]).max() <= 2.0 ** 15
+    xd = x.numpy().astype(np.float64)
+    err = np.abs(pl.sum(0) / s - xd)
+    assert (err <= 2.0 ** -22 * np.abs(xd) + 2.0 ** -25 / s).all()
+    assert (np.abs(pl[1]) <= np.abs(pl[0]) * 2.0 ** -11 + 2.0 ** -25).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(700, 512, 256), (333, 768, 2048), (5000, 1536, 512), (130, 256, 16), (26944, 512, 512)])
+@pytest.mark.parametrize("mode", ["plain", "res", "gelu_split"])
+def test_gemm_f16x2_accuracy(dev, M, N, K, mode):
+    """Against fp64, next to the fp32-MFMA GEMM: the three-term product on 22-bit operands stays within a small multiple of the fp32
+    chain's error (both share the fp32 accumulation rounding, which dominates at these K)."""
+    from multimodal_diffusion_amd import functional as Fn, _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g) * 3.0
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    if mode == "gelu_split":
+        ref = R.gelu_erf(R.linear(x.double(), w.double(), b.double()))
+        x2, sx = Fn.split_f16x2(x.to(dev))
+        w2, sw = Fn.split_f16x2(w.to(dev))
+        so = Fn.f16x2_scale(float(ref.abs().max()))
+        img = Fn.linear_f16x2(x2, M, w2, N, K, sx * sw, bias=b.to(dev), act=L.ACT_GELU, out_scale=so).cpu().numpy()
+        y = torch.from_numpy(_h2_decode(img, M, N).sum(0) / so)
+        y32 = Fn.linear(x.to(dev), w.to(dev), b.to(dev), act=L.ACT_GELU).cpu().double()
+    else:
+        y, y32, ref, _ = _gemm(dev, x, w, b, r if mode == "res" else None)
+    e2 = (y.double() - ref).abs().max().item()
+    e32 = (y32 - ref).abs().max().item()
+    print(f"f16x2 gemm {M}x{N}x{K} {mode}: err {e2:.3e} (fp32-MFMA {e32:.3e}), |ref| {ref.abs().max().item():.3g}")
+    assert e2 <= 4e-6 * ref.abs().max().item()
+    assert e2 <= 2.5 * e32 + 1e-7, (e2, e32)
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 133, 4), (1, 421, 4), (3, 64, 8), (2, 37, 4)])
+def test_attention_f16x2(dev, B, N, H):
+    """in_proj epilogue -> f16x2 q|k|v image -> attention, against softmax(q k^T / 8) v in fp64 and the fp32-MFMA kernel."""
+    from multimodal_diffusion_amd import functional as Fn, _lib as L
+    d = H * 64
+    g = torch.Generator().manual_seed(B * 1000 + N + H)
+    qkv = torch.randn(B * N, 3 * d, generator=g) * 1.5
+    bias = torch.randn(3 * d, generator=g) * 0.1
+    lib = L.lib()
+    img = torch.empty(lib.avd_qkv3_bytes(B, N, H), dtype=torch.uint8, device=dev)
+    x2, sx = Fn.split_f16x2(qkv.to(dev))
+    w2, sw = Fn.split_f16x2(torch.eye(3 * d).to(dev))
+    sq = Fn.f16x2_scale(float((qkv + bias).abs().max()))
+    bd = bias.to(dev)
+    L.check(lib.avd_gemm_f16x2_qkv_f32(x2.data_ptr(), w2.data_ptr(), bd.data_ptr(), img.data_ptr(), B * N, N, H, 3 * d,
+                                       0.125 * 1.4426950408889634, sx * sw, sq, L.stream_ptr(dev)))
+    out = torch.empty(B, N, d, device=dev)
+    L.check(lib.avd_attn_fwd_qkv_f16x2_f32(img.data_ptr(), out.data_ptr(), None, B, N, H, N, sq, 1.0, L.stream_ptr(dev)))
+    full_ = (qkv + bias).double().view(B, N, 3, H, 64)
+    q, k, v = (full_[:, :, i].transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v).transpose(1, 2).reshape(B, N, d)
+    e2 = rel_err(out.cpu(), ref)
+    e32 = rel_err(Fn.attention((qkv + bias).view(B, N, 3 * d).to(dev), H).cpu(), ref)
+    print(f"f16x2 attention B{B} N{N} H{H}: err {e2:.3e} (fp32-MFMA {e32:.3e})")
+    assert e2 < 3e-6 and e2 < 3.0 * e32 + 2e-7, (e2, e32)
+    # image output (the A operand of out_proj) carries the same values to 22 bits; rows >= n_query stay untouched
+    o2 = torch.zeros(lib.avd_split3_bytes(B * N, d), dtype=torch.uint8, device=dev)
+    nq = max(1, N - 5)
+    L.check(lib.avd_attn_fwd_qkv_f16x2_f32(img.data_ptr(), None, o2.data_ptr(), B, N, H, nq, sq, sq, L.stream_ptr(dev)))
+    got = (_h2_decode(o2.cpu().numpy(), B * N, d).sum(0) / sq).reshape(B, N, d)
+    want = out.cpu().double().numpy()
+    assert np.abs(got[:, :nq] - want[:, :nq]).max() <= 2.0 ** -21 * np.abs(want).max()
+    assert not got[:, nq:].any()
+
+
+def test_core_f16x2_vs_oracle_and_f32(dev, full):
+    """MMDiT.forward at 16,840 rows: inside the fp32 parity tolerance, and within a small multiple of the fp32-MFMA path's own
+    distance from the fp64 oracle."""
+    ws, _ = full
+    core2, _, _, _ = _full_modules(dev, ws)
+    core32, _, _, _ = _full_modules(dev, ws)
+    core2.matmul = "f16x2"
+    x = torch.randn(40, 421, 512, generator=torch.Generator().manual_seed(12))
+    y2 = core2(x.to(dev)).cpu()
+    y32 = core32(x.to(dev)).cpu()
+    assert not torch.equal(y2, y32), "f16x2 path did not run"
+    assert torch.isfinite(y2).all()
+    sub = slice(0, 3)
+    ref = R.mmdit_forward(x[sub].double(), {k: v.double() for k, v in ws["core"].items()}, 8, 8)
+    e2, e32 = rel_err(y2[sub], ref), rel_err(y32[sub], ref)
+    print(f"f16x2 core: err {e2:.3e} (fp32-MFMA {e32:.3e})")
+    assert e2 < TOL and e32 < TOL
+    assert e2 < 3.0 * e32 + 1e-7, (e2, e32)
+    assert rel_err(y2, y32) < 3e-5
+
+
+def test_full_step_f16x2_vs_oracle(dev, full):
+    """BASELINE C3 shape, B=20 (16,840 rows), one CFG step against the CPU oracle; deterministic."""
+    import multimodal_diffusion_amd as A
+    ws, _ = full
+    core, head, av, aa = _full_modules(dev, ws)
+    B = 20
+    g = torch.Generator().manual_seed(256)
+    z_v = torch.randn(B, 8, 12, 32, 32, generator=g)
+    z_a = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn = torch.tensor([982, 500, 16, 999] * 5)
+    tp = torch.tensor([966, 480, -1, 979] * 5)
+    nb = 4
+    ref = R.denoise_step_a2v(z_v[:nb], z_a[:nb], tn[:nb], tp[:nb], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"],
+                             core=ws["core"], head=ws["head"], n_layers=8, n_heads=8, guidance=3.5)
+    outs = {}
+    for mode in ("f16x2", "f32"):
+        eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video",
+                              latent_shape=tuple(z_v.shape), prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=mode)
+        eng.set_prompt(z_a.to(dev))
+        outs[mode] = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev))
+        assert torch.equal(outs[mode], eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)))
+    e2, e32 = rel_err(outs["f16x2"][:nb].cpu(), ref), rel_err(outs["f32"][:nb].cpu(), ref)
+    print(f"f16x2 step: err {e2:.3e} (fp32-MFMA {e32:.3e})")
+    assert e2 < TOL and e2 < 3.0 * e32 + 1e-7, (e2, e32)
+
+
+def test_chain_f16x2_tracks_f32(dev, full):
+    """A 10-step DDIM + CFG trajectory at the C3 shape (B=20): within the chained tolerance of the fp32-MFMA mode (rel L2 <= 1e-3,
+    SURVEY 8c), eager and as a replayed HIP graph — late steps carry |x| ~ 1e4..1e5 in the residual stream."""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd import schedule_utils as su
+    ws, _ = full
+    B = 20
+    g = torch.Generator().manual_seed(99)
+    z = torch.randn(B, 8, 12, 32, 32, generator=g).to(dev)
+    za = torch.randn(B, 8, 150, generator=g).to(dev)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    sched = su.make_sampling_schedule(1000, 10)
+    outs = {}
+    for mode in ("f32", "bf16x3", "f16x2"):
+        core, head, av, aa = _full_modules(dev, ws)
+        eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video",
+                              latent_shape=tuple(z.shape), prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=mode)
+        eng.set_prompt(za)
+        outs[mode] = eng.run(z, sched)
+        if mode == "f16x2":
+            outs["f16x2_graph"] = eng.run(z, sched, graph=True)
+    ref = outs["f32"].double()
+    assert torch.isfinite(outs["f16x2"]).all()
+    l2 = {k: float((outs[k].double() - ref).norm() / ref.norm()) for k in ("bf16x3", "f16x2", "f16x2_graph")}
+    print(f"10-step chain vs fp32-MFMA, rel L2: {l2}, |x| max {ref.abs().max().item():.3g}")
+    assert l2["f16x2"] < 1e-3
+    assert torch.equal(outs["f16x2"], outs["f16x2_graph"])
+
+
+# ---------------------------------------------------------------------------------------------------- edges of the range
+@pytest.mark.parametrize("scale", [1e-30, 1e-12, 1.0, 1e12, 1e18])
+def test_f16x2_dynamic_range(dev, scale):
+    """The image scale absorbs the operand's magnitude: from 1e-30 to 1e18 the error stays a small multiple of the fp32 chain's."""
+    g = torch.Generator().manual_seed(int(abs(math.log10(scale))) + 3)
+    M, N, K = 300, 256, 512
+    x = torch.randn(M, K, generator=g) * scale
+    w = torch.randn(N, K, generator=g) * (1.0 / math.sqrt(K)) * (scale if scale > 1 else 1.0)
+    y2, y32, ref, mag = _gemm(dev, x, w)
+    assert torch.isfinite(y2).all()
+    assert ((y2 - ref).abs() <= 2.0 * K * 2.0 ** -24 * mag).all()
+    e2, e32 = (y2 - ref).abs().max().item(), (y32 - ref).abs().max().item()
+    assert e2 <= 2.5 * e32 + 1e-30, (e2, e32)
+
+
+def test_f16x2_wide_spread_inside_one_image(dev):
+    """One image, magnitudes spread over 2^24: elements far below the top of the range keep only the ABSOLUTE accuracy
+    2^-25 / s, which is what the documented bound promises — error <= 2^-21 sum|x w| + K 2^-24 max|x| max|w|."""
+    g = torch.Generator().manual_seed(21)
+    M, N, K = 260, 256, 512
+    x = torch.randn(M, K, generator=g) * torch.exp2(-torch.randint(0, 24, (M, K), generator=g).float())
+    w = torch.randn(N, K, generator=g) * torch.exp2(-torch.randint(0, 24, (N, K), generator=g).float())
+    y2, y32, ref, mag = _gemm(dev, x, w)
+    bound = 2.0 ** -21 * mag + K * 2.0 ** -24 * x.abs().max().item() * w.abs().max().item()
+    assert ((y2 - ref).abs() <= bound).all()
+    # fp16 subnormals in the planes are honoured by the matrix pipe: rows made ONLY of small elements are still accurate to
+    # the absolute floor of the image (not flushed to a relative 2^-11)
+    xs = torch.zeros(4, K)
+    xs[0, 0] = 1.0                                              # fixes the scale: s = 2^14
+    xs[1:] = torch.randn(3, K, generator=g) * 2.0 ** -20       # scaled to ~2^-6: the l plane is subnormal
+    ws = torch.randn(N, K, generator=g)
+    y2, _, ref, _ = _gemm(dev, xs, ws)
+    floor = K * 2.0 ** -25 / 2.0 ** 14 * ws.abs().max().item() * 2
+    print(f"small-element rows: err {(y2[1:] - ref[1:]).abs().max().item():.3e}, floor {floor:.3e}, "
+          f"flushed-l would be {2.0 ** -31 * math.sqrt(K):.3e}")
+    assert ((y2[1:] - ref[1:]).abs() <= floor + 2.0 ** -22 * (xs[1:].double().abs() @ ws.double().abs().t())).all()
+
+
+def test_f16x2_cancellation(dev):
+    """K-long catastrophic cancellation (products in +a, -a pairs): the error is bounded by the operands' 22 bits,
+    3 * 2^-22 per product plus the fp32 accumulation both paths share."""
+    g = torch.Generator().manual_seed(9)
+    M, N, K = 260, 256, 2048
+    a = torch.randn(M, K // 2, generator=g) * 100.0
+    x = torch.empty(M, K)
+    x[:, 0::2], x[:, 1::2] = a, -a
+    x[:, 1::2] += torch.randn(M, K // 2, generator=g) * 1e-5
+    w = torch.empty(N, K)
+    wv = torch.randn(N, K // 2, generator=g)
+    w[:, 0::2], w[:, 1::2] = wv, wv
+    y2, y32, ref, mag = _gemm(dev, x, w)
+    assert ((y2 - ref).abs() <= (K * 2.0 ** -24 + 3 * 2.0 ** -22) * mag).all()
+    print(f"cancellation: f16x2 {(y2 - ref).abs().max().item():.3e}, fp32-MFMA {(y32 - ref).abs().max().item():.3e}")
+
+
+def test_f16x2_out_of_range_is_loud(dev):
+    """A scale that does not cover the data (or inf / NaN in it) must not saturate silently: the rows it touches come out NaN
+    and every other row is untouched."""
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(300, 256, generator=g)
+    w = torch.randn(256, 256, generator=g) / 16
+    x[5, 17] = 1.0e3                       # far past the scale derived for |x| <= 8 below
+    x[77, 3] = float("nan")
+    x[200, 0] = float("inf")
+    from multimodal_diffusion_amd import functional as Fn
+    y2, _, ref, _ = _gemm(dev, x, w, sx=Fn.f16x2_scale(8.0))
+    bad = torch.tensor([5, 77, 200])
+    good = torch.ones(300, dtype=torch.bool)
+    good[bad] = False
+    assert torch.isnan(y2[bad]).all()
+    assert torch.isfinite(y2[good]).all() and rel_err(y2[good], ref[good]) < 3e-6
+
+
+def test_f16x2_scales_hold_for_adversarial_weights(dev, full):
+    """The core's image scales come from bounds that hold for every input: blow up the norm gains, weights and biases, feed a
+    residual stream of magnitude 1e6 and rows of zeros — the result stays finite and tracks the fp32-MFMA path."""
+    ws, _ = full
+    cores = []
+    for mode in ("f16x2", "f32"):
+        core, _, _, _ = _full_modules(dev, ws)
+        g = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            for i, b in enumerate(core.blocks):
+                b.norm1.scale.mul_(40.0 if i % 2 else 0.02)
+                b.norm2.scale.mul_(0.03 if i % 2 else 25.0)
+                b.attn.mha.in_proj_weight.mul_(0.05 if i % 2 else 3.0)
+                b.attn.mha.in_proj_bias.add_(torch.randn(1536, generator=g).to(dev) * 5.0)
+                b.mlp.fc1.weight.mul_(0.1 if i % 2 else 2.0)
+                b.mlp.fc1.bias.add_(torch.randn(2048, generator=g).to(dev) * 3.0)
+                b.mlp.fc2.weight.mul_(1e-3 if i % 3 else 1.0)
+                b.attn.mha.out_proj.weight.mul_(1e-2 if i % 3 == 1 else 1.0)
+        core.matmul = mode
+        cores.append(core)
+    x = torch.randn(16, 421, 512, generator=torch.Generator().manual_seed(3))
+    x[0] *= 1e6
+    x[1] *= 1e-6
+    x[2, :100] = 0.0
+    x[3, 7, 5] = 3e7                                  # one huge outlier channel
+    y2 = cores[0](x.to(dev)).cpu()
+    y32 = cores[1](x.to(dev)).cpu()
+    assert not torch.equal(y2, y32)
+    assert torch.isfinite(y2).all() and torch.isfinite(y32).all()
+    for s in range(16):
+        assert rel_err(y2[s], y32[s].double()) < 1e-4, s
+
+
+def test_f16x2_engine_follows_weight_updates(dev, full):
+    """The scales are cached per parameter version: an in-place weight update (x64 on a norm gain with in_proj / 64, so the
+    attention logits keep their conditioning; x32 on fc1 with fc2 / 32) is picked up — a stale scale would overflow fp16."""
+    ws, _ = full
+    core, _, _, _ = _full_modules(dev, ws)
+    ref_core, _, _, _ = _full_modules(dev, ws)
+    core.matmul = "f16x2"
+    x = torch.randn(16, 421, 512, generator=torch.Generator().manual_seed(8)).to(dev)
+    y0 = core(x)
+    for c in (core, ref_core):
+        with torch.no_grad():
+            c.blocks[0].norm1.scale.mul_(64.0)
+            c.blocks[0].attn.mha.in_proj_weight.mul_(1.0 / 64.0)
+            c.blocks[3].mlp.fc1.weight.mul_(32.0)
+            c.blocks[3].mlp.fc2.weight.mul_(1.0 / 32.0)
+    y1, r1 = core(x), ref_core(x)
+    assert torch.isfinite(y1).all() and not torch.equal(y0, y1)
+    assert rel_err(y1.cpu(), r1.cpu().double()) < 1e-4
