@@ -226,6 +226,16 @@ typedef struct {                       /* avdiff/models/heads/noise_heads.py:94-
     const float* const* shared_ln_bias;
     const float* out_proj_weight;      /* out_proj.{m}.weight [d_out,hidden] */
     const float* out_proj_bias;
+    /* optional split-operand mode of the head's Linears (same meaning as avd_core_weights.split_terms; 0 = fp32 MFMA).  Taken when
+     * every image pointer below is non-NULL, d_in % 16 == 0, hidden % 256 == 0, d_out % 256 == 0 and there are >= 6144 rows. */
+    int split_terms;
+    const void* input_proj_weight3;    /* operand images of the weights above (avd_split3_f32, or avd_split_f16x2_f32 for terms 3) */
+    const void* const* shared_lin_weight3;
+    const void* out_proj_weight3;
+    /* split_terms == 3 only, HOST array of 2 * (n_shared + 2) power-of-two scales: the weight images [input_proj, shared 0.., out_proj],
+     * then the activation images [head input rows, input_proj output, LayerNorm+act output 0..] (the caller bounds the input rows;
+     * the rest follows from the weights, see multimodal_diffusion_amd/noise_heads.py) */
+    const float* f16x2_scale;
 } avd_head_weights;
 
 /* ---- "bf16x3": fp32-accurate Linear on the bf16 matrix pipe (same reference ops as avd_gemm_bias_act_f32:
@@ -267,7 +277,8 @@ int avd_attn_fwd_fp8_f32(const void* qkv3, void* workspace, int64_t workspace_by
                          int n_query, avd_stream_t stream);
 /* C = act(A W^T + bias) (+ residual), A3/W3 split3 images of A [M,K] and W [N,K]; N % 256 == 0, K % 16 == 0.
  * C3 == NULL: fp32 row-major C [M,N], act AVD_ACT_NONE, residual optional (may alias C).
- * C3 != NULL: the result is written as the split3 image of [M,N] instead (bias + AVD_ACT_GELU, no residual). */
+ * C3 != NULL: the result is written as the split3 image of [M,N] instead (bias required, act AVD_ACT_NONE or AVD_ACT_GELU,
+ * no residual). */
 int avd_gemm_bf16x3_f32(const void* A3, const void* W3, const float* bias, const float* residual, float* C, void* C3,
                         int64_t M, int N, int K, int act, int terms, avd_stream_t stream);
 

@@ -52,7 +52,9 @@ class HeadWeights(C.Structure):
                 ("input_proj_weight", C.c_void_p), ("input_proj_bias", C.c_void_p),
                 ("shared_lin_weight", C.POINTER(C.c_void_p)), ("shared_lin_bias", C.POINTER(C.c_void_p)),
                 ("shared_ln_weight", C.POINTER(C.c_void_p)), ("shared_ln_bias", C.POINTER(C.c_void_p)),
-                ("out_proj_weight", C.c_void_p), ("out_proj_bias", C.c_void_p)]
+                ("out_proj_weight", C.c_void_p), ("out_proj_bias", C.c_void_p),
+                ("split_terms", C.c_int), ("input_proj_weight3", C.c_void_p), ("shared_lin_weight3", C.POINTER(C.c_void_p)),
+                ("out_proj_weight3", C.c_void_p), ("f16x2_scale", C.POINTER(C.c_float))]
 
 
 class StepDesc(C.Structure):

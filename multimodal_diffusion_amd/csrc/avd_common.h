@@ -238,7 +238,10 @@ int layernorm_act_f32(const float* x, const float* gamma, const float* beta, flo
 int64_t split3_bytes(int64_t rows, int K);
 // h2_scale > 0: write the f16x2 image with that scale instead of the three bf16 planes
 int split3_f32(const float* x, int64_t ld, void* out, int64_t rows, int K, hipStream_t st, float h2_scale = 0.f);
+int split3_rows_f32(const float* x, RowMap xm, void* out, int64_t rows, int K, hipStream_t st, float h2_scale = 0.f);
 int rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t rows, int d, float eps, hipStream_t st, float h2_scale = 0.f);
+int layernorm_act_split3_f32(const float* x, const float* gamma, const float* beta, void* out, int64_t rows, int d, float eps, int act,
+                             hipStream_t st, float h2_scale = 0.f);
 bool gemm_bf16x3_supported(int64_t M, int N, int K);
 int attn_f32_split3(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st);
 // sk_ws / sk_floats: optional scratch for the stream-K launch (gemm_bf16x3_sk_floats() floats); null = plain tiling

@@ -278,7 +278,24 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
 }
 
 // ---------------------------------------------------------------- MultiModalNoiseHead (one modality path)
-static int64_t head_ws_bytes(const avd_head_weights* w, int64_t rows) { return 2 * align_up(rows * w->hidden * 4); }
+// split-operand mode of the head (gemm_bf16x3.hip): all four kinds of Linear must fit the 256-column tiles
+static bool head_use_split(const avd_head_weights* w, int64_t rows) {
+    if (w->split_terms == 0 || rows < split_min_rows()) return false;
+    if (!w->input_proj_weight3 || !w->out_proj_weight3 || (w->n_shared > 0 && !w->shared_lin_weight3)) return false;
+    for (int j = 0; j < w->n_shared; ++j)
+        if (!w->shared_lin_weight3[j]) return false;
+    if (w->split_terms == 3 && !w->f16x2_scale) return false;
+    return gemm_bf16x3_supported(rows, w->hidden, w->d_in) && gemm_bf16x3_supported(rows, w->hidden, w->hidden) &&
+           gemm_bf16x3_supported(rows, w->d_out, w->hidden);
+}
+
+static int64_t head_ws_bytes(const avd_head_weights* w, int64_t rows) {
+    const int64_t fp32_path = 2 * align_up(rows * w->hidden * 4);
+    if (!head_use_split(w, rows)) return fp32_path;
+    const int wide = w->d_in > w->hidden ? w->d_in : w->hidden;
+    const int64_t split_path = 2 * align_up(split3_bytes(rows, wide)) + align_up(rows * w->hidden * 4);
+    return split_path > fp32_path ? split_path : fp32_path;
+}
 
 static int head_forward(const avd_head_weights* w, const float* h, RowMap hm, int64_t rows, float* out, void* ws,
                         int64_t ws_bytes, hipStream_t st) {
@@ -287,11 +304,42 @@ static int head_forward(const avd_head_weights* w, const float* h, RowMap hm, in
     AVD_REQUIRE(w->input_proj_weight && w->out_proj_weight, AVD_EINVAL, "head: null weights");
     AVD_REQUIRE(w->n_shared == 0 || (w->shared_lin_weight && w->shared_lin_bias && w->shared_ln_weight && w->shared_ln_bias),
                 AVD_EINVAL, "head: null shared-trunk tables");
+    AVD_REQUIRE(w->split_terms == 0 || w->split_terms == 6 || w->split_terms == 9 || w->split_terms == 1 || w->split_terms == 3, AVD_EINVAL,
+                "head: split_terms must be 0 (fp32), 6, 9, 1 or 3, got %d", w->split_terms);
     AVD_REQUIRE(ws && ws_bytes >= head_ws_bytes(w, rows), AVD_EWORKSPACE, "head: workspace too small");
     Carver cv{static_cast<char*>(ws), 0, ws_bytes};
+    const RowMap rh{w->hidden, 0, 0}, ro{w->d_out, 0, 0};
+    if (head_use_split(w, rows)) {
+        // the same chain with every Linear on the split-operand kernels; activations travel as operand images
+        const int terms = w->split_terms, n = w->n_shared;
+        const bool h2 = terms == 3;
+        const float* fs = w->f16x2_scale;
+        if (h2)
+            for (int i = 0; i < 2 * (n + 2); ++i)
+                AVD_REQUIRE(fs[i] > 0.f && fs[i] < __builtin_inff(), AVD_EINVAL, "head: f16x2_scale[%d] must be positive and finite", i);
+        auto wsc = [&](int i) { return h2 ? fs[i] : 1.f; };                  // weight image i: input_proj, shared 0.., out_proj
+        auto asc = [&](int i) { return h2 ? fs[n + 2 + i] : 0.f; };          // activation image i: input, input_proj out, LN 0..
+        const int wide = w->d_in > w->hidden ? w->d_in : w->hidden;
+        void* imgA = cv.take((split3_bytes(rows, wide) + 3) / 4);
+        void* imgB = cv.take((split3_bytes(rows, wide) + 3) / 4);
+        float* t2 = cv.take(rows * w->hidden);
+        if (int rc = split3_rows_f32(h, hm, imgA, rows, w->d_in, st, asc(0))) return rc;
+        if (int rc = gemm_bf16x3(imgA, w->input_proj_weight3, w->input_proj_bias, nullptr, nullptr, imgB, rows, w->hidden, w->d_in, AVD_ACT_NONE,
+                                 terms, st, nullptr, 0, h2 ? asc(0) * wsc(0) : 1.f, h2 ? asc(1) : 1.f)) return rc;
+        void* cur = imgB;
+        void* nxt = imgA;
+        for (int j = 0; j < n; ++j) {
+            if (int rc = gemm_bf16x3(cur, w->shared_lin_weight3[j], w->shared_lin_bias[j], nullptr, t2, nullptr, rows, w->hidden, w->hidden,
+                                     AVD_ACT_NONE, terms, st, nullptr, 0, h2 ? asc(1 + j) * wsc(1 + j) : 1.f, 1.f)) return rc;
+            if (int rc = layernorm_act_split3_f32(t2, w->shared_ln_weight[j], w->shared_ln_bias[j], nxt, rows, w->hidden, w->ln_eps, w->act, st,
+                                                  asc(2 + j))) return rc;
+            void* t = cur; cur = nxt; nxt = t;
+        }
+        return gemm_bf16x3(cur, w->out_proj_weight3, w->out_proj_bias, nullptr, out, nullptr, rows, w->d_out, w->hidden, AVD_ACT_NONE, terms, st,
+                           nullptr, 0, h2 ? asc(1 + n) * wsc(1 + n) : 1.f, 1.f);
+    }
     float* t1 = cv.take(rows * w->hidden);
     float* t2 = cv.take(rows * w->hidden);
-    const RowMap rh{w->hidden, 0, 0}, ro{w->d_out, 0, 0};
     if (int rc = gemm_f32(h, hm, w->input_proj_weight, w->input_proj_bias, nullptr, rh, t1, rh, rows, w->hidden, w->d_in, AVD_ACT_NONE, st)) return rc;
     for (int j = 0; j < w->n_shared; ++j) {
         if (int rc = gemm_f32(t1, rh, w->shared_lin_weight[j], w->shared_lin_bias[j], nullptr, rh, t2, rh, rows, w->hidden, w->hidden, AVD_ACT_NONE, st)) return rc;

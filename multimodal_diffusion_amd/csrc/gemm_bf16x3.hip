@@ -37,7 +37,7 @@ namespace avd {
 // ---------------------------------------------------------------------------------------------------------
 // x [rows][K] (row stride ld) -> split3 image; rows in [rows, rows_pad) are written as zeros
 template <bool F16>   // F16: f16x2 image with scale s (avd_common.h)
-__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, int64_t ld, unsigned char* __restrict__ out,
+__global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, RowMap xm, unsigned char* __restrict__ out,
                                                      int64_t rows, int64_t rows_pad, int K, float s) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int per_row = K >> 3;
@@ -46,8 +46,9 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
     const int k = (int)(i % per_row) * 8;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (r < rows) {
-        *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(x + r * ld + k);
-        *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(x + r * ld + k + 4);
+        const float* xr = x + xm.off(r) + k;
+        *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(xr);
+        *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(xr + 4);
     }
     if constexpr (F16) store_split8_h2(out, r, k, K, v, s);
     else store_split8(out, r, k, K, v);
@@ -89,10 +90,69 @@ __global__ __launch_bounds__(256) void rmsnorm_split3_kernel(const float* __rest
     }
 }
 
+// LayerNorm + activation (noise_heads.py:141-147: Linear -> LayerNorm -> act) writing the operand image of its output; one wave
+// per row, same arithmetic as layernorm_act_kernel (rowops.hip)
+template <int NC, bool F16, bool GELU>   // GELU: the activation is known to be GELU (the shipped heads); otherwise read from `act`
+__global__ __launch_bounds__(256) void layernorm_act_split3_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta, unsigned char* __restrict__ out,
+                                                                   int64_t rows, int d, float eps, int act, float s) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * d;
+    float v[NC][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < d) {
+            *reinterpret_cast<f32x4*>(v[i]) = *reinterpret_cast<const f32x4*>(xr + c);
+            *reinterpret_cast<f32x4*>(v[i] + 4) = *reinterpret_cast<const f32x4*>(xr + c + 4);
+            sum += (v[i][0] + v[i][1] + v[i][2] + v[i][3]) + (v[i][4] + v[i][5] + v[i][6] + v[i][7]);
+        }
+    }
+    const float mean = wave_sum(sum) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < d) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float t = v[i][e] - mean;
+                q += t * t;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);      // biased variance, as torch.nn.LayerNorm
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {
+        const int c = (lane + 64 * i) * 8;
+        if (c < d) {
+            float o[8], gm[8], bt[8];
+            *reinterpret_cast<f32x4*>(gm) = *reinterpret_cast<const f32x4*>(gamma + c);
+            *reinterpret_cast<f32x4*>(gm + 4) = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+            *reinterpret_cast<f32x4*>(bt) = *reinterpret_cast<const f32x4*>(beta + c);
+            *reinterpret_cast<f32x4*>(bt + 4) = *reinterpret_cast<const f32x4*>(beta + c + 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = (v[i][e] - mean) * rstd * gm[e] + bt[e];
+                if (GELU || act == AVD_ACT_GELU) t = gelu_erf(t);
+                else if (act == AVD_ACT_SILU) t = silu(t);
+                else if (act == AVD_ACT_RELU) t = fmaxf(t, 0.f);
+                else if (act == AVD_ACT_LEAKY_RELU) t = t > 0.f ? t : 0.1f * t;
+                o[e] = t;
+            }
+            if constexpr (F16) store_split8_h2(out, row, c, d, o, s);
+            else store_split8(out, row, c, d, o);
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // GEMM
 // ---------------------------------------------------------------------------------------------------------
-enum { S3_EPI_BIAS = 0, S3_EPI_RES = 2, S3_EPI_GELU_SPLIT = 3, S3_EPI_QKV3 = 4 };
+enum { S3_EPI_BIAS = 0, S3_EPI_RES = 2, S3_EPI_GELU_SPLIT = 3, S3_EPI_QKV3 = 4, S3_EPI_SPLIT = 5 };   // 5: bias, image out, no activation
 
 struct S3Args {
     const unsigned char* A;   // split3 image of [M][K]
@@ -297,7 +357,7 @@ __device__ __forceinline__ void s3_epilogue(const S3Args& g, f32x16 (&acc)[4][2]
                     }
                 }
             }
-        } else if constexpr (EPI == S3_EPI_GELU_SPLIT) {
+        } else if constexpr (EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT) {
             // 8 lanes per row (8 columns each), 8 rows per wave instruction
             const int cr = lane >> 3, cc = (lane & 7) * 8;
             const int n = nbase + cc;
@@ -315,7 +375,10 @@ __device__ __forceinline__ void s3_epilogue(const S3Args& g, f32x16 (&acc)[4][2]
                     sk_add4(sp, m, n + 4, *reinterpret_cast<f32x4*>(v + 4));
                 }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = gelu_erf((F16 ? v[e] * g.ab_inv : v[e]) + bv[e]);
+                for (int e = 0; e < 8; ++e) {
+                    const float t = (F16 ? v[e] * g.ab_inv : v[e]) + bv[e];
+                    v[e] = EPI == S3_EPI_GELU_SPLIT ? gelu_erf(t) : t;
+                }
                 if (m < g.M) {
                     if constexpr (F16) store_split8_h2(g.C3, m, n, g.N, v, g.c_scale);
                     else store_split8(g.C3, m, n, g.N, v);
@@ -742,8 +805,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
 int64_t split3_bytes(int64_t rows, int K) { return ((rows + 255) / 256 * 256) * (int64_t)K * 6; }
 
 int split3_f32(const float* x, int64_t ld, void* out, int64_t rows, int K, hipStream_t st, float h2_scale) {
+    return split3_rows_f32(x, RowMap{ld, 0, 0}, out, rows, K, st, h2_scale);
+}
+
+int split3_rows_f32(const float* x, RowMap xm, void* out, int64_t rows, int K, hipStream_t st, float h2_scale) {
     AVD_REQUIRE(x && out, AVD_EINVAL, "split3: null pointer");
-    AVD_REQUIRE(rows > 0 && K > 0 && K % 16 == 0 && ld >= K && ld % 4 == 0, AVD_EUNSUPPORTED,
+    const int64_t ld = xm.ld;
+    AVD_REQUIRE(rows > 0 && K > 0 && K % 16 == 0 && ld >= K && ld % 4 == 0 && xm.stride % 4 == 0, AVD_EUNSUPPORTED,
                 "split3: need rows > 0, K %% 16 == 0, ld %% 4 == 0 (rows=%lld K=%d ld=%lld)", (long long)rows, K, (long long)ld);
     AVD_REQUIRE(aligned16(x) && aligned16(out), AVD_EUNSUPPORTED, "split3: pointers must be 16-byte aligned");
     const int64_t rows_pad = (rows + 255) / 256 * 256;
@@ -753,10 +821,10 @@ int split3_f32(const float* x, int64_t ld, void* out, int64_t rows, int K, hipSt
     ProfScope prof(tag, (double)rows * K * 10.0, st);
     AVD_REQUIRE(h2_scale >= 0.f && h2_scale < __builtin_inff(), AVD_EINVAL, "split3: f16x2 image scale must be positive and finite");
     if (h2_scale > 0.f)
-        hipLaunchKernelGGL(split3_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ld,
+        hipLaunchKernelGGL(split3_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, xm,
                            static_cast<unsigned char*>(out), rows, rows_pad, K, h2_scale);
     else
-        hipLaunchKernelGGL(split3_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, ld,
+        hipLaunchKernelGGL(split3_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, xm,
                            static_cast<unsigned char*>(out), rows, rows_pad, K, 0.f);
     AVD_CHECK_LAUNCH("split3");
     return AVD_OK;
@@ -786,6 +854,32 @@ int rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t ro
     return AVD_OK;
 }
 
+int layernorm_act_split3_f32(const float* x, const float* gamma, const float* beta, void* out, int64_t rows, int d, float eps, int act,
+                             hipStream_t st, float h2_scale) {
+    AVD_REQUIRE(x && gamma && beta && out, AVD_EINVAL, "layernorm_split3: null pointer");
+    AVD_REQUIRE(rows > 0 && d > 0 && d % 16 == 0 && d <= 2048, AVD_EUNSUPPORTED, "layernorm_split3: d=%d must be a multiple of 16, <= 2048", d);
+    AVD_REQUIRE(aligned16(x) && aligned16(out) && aligned16(gamma) && aligned16(beta), AVD_EUNSUPPORTED, "layernorm_split3: pointers must be 16-byte aligned");
+    AVD_REQUIRE(h2_scale >= 0.f && h2_scale < __builtin_inff(), AVD_EINVAL, "layernorm_split3: f16x2 image scale must be positive and finite");
+    static const int tag = prof_tag_id("layernorm_act_split3_kernel");
+    ProfScope prof(tag, 10.0 * (double)rows * d, st);
+    const unsigned grid = (unsigned)((rows + 3) / 4);
+    unsigned char* o = static_cast<unsigned char*>(out);
+#define AVD_LN3K(NC, F16, G) hipLaunchKernelGGL((layernorm_act_split3_kernel<NC, F16, G>), dim3(grid), dim3(256), 0, st, x, gamma, beta, o, rows, d, eps, act, h2_scale)
+#define AVD_LN3(NC)                                                                            \
+    if (h2_scale > 0.f) { if (act == AVD_ACT_GELU) AVD_LN3K(NC, true, true); else AVD_LN3K(NC, true, false); } \
+    else { if (act == AVD_ACT_GELU) AVD_LN3K(NC, false, true); else AVD_LN3K(NC, false, false); }
+    switch ((d + 511) / 512) {
+        case 1: AVD_LN3(1); break;
+        case 2: AVD_LN3(2); break;
+        case 3: AVD_LN3(3); break;
+        default: AVD_LN3(4); break;
+    }
+#undef AVD_LN3
+#undef AVD_LN3K
+    AVD_CHECK_LAUNCH("layernorm_split3");
+    return AVD_OK;
+}
+
 bool gemm_bf16x3_supported(int64_t M, int N, int K) { return M > 0 && N > 0 && N % 256 == 0 && K > 0 && K % 16 == 0; }
 
 // tile configuration: 0 = 256x256, 8 waves, one block per CU; 1 = 256x128, 4 waves, two blocks per CU.
@@ -795,7 +889,7 @@ static int s3_tile_for(int epi, int64_t M, int N) {
     if (forced == 0 || forced == 1) return forced;
     // C3 pipeline, ms per step over 8 launches: fc1+GELU->split3 2.75 (one block/CU) vs 2.48 (two); in_proj->qkv3 1.98 vs 1.94;
     // out_proj/fc2 + residual (16 launches) 3.07 vs 3.27
-    if (epi == S3_EPI_GELU_SPLIT || epi == S3_EPI_QKV3) return 1;
+    if (epi == S3_EPI_GELU_SPLIT || epi == S3_EPI_QKV3 || epi == S3_EPI_SPLIT) return 1;
     // 256x256 tiles only when they occupy most of the 256 CUs (C3: 106 x 2 = 212 blocks); at the 128x128 geometry
     // (8,512 rows) the 256x128 tiles run the whole step in 3.75 ms against 4.78
     return (M + 255) / 256 * (N / 256) >= 192 ? 0 : 1;
@@ -922,8 +1016,9 @@ int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* 
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, R, C,
              static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0, 0, 0, 0, 0.f, terms, 1.0f / ab_scale, c_scale, sk_ws, nullptr, 0, sk_floats};
     if (C3) {
-        AVD_REQUIRE(act == AVD_ACT_GELU && !R && bias, AVD_EUNSUPPORTED, "gemm_bf16x3: split3 output implies bias + GELU, no residual");
-        return launch_s3<S3_EPI_GELU_SPLIT>(a, st);
+        AVD_REQUIRE((act == AVD_ACT_GELU || act == AVD_ACT_NONE) && !R && bias, AVD_EUNSUPPORTED,
+                    "gemm_bf16x3: image output implies bias, act NONE or GELU, no residual");
+        return act == AVD_ACT_GELU ? launch_s3<S3_EPI_GELU_SPLIT>(a, st) : launch_s3<S3_EPI_SPLIT>(a, st);
     }
     AVD_REQUIRE(act == AVD_ACT_NONE, AVD_EUNSUPPORTED, "gemm_bf16x3: fp32 output supports act NONE only");
     if (R) return launch_s3<S3_EPI_RES>(a, st);

@@ -71,6 +71,10 @@ class MultiModalNoiseHead(nn.Module):
         self.out_proj = nn.ModuleDict({m: nn.Linear(self.hidden_dim, self.output_dims[m]) for m in self.modalities})
         self.apply(_init_linear)
         self._ws: Optional[torch.Tensor] = None
+        # matrix-pipe mode of the Linears, as MMDiT.matmul ("f32" | "bf16x3" | "bf16x3_strict" | "bf16" | "f16x2"); shapes the split
+        # kernels do not cover (d_out % 256, fewer than 6144 rows) stay on the fp32 MFMA kernels
+        self.matmul = "f32"
+        self._images: dict = {}
 
     def get_output_dim(self, modality: str) -> int:
         return int(self.output_dims[modality])
@@ -85,7 +89,50 @@ class MultiModalNoiseHead(nn.Module):
             blocks += list(self.spec[m])
         return blocks
 
-    def weight_table(self, m: str):
+    def _image(self, name: str, p: torch.Tensor, h2_scale: float) -> torch.Tensor:
+        """Operand image of a weight for the split matmul modes (cached per parameter version, refreshed in place)."""
+        from . import functional as Fn
+        key = (p.data_ptr(), p._version, tuple(p.shape), float(h2_scale))
+        hit = self._images.get(name)
+        if hit is None or hit[0] != key:
+            old = hit[1] if hit is not None and hit[0][2] == key[2] and hit[1].device == p.device else None
+            img = Fn.split_f16x2(p.detach(), h2_scale, out=old)[0] if h2_scale > 0 else Fn.split3(p.detach(), out=old)
+            hit = (key, img)
+            self._images[name] = hit
+        return hit[1]
+
+    def _f16x2_scales(self, m: str, blocks, in_bound: float, in_norm: float):
+        """Power-of-two scales of the f16x2 images of modality m's path, from bounds that hold for every input row x with
+        |x_i| <= in_bound, ||x||_2 <= in_norm:  input_proj output  |o_n| <= ||x|| ||w_n|| + |b_n|,  ||o|| <= ||x|| sigma_max(W) + ||b||;
+        LayerNorm output  |y_i| <= sqrt(hidden) |gamma_i| + |beta_i|  (every activation here satisfies |act(y)| <= |y|)."""
+        from . import functional as Fn
+        ps = [self.input_proj[m].weight, self.input_proj[m].bias] + [q for b in blocks for q in (b[0].weight, b[1].weight, b[1].bias)] + \
+            [self.out_proj[m].weight]
+        key = (tuple((q.data_ptr(), q._version) for q in ps), float(in_bound), float(in_norm))
+        hit = self._images.get(f"{m}.f16x2")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                wi, bi = self.input_proj[m].weight, self.input_proj[m].bias
+                vals = [wi.abs().max(), wi.norm(dim=1).max(), bi.abs().max()]
+                for b in blocks:
+                    vals += [b[0].weight.abs().max(), b[1].weight.abs().max(), b[1].bias.abs().max()]
+                vals.append(self.out_proj[m].weight.abs().max())
+                q = torch.stack([v.double() for v in vals]).cpu().tolist()
+            w_in, wn_in, b_in = q[0], q[1], q[2]
+            w_sc = [Fn.f16x2_scale(w_in)] + [Fn.f16x2_scale(q[3 + 3 * j]) for j in range(len(blocks))] + [Fn.f16x2_scale(q[-1])]
+            a_sc = [Fn.f16x2_scale(in_bound), Fn.f16x2_scale(in_norm * wn_in + b_in)]
+            a_sc += [Fn.f16x2_scale(self.hidden_dim ** 0.5 * q[4 + 3 * j] + q[5 + 3 * j]) for j in range(len(blocks))]
+            hit = (key, w_sc + a_sc)
+            self._images[f"{m}.f16x2"] = hit
+        return hit[1]
+
+    def weight_table(self, m: str, matmul: Optional[str] = None, in_bound: Optional[float] = None, in_norm: Optional[float] = None):
+        """Pointer table of modality m's path.  matmul (default: self.matmul) other than "f32" adds the operand images of the split
+        matmul modes; "f16x2" also needs bounds on the rows the head will see (in_bound >= |x_i|, in_norm >= ||x||_2) — the
+        engine derives them from the core's final norm."""
+        matmul = self.matmul if matmul is None else matmul
+        if matmul not in L.MATMUL_TERMS:
+            raise ValueError(f"matmul must be one of {sorted(L.MATMUL_TERMS)}, got {matmul!r}")
         blocks = self._trunk(m)
         n = len(blocks)
         keep = []
@@ -95,7 +142,7 @@ class MultiModalNoiseHead(nn.Module):
             keep.append(t)
             return t.data_ptr()
 
-        arrs = [(C.c_void_p * max(n, 1))() for _ in range(4)]
+        arrs = [(C.c_void_p * max(n, 1))() for _ in range(5)]
         for j, blk in enumerate(blocks):
             arrs[0][j], arrs[1][j] = dp(blk[0].weight), dp(blk[0].bias)
             arrs[2][j], arrs[3][j] = dp(blk[1].weight), dp(blk[1].bias)
@@ -105,6 +152,26 @@ class MultiModalNoiseHead(nn.Module):
                            C.cast(arrs[0], C.POINTER(C.c_void_p)), C.cast(arrs[1], C.POINTER(C.c_void_p)),
                            C.cast(arrs[2], C.POINTER(C.c_void_p)), C.cast(arrs[3], C.POINTER(C.c_void_p)),
                            dp(self.out_proj[m].weight), dp(self.out_proj[m].bias))
+        terms = L.MATMUL_TERMS[matmul]
+        shapes_ok = self.input_dims[m] % 16 == 0 and self.hidden_dim % 256 == 0 and self.output_dims[m] % 256 == 0
+        if terms and shapes_ok:
+            sc = None
+            if matmul == "f16x2":
+                if in_bound is None or in_norm is None:
+                    raise ValueError("matmul='f16x2' needs in_bound / in_norm (bounds on the head's input rows)")
+                sc = self._f16x2_scales(m, blocks, in_bound, in_norm)
+                scales = (C.c_float * len(sc))(*sc)
+                arrs.append(scales)                 # host array: kept alive with the table, not a device tensor
+                hw.f16x2_scale = C.cast(scales, C.POINTER(C.c_float))
+            ws = [self.input_proj[m].weight] + [b[0].weight for b in blocks] + [self.out_proj[m].weight]
+            imgs = [self._image(f"{m}.{i}", w, sc[i] if sc else 0.0) for i, w in enumerate(ws)]
+            keep += imgs
+            hw.split_terms = terms
+            hw.input_proj_weight3 = imgs[0].data_ptr()
+            for j in range(n):
+                arrs[4][j] = imgs[1 + j].data_ptr()
+            hw.shared_lin_weight3 = C.cast(arrs[4], C.POINTER(C.c_void_p))
+            hw.out_proj_weight3 = imgs[-1].data_ptr()
         return hw, (arrs, keep)
 
     def forward(self, inputs: Dict[str, torch.Tensor], return_dict: bool = True
@@ -120,7 +187,11 @@ class MultiModalNoiseHead(nn.Module):
             if d_in != self.input_dims[m]:
                 raise RuntimeError(f"{m}: expected last dim {self.input_dims[m]}, got {d_in}")
             rows = x.numel() // d_in
-            hw, keep = self.weight_table(m)
+            if self.matmul == "f16x2":      # standalone call: bound the rows from the data (one device sync)
+                amax = float(x.abs().max())
+                hw, keep = self.weight_table(m, in_bound=amax, in_norm=amax * d_in ** 0.5)
+            else:
+                hw, keep = self.weight_table(m)
             need = L.lib().avd_head_workspace_bytes(C.byref(hw), rows)
             if self._ws is None or self._ws.numel() < need or self._ws.device != x.device:
                 self._ws = torch.empty(max(need, 1), dtype=torch.uint8, device=x.device)

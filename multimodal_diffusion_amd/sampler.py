@@ -185,7 +185,18 @@ class DenoiseEngine:
             self._core_tab, self._keep_core = core.weight_table()
         finally:
             core.matmul, core.attn = prev
-        self._head_tab, self._keep_head = head.weight_table(self.target)
+        # the head follows the engine's mode; its input rows are the core's final-norm output, bounded by that norm's parameters:
+        # RMSNorm |y_i| <= sqrt(d) |g_i|, ||y|| <= sqrt(d) max|g|; LayerNorm adds |b_i| resp. ||b||
+        hb = hn = None
+        if self.matmul == "f16x2":
+            fn_ = core.final_norm
+            with torch.no_grad():
+                g = fn_.weight if hasattr(fn_, "bias") and fn_.bias is not None else fn_.scale
+                gmax = float(g.abs().max()) * core.cfg.d_model ** 0.5
+                bias = getattr(fn_, "bias", None)
+                hb = gmax + (float(bias.abs().max()) if bias is not None else 0.0)
+                hn = gmax + (float(bias.norm()) if bias is not None else 0.0)
+        self._head_tab, self._keep_head = head.weight_table(self.target, matmul=self.matmul, in_bound=hb, in_norm=hn)
         self._aw = L.dev_f32(self.adapt_t.proj.weight.detach(), "adapter weight")
         self._ab = L.dev_f32(self.adapt_t.proj.bias.detach(), "adapter bias")
         if self._aw.device != self.device:

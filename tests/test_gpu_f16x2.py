@@ -331,3 +331,31 @@ def test_f16x2_engine_follows_weight_updates(dev, full):
     y1, r1 = core(x), ref_core(x)
     assert torch.isfinite(y1).all() and not torch.equal(y0, y1)
     assert rel_err(y1.cpu(), r1.cpu().double()) < 1e-4
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+@pytest.mark.parametrize("act", ["gelu", "leaky_relu"])
+def test_head_split_modes_vs_oracle(dev, full, mode, act):
+    """MultiModalNoiseHead with its Linears on the split-operand kernels (input rows -> image, bias-only image epilogue, LayerNorm +
+    activation -> image): same tolerance as the fp32 path, 6,736 rows; the audio path (d_out = 32) stays on the fp32 kernels."""
+    import multimodal_diffusion_amd as A
+    ws, _ = full
+    heads = {}
+    for m in (mode, "f32"):
+        head = A.MultiModalNoiseHead({"video": 512, "audio": 512}, {"video": 256, "audio": 32}, hidden_dim=512, activation=act).eval()
+        head.load_state_dict(ws["head"], strict=True)
+        head.to(dev)
+        head.matmul = m
+        heads[m] = head
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(16, 421, 512, generator=g) * 1.7
+    x[3] *= 30.0
+    out = heads[mode]({"video": x.to(dev), "audio": x[:2].to(dev)})
+    out32 = heads["f32"]({"video": x.to(dev), "audio": x[:2].to(dev)})
+    assert not torch.equal(out["video"], out32["video"]), "split path did not run"
+    assert torch.equal(out["audio"], out32["audio"])
+    hw = {k: v.double() for k, v in ws["head"].items()}
+    ref = R.noise_head(x[:4].double(), hw, "video", activation=act)
+    e, e32 = rel_err(out["video"][:4].cpu(), ref), rel_err(out32["video"][:4].cpu(), ref)
+    print(f"head {mode} {act}: err {e:.3e} (fp32-MFMA {e32:.3e})")
+    assert e < TOL and e < 3.0 * e32 + 1e-7, (e, e32)
