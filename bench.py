@@ -11,10 +11,16 @@ mvp.yaml model dims d=512 L=8 H=8), fp32 results, synthetic inputs, random-init 
 Weak scaling: every rank steps its own 32 samples; the only collective is one RCCL broadcast of the
 conditioning latents before the loop.  Rank 0 prints ONE JSON line.
 
-Matrix-pipe modes (--matmul): "bf16x3" (default since round 2: every fp32 operand split exactly into three bf16 planes, six
-product terms, fp32 accumulation — the error of an fp32 FMA chain, tests/test_gpu_parity.py bf16x3 suites), "f32" (fp32 MFMA,
-the round-1 default, measured in the same run as "alt"), "bf16x3_strict" (nine terms), "bf16" (one term: reduced precision,
-BASELINE config C2 — never the default, its error is reported, not gated).
+Matrix-pipe modes (--matmul), all with fp32 accumulation and fp32 results:
+  "f16x2"  (default) every operand of the block projections, the attention and the noise head held as two scaled fp16 planes
+           (22 significant bits), three product terms; measured error against the fp32 CPU oracle <= the fp32-MFMA path's on
+           every GEMM / attention / step test (tests/test_gpu_f16x2.py), scales bounded from the weights so fp16 cannot overflow;
+  "bf16x3" every fp32 operand split EXACTLY into three bf16 planes, six product terms (tests/test_gpu_parity.py bf16x3 suites);
+  "f32"    fp32 MFMA everywhere (the round-1 default);  "bf16x3_strict" nine terms.
+  These three are measured in the same run and reported under "alt".
+  "bf16"   one bf16 plane: reduced precision, BASELINE config C2 — never the default, its error is reported, not gated.
+The f16x2 engine runs the cond / null CFG halves as two kernel chains on two HIP streams by default (bit-identical results,
+--split-streams 0 turns it off); the per-kernel roofline pass always runs single-stream, where a kernel's duration is its own.
 """
 from __future__ import annotations
 
@@ -144,10 +150,11 @@ def parse_args(argv=None):
     ap.add_argument("--sampler-steps", type=int, default=50)
     ap.add_argument("--guidance", type=float, default=3.5)
     ap.add_argument("--graph", action="store_true", help="replay a captured 2-step HIP graph instead of eager launches")
-    ap.add_argument("--split-streams", type=int, default=0, help="run the cond/null halves on two HIP streams")
-    ap.add_argument("--matmul", default="bf16x3", choices=sorted(MODE_TERMS),
-                    help="bf16x3 (default): block projections + attention on the bf16 matrix pipe with exactly split fp32 "
-                         "operands (fp32-level error); f32: fp32 MFMA everywhere; bf16x3_strict: all nine product terms; "
+    ap.add_argument("--split-streams", type=int, default=-1,
+                    help="run the cond/null halves on two HIP streams: 1 / 0; -1 (default) = the engine's rule (on for f16x2 at >= 6144 rows per half)")
+    ap.add_argument("--matmul", default="f16x2", choices=sorted(MODE_TERMS),
+                    help="f16x2 (default): two scaled fp16 planes per operand, three product terms; bf16x3: three bf16 planes, six terms "
+                         "(exact operand split); f32: fp32 MFMA everywhere; bf16x3_strict: all nine product terms; "
                          "bf16: plain bf16 operands (reduced precision, reported error)")
     ap.add_argument("--attn", default="default", choices=["default", "fp8"],
                     help="fp8: e4m3 QK^T / PV in the attention (reduced precision, BASELINE C5; needs a split matmul mode; never the default)")
@@ -242,11 +249,13 @@ def main():
     mods, tdim = build_modules(dev)
     av, aa, core, head = mods
 
-    def make_engine(mode):
+    def make_engine(mode, split="arg"):
+        if split == "arg":
+            split = None if args.split_streams < 0 else bool(args.split_streams)
         e = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=tdim, target="video",
                             latent_shape=lat, prompt_tokens=na, alpha_bar=abar, guidance=args.guidance,
-                            split_streams=bool(args.split_streams), matmul=mode,
-                            attn=args.attn if mode != "f32" else "default")
+                            split_streams=split, matmul=mode,
+                            attn=args.attn if mode not in ("f32", "f16x2") else "default")
         e.set_prompt(z_a0)
         e.begin(sched)
         return e
@@ -314,7 +323,8 @@ def main():
             "config": {"workload": f"C3: {size}x{size} audio->video CFG denoising step (cond+null MMDiT d512 L8 H8 + noise head + "
                                    f"DDIM), {nv}+{na} tokens, batch {B} per GPU, DDIM {S} steps, guidance {args.guidance}",
                        "global_batch": B * world, "tokens": nv + na, "sampler_steps": S,
-                       "parallelism": f"dp{world}", "launch": "hipgraph" if args.graph else "eager", "matmul": args.matmul, "attn": args.attn},
+                       "parallelism": f"dp{world}", "launch": "hipgraph" if args.graph else "eager", "matmul": args.matmul, "attn": args.attn,
+                       "cfg_halves": "two HIP streams" if eng._split_streams else "one stacked 2B batch, one stream"},
             "per_gpu_steps_per_s": per_gpu,
             "value_is": "sum over ranks of batch-32 steps/s (weak scaling); per_gpu_steps_per_s is the global-batch step rate",
             "sample_steps_per_s": world * B * per_gpu,
@@ -324,15 +334,35 @@ def main():
 
     # ---- roofline of the dominant kernel: per-launch HIP events on the launch stream, separate instrumented pass
     if rank == 0 and not args.no_roofline:
+        # always single-stream: with the CFG halves on two streams two kernels share the chip and an event pair around one launch
+        # times both; the kernels are the same ones, launched on the stacked 2B batch
+        eng_r = make_engine(args.matmul, split=False) if eng._split_streams else eng
+        zr, zr2 = z0.clone(), torch.empty_like(z0)
+
+        def run_r(k):
+            nonlocal zr, zr2
+            for i in range(k):
+                if i % S == 0:
+                    eng_r.rewind()
+                    zr.copy_(z0)
+                eng_r.advance(zr, zr2)
+                zr, zr2 = zr2, zr
+
+        run_r(2)
+        torch.cuda.synchronize()
         L.prof_enable(True)
-        state["i"] = 0
-        saved = graph
-        graph = None
-        run_steps(5)
-        graph = saved
+        run_r(5)
         torch.cuda.synchronize()
         L.prof_enable(False)
         out["roofline"], out["kernels"] = roofline_of(L.prof_report(), args.matmul, 5)
+        out["roofline"]["pass"] = "5 instrumented single-stream steps after the timed region (HIP events around every launch, on its stream)"
+        if eng_r is not eng:
+            torch.cuda.synchronize()
+            r0 = time.perf_counter()
+            run_r(args.steps)
+            torch.cuda.synchronize()
+            out["single_stream_steps_per_s"] = args.steps / (time.perf_counter() - r0)
+            del eng_r
 
     # ---- CPU baseline: the oracle (a from-scratch torch port of the reference step) on this host's cores
     tn = tp = cpu_ref = None
@@ -364,7 +394,7 @@ def main():
     # ---- the other matmul modes, measured the same way right after (N=1 only; never part of `value`)
     if rank == 0 and world == 1 and not args.no_alt:
         alts = []
-        for other in ("f32", "bf16x3", "bf16x3_strict", "f16x2"):
+        for other in ("f32", "bf16x3", "bf16x3_strict", "f16x2"):      # each with its engine's default stream layout
             if other == args.matmul:
                 continue
             eng2 = make_engine(other)

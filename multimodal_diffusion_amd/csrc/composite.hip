@@ -451,7 +451,8 @@ static int plan_step(const avd_step_desc* s, StepPlan& p) {
     // one slice per CFG half (they may run on two streams), or the stacked 2B batch in one piece, whichever is larger
     const int64_t halves = 2 * core_ws_bytes(s->core, e.B, p.N), whole = core_ws_bytes(s->core, 2 * e.B, p.N);
     p.core = halves > whole ? halves : whole;
-    p.head = 2 * head_ws_bytes(s->head, p.rows / 2);
+    const int64_t head_halves = 2 * head_ws_bytes(s->head, p.rows / 2), head_whole = head_ws_bytes(s->head, p.rows);
+    p.head = head_halves > head_whole ? head_halves : head_whole;
     p.eps = align_up(p.rows * p.D * 4);
     p.ss = align_up((int64_t)2 * e.B * p.N * 4);
     p.total = p.x2 + p.tok + p.core + p.head + p.ss + p.eps;      // eps stays last (DenoiseEngine.eps_tokens reads the tail)

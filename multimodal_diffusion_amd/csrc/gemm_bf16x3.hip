@@ -175,7 +175,20 @@ struct S3Args {
     unsigned int* sk_flags;
     int ntiles;
     int64_t sk_floats;          // host only: floats available at sk_partial
+#ifdef AVD_S3_STAMPS            // diagnostic build only (tools/micro/s3_stamps.py), never in the product library
+    unsigned long long* dbg;
+#endif
 };
+
+#ifdef AVD_S3_STAMPS
+// wave 0 of every block sums, over its K loop, the core-clock cycles between the loop top, the DMA wait, the barrier, the DMA
+// issue and the end of the step; plus stamps at block entry, loop start, loop end, block end
+#define S3_T() __builtin_amdgcn_s_memtime()
+#define S3_DBG(i, v) do { if (threadIdx.x == 0) g.dbg[(size_t)blockIdx.x * 16 + (i)] = (v); } while (0)
+#else
+#define S3_T() 0ull
+#define S3_DBG(i, v) do { } while (0)
+#endif
 
 // flags of the stream-K launches: zero at module load, every launch leaves its slot zeroed (each flag has one consumer)
 constexpr int S3_SK_SLOTS = 32, S3_SK_FLAGS = 512;
@@ -427,21 +440,41 @@ template <> struct S3Terms<1> { static constexpr int N = 1; static constexpr int
 // 3: f16x2 images (two fp16 planes h, l with 11 significant bits each): hl, lh, hh; ll (2^-22 relative) is dropped
 template <> struct S3Terms<3> { static constexpr int N = 3; static constexpr int PA[3] = {0, 1, 0}; static constexpr int PB[3] = {1, 0, 0}; };
 
-constexpr int S3_BM = 256, S3_BN = 256, S3_NST = 3;
-constexpr int S3_STAGE = (S3_BM + S3_BN) * 96;          // 48 KiB
-constexpr int S3_LDS = S3_NST * S3_STAGE;                // 144 KiB (the epilogue slabs, 8 x 64 x 68 floats, fit inside)
+// LDS stage = the planes a mode moves, compact: [region (128 rows)][plane][128 rows][32 B]; region stride = planes x 4 KiB.
+// The global -> LDS transport, not the matrix pipe, paces these loops (~25 GB/s per CU per tile in flight), so
+// the modes that move fewer planes spend the LDS they save on a deeper ring: more tiles in flight per CU.
+constexpr int S3_BM = 256, S3_BN = 256;
+__host__ __device__ constexpr int s3_nst(int terms) { return terms == 3 ? 4 : terms == 1 ? 6 : 3; }
+__host__ __device__ constexpr int s3_stage(int terms) { return (S3_BM + S3_BN) / 128 * s3_planes(terms) * S3_PLANE; }   // 48 / 32 / 16 KiB
+constexpr int S3_SLABS = 8 * 64 * 68 * 4;                // epilogue slabs of the 8 waves, reuse the stage area
+__host__ __device__ constexpr int s3_lds(int terms) {
+    return s3_nst(terms) * s3_stage(terms) > S3_SLABS ? s3_nst(terms) * s3_stage(terms) : S3_SLABS;
+}
+
+// wait until at most n of this wave's DMA pieces are still in flight (n is wave-uniform, 0 <= n <= MAXN)
+template <int MAXN, int STEP>
+__device__ __forceinline__ void wait_vm_tiles(int tiles) {
+    if constexpr (MAXN == 0) { wait_vm<0>(); }
+    else {
+        if (tiles >= MAXN) wait_vm<MAXN * STEP>();
+        else wait_vm_tiles<MAXN - 1, STEP>(tiles);
+    }
+}
 
 template <int EPI, int TERMS, bool SK>
 __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
     constexpr int BM = S3_BM, BN = S3_BN, WM = 128, WN = 64;
-    constexpr int TM = 4, TN = 2, NST = S3_NST, STAGE = S3_STAGE;
+    constexpr int TM = 4, TN = 2, NST = s3_nst(TERMS), STAGE = s3_stage(TERMS);
     constexpr int NPL = s3_planes(TERMS);                 // planes moved and read
+    constexpr int RCH = NPL * S3_PLANE;                   // one 128-row region of a stage
     constexpr bool F16 = TERMS == 3;
     constexpr int PPR = 4 * NPL;                          // one-KiB pieces per 128-row region per stage
     constexpr int PPW = 4 * PPR / 8;                      // 4 regions per stage / 8 waves
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
     constexpr bool sk = SK;
+    [[maybe_unused]] const unsigned long long t_entry = S3_T();
+    [[maybe_unused]] unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_body = 0;
     int bm, bn;
     SkRange skr{};
     int sk_s = 0, sk_phase = 0;
@@ -472,12 +505,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = wm * WM + i * 32 + l31;
-        a_off[i] = (r >> 7) * S3_CHUNK + (r & 127) * 32 + ((hi ^ ((r >> 3) & 1)) << 4);
+        a_off[i] = (r >> 7) * RCH + (r & 127) * 32 + ((hi ^ ((r >> 3) & 1)) << 4);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int r = BM + wn * WN + j * 32 + l31;
-        b_off[j] = (r >> 7) * S3_CHUNK + (r & 127) * 32 + ((hi ^ ((r >> 3) & 1)) << 4);
+        b_off[j] = (r >> 7) * RCH + (r & 127) * 32 + ((hi ^ ((r >> 3) & 1)) << 4);
     }
     using TT = S3Terms<TERMS>;
     constexpr int CLD = WN + 4;
@@ -500,7 +533,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
         for (int i = 0; i < PPW; ++i) {
             const int q = wave * PPW + i;
             const int region = q / PPR, within = (q % PPR) * 1024;
-            dst_off[i] = region * S3_CHUNK + within;
+            dst_off[i] = region * RCH + within;
             if (region < 2) {
                 int rt = bm * 2 + region;
                 rt = rt < nrtA ? rt : nrtA - 1;
@@ -525,13 +558,20 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
         const int nk = k1 - k0;
-        issue(0, 0);
-        if (nk > 1) issue(1, 1);
+#pragma unroll
+        for (int t = 0; t < NST - 1; ++t)
+            if (t < nk) issue(t, t);
         int cur = 0, nxt = NST - 1;
+        [[maybe_unused]] const unsigned long long t_loop = S3_T();
         for (int kt = 0; kt < nk; ++kt) {
-            if (kt + NST - 1 <= nk) wait_vm<(NST - 2) * PPW>(); else wait_vm<0>();
+            [[maybe_unused]] const unsigned long long t0 = S3_T();
+            // tile kt must have landed; the (up to NST - 2) tiles issued after it may stay in flight
+            wait_vm_tiles<NST - 2, PPW>((kt + NST - 1 <= nk ? kt + NST - 1 : nk) - kt - 1);
+            [[maybe_unused]] const unsigned long long t1 = S3_T();
             asm volatile("s_barrier" ::: "memory");   // no fence: a fence would drain vmcnt and with it the tiles in flight
+            [[maybe_unused]] const unsigned long long t2 = S3_T();
             if (kt + NST - 1 < nk) issue(kt + NST - 1, nxt);
+            [[maybe_unused]] const unsigned long long t3 = S3_T();
             const unsigned char* st = smem3 + cur * STAGE;
             cur = cur + 1 == NST ? 0 : cur + 1;
             nxt = nxt + 1 == NST ? 0 : nxt + 1;
@@ -551,7 +591,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = mma16<F16>(af[i][TT::PA[t]], bf[j][TT::PB[t]], acc[i][j]);
+#ifdef AVD_S3_STAMPS
+            asm volatile("s_nop 0" ::: "memory");
+            c_wait += t1 - t0; c_bar += t2 - t1; c_issue += t3 - t2; c_body += S3_T() - t3;
+#endif
         }
+        [[maybe_unused]] const unsigned long long t_end = S3_T();
         __syncthreads();
 
         float* slab = reinterpret_cast<float*>(smem3) + wave * 64 * CLD;
@@ -577,6 +622,12 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
             }
         }
         s3_epilogue<EPI, F16>(g, acc, slab, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane, sp);
+#ifdef AVD_S3_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        S3_DBG(0, t_entry); S3_DBG(1, t_loop); S3_DBG(2, t_end); S3_DBG(3, S3_T());
+        S3_DBG(4, c_wait); S3_DBG(5, c_bar); S3_DBG(6, c_issue); S3_DBG(7, c_body); S3_DBG(8, (unsigned long long)nk);
+        S3_DBG(9, __builtin_amdgcn_s_memrealtime());
+#endif
         if (!sk) break;
         __syncthreads();      // slabs drained before the next segment's DMA lands on them
     }
@@ -588,20 +639,28 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
 // tile kt+1 are spread between them and the DMA of tile kt+2 is in flight.  The term order is chosen so that every operand
 // plane is dead before its successor is read into the same registers.
 constexpr int S3B_BM = 256, S3B_BN = 128;
-constexpr int S3B_STAGE = (S3B_BM + S3B_BN) * 96;        // 36 KiB
-constexpr int S3B_LDS = 2 * S3B_STAGE;                    // 72 KiB (4 epilogue slabs of 64 x 68 floats fit inside)
+// two blocks per CU: <= 80 KiB each.  Three planes: two 36 KiB stages; two planes (f16x2): three 24 KiB stages; one: four 12 KiB.
+__host__ __device__ constexpr int s3b_nst(int terms) { return terms == 3 ? 3 : terms == 1 ? 4 : 2; }
+__host__ __device__ constexpr int s3b_stage(int terms) { return (S3B_BM + S3B_BN) / 128 * s3_planes(terms) * S3_PLANE; }
+constexpr int S3B_SLABS = 4 * 64 * 68 * 4;               // epilogue slabs of the 4 waves
+__host__ __device__ constexpr int s3b_lds(int terms) {
+    return s3b_nst(terms) * s3b_stage(terms) > S3B_SLABS ? s3b_nst(terms) * s3b_stage(terms) : S3B_SLABS;
+}
 
 template <int EPI, int TERMS, bool SK>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
     constexpr int BM = S3B_BM, BN = S3B_BN, WM = 128, WN = 64;
-    constexpr int TM = 4, TN = 2, STAGE = S3B_STAGE;
+    constexpr int TM = 4, TN = 2, NST = s3b_nst(TERMS), STAGE = s3b_stage(TERMS);
     constexpr int NPL = s3_planes(TERMS);
     constexpr bool F16 = TERMS == 3;
     constexpr int PPR = 4 * NPL;                          // one-KiB pieces per 128-row region per stage
-    constexpr int PPW = 3 * PPR / 4;                      // 3 regions per stage / 4 waves
+    constexpr int PPW = 3 * PPR / 4;
+    constexpr int RCH = NPL * S3_PLANE;                   // one 128-row region of a stage                      // 3 regions per stage / 4 waves
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
     constexpr bool sk = SK;
+    [[maybe_unused]] const unsigned long long t_entry = S3_T();
+    [[maybe_unused]] unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_body = 0;
     int bm, bn;
     SkRange skr{};
     int sk_s = 0, sk_phase = 0;
@@ -632,12 +691,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = wm * WM + i * 32 + l31;
-        a_off[i] = (r >> 7) * S3_CHUNK + (r & 127) * 32 + ((hi ^ ((r >> 3) & 1)) << 4);
+        a_off[i] = (r >> 7) * RCH + (r & 127) * 32 + ((hi ^ ((r >> 3) & 1)) << 4);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int r = BM + wn * WN + j * 32 + l31;
-        b_off[j] = (r >> 7) * S3_CHUNK + (r & 127) * 32 + ((hi ^ ((r >> 3) & 1)) << 4);
+        b_off[j] = (r >> 7) * RCH + (r & 127) * 32 + ((hi ^ ((r >> 3) & 1)) << 4);
     }
 #define S3_LDA(dst, st, p) _Pragma("unroll") for (int i = 0; i < TM; ++i) dst[i] = *reinterpret_cast<const bf16x8*>((st) + a_off[i] + S3_PLANE * (p))
 #define S3_LDB(dst, st, p) _Pragma("unroll") for (int j = 0; j < TN; ++j) dst[j] = *reinterpret_cast<const bf16x8*>((st) + b_off[j] + S3_PLANE * (p))
@@ -661,7 +720,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
     for (int i = 0; i < PPW; ++i) {
         const int q = wave * PPW + i;
         const int region = q / PPR, within = (q % PPR) * 1024;
-        dst_off[i] = region * S3_CHUNK + within;
+        dst_off[i] = region * RCH + within;
         if (region < 2) {
             int rt = bm * 2 + region;
             rt = rt < nrtA ? rt : nrtA - 1;
@@ -685,11 +744,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ring of NST stages: while the MFMAs of tile kt run on fragments held in registers, the fragments of tile kt+1 are read from
+    // its stage and tiles kt+2 .. kt+NST-1 are in flight (the stage of tile kt is refilled with tile kt+NST at the top)
     const int nk = k1 - k0;
     issue(0, 0);
     wait_vm<0>();
     asm volatile("s_barrier" ::: "memory");
-    if (nk > 1) issue(1, 1);
+#pragma unroll
+    for (int t = 1; t < NST; ++t)
+        if (t < nk) issue(t, t);
     bf16x8 ah[TM], am[TM], al[TM], bh[TN], bmm[TN], bl[TN];
     S3_LDA(ah, smem3, 0);
     S3_LDB(bh, smem3, 0);
@@ -702,12 +765,21 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
         S3_LDB(bl, smem3, 2);
     }
 
+    int st_cur = 0, st_nx = 1 % NST;
+    [[maybe_unused]] const unsigned long long t_loop = S3_T();
     for (int kt = 0; kt < nk; ++kt) {
-        // tile kt+1 has landed in stage (kt+1)&1; stage kt&1 (whose fragments are in registers) is free for tile kt+2
-        wait_vm<0>();
+        [[maybe_unused]] const unsigned long long t0 = S3_T();
+        // tile kt+1 must have landed (tiles kt+2 .. may stay in flight); after the barrier every wave holds tile kt's fragments
+        // in registers, so its stage is free for tile kt+NST
+        wait_vm_tiles<NST - 2, PPW>((kt + NST <= nk ? kt + NST : nk) - kt - 2);
+        [[maybe_unused]] const unsigned long long t1 = S3_T();
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + 2 < nk) issue(kt + 2, kt & 1);
-        const unsigned char* nx = smem3 + ((kt + 1) & 1) * STAGE;
+        [[maybe_unused]] const unsigned long long t2 = S3_T();
+        if (kt + NST < nk) issue(kt + NST, st_cur);
+        [[maybe_unused]] const unsigned long long t3 = S3_T();
+        const unsigned char* nx = smem3 + st_nx * STAGE;
+        st_cur = st_nx;
+        st_nx = st_nx + 1 == NST ? 0 : st_nx + 1;
         bf16x8 ah_n[TM], bl_n[TN];
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (TERMS == 1) {
@@ -767,7 +839,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
         }
 #pragma unroll
         for (int i = 0; i < TM; ++i) ah[i] = ah_n[i];
+#ifdef AVD_S3_STAMPS
+        asm volatile("s_nop 0" ::: "memory");
+        c_wait += t1 - t0; c_bar += t2 - t1; c_issue += t3 - t2; c_body += S3_T() - t3;
+#endif
     }
+    [[maybe_unused]] const unsigned long long t_end = S3_T();
     __syncthreads();
     constexpr int CLD = WN + 4;
     float* slab = reinterpret_cast<float*>(smem3) + wave * 64 * CLD;
@@ -791,6 +868,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
         }
     }
     s3_epilogue<EPI, F16>(g, acc, slab, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane, sp);
+#ifdef AVD_S3_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    S3_DBG(0, t_entry); S3_DBG(1, t_loop); S3_DBG(2, t_end); S3_DBG(3, S3_T());
+    S3_DBG(4, c_wait); S3_DBG(5, c_bar); S3_DBG(6, c_issue); S3_DBG(7, c_body); S3_DBG(8, (unsigned long long)nk);
+    S3_DBG(9, __builtin_amdgcn_s_memrealtime());
+#endif
     if (!sk) break;
     __syncthreads();      // slabs drained before the next segment's DMA lands on them
     }   // segments
@@ -896,6 +979,10 @@ static int s3_tile_for(int epi, int64_t M, int N) {
 }
 
 int g_s3_streamk = getenv("AVD_S3_STREAMK") ? atoi(getenv("AVD_S3_STREAMK")) : 0;   // measured slower than plain tiling: off
+#ifdef AVD_S3_STAMPS
+unsigned long long* g_s3_dbg = nullptr;
+extern "C" void lab_set_dbg(unsigned long long* p) { g_s3_dbg = p; }
+#endif
 
 static int sk_cu_count() {                 // CUs of the current device (looked up once per device)
     static std::atomic<int> cache[64];
@@ -928,12 +1015,15 @@ static int sk_flags_base(unsigned int** out) {
 template <int EPI, int TERMS>
 static int launch_s3t(const S3Args& a, hipStream_t st) {
     const int tile = s3_tile_for(EPI, a.M, a.N);
-    const int BMt = tile ? S3B_BM : S3_BM, BNt = tile ? S3B_BN : S3_BN, lds = tile ? S3B_LDS : S3_LDS;
+    const int BMt = tile ? S3B_BM : S3_BM, BNt = tile ? S3B_BN : S3_BN, lds = tile ? s3b_lds(TERMS) : s3_lds(TERMS);
     static LdsAttr attr[2];
     const void* kern = tile ? reinterpret_cast<const void*>(gemm_bf16x3_b_kernel<EPI, TERMS, false>)
                             : reinterpret_cast<const void*>(gemm_bf16x3_kernel<EPI, TERMS, false>);
     if (int rc = attr[tile].ensure(kern, lds, "gemm_bf16x3")) return rc;
     S3Args g = a;
+#ifdef AVD_S3_STAMPS
+    g.dbg = g_s3_dbg;
+#endif
     g.nbn = a.N / BNt;
     // stream-K when the caller lent scratch for the parked partial tiles and plain tiling would leave a ragged last round
     {

@@ -110,7 +110,7 @@ class DenoiseEngine:
 
     def __init__(self, *, adapt_v: LinearAdapter, adapt_a: LinearAdapter, core: MMDiT, head: MultiModalNoiseHead,
                  tstep_dim: int, target: str, latent_shape: Tuple[int, ...], prompt_tokens: int, alpha_bar: torch.Tensor,
-                 guidance: float, eta: float = 0.0, tube=(2, 4, 4), chunk=(4, 4), split_streams: bool = False,
+                 guidance: float, eta: float = 0.0, tube=(2, 4, 4), chunk=(4, 4), split_streams: Optional[bool] = None,
                  temb_mode: str = "concat", matmul: Optional[str] = None, attn: Optional[str] = None):
         if target not in ("video", "audio"):
             raise ValueError("target must be 'video' or 'audio'")
@@ -163,6 +163,11 @@ class DenoiseEngine:
         # matrix-pipe mode of this engine ("f32" | "bf16x3", default: the core's own setting); the core module keeps its setting
         self.matmul = core.matmul if matmul is None else matmul
         self.attn = core.attn if attn is None else attn
+        # cond / null halves as two kernel chains on two HIP streams (bit-identical results).  Default: on where it was measured to
+        # pay — the f16x2 mode, whose kernels alternate matrix-bound loops with memory-bound epilogues, with >= 6144 rows per half
+        # (C3: 166 -> 174 steps/s, 512x512: 137 -> 144); the fp32 and bf16x3 modes are matrix-bound throughout and gain nothing
+        if split_streams is None:
+            split_streams = self.matmul == "f16x2" and B * self.N >= 6144
         self._split_streams = bool(split_streams)
         self._captured = False
         self.workspace: Optional[torch.Tensor] = None

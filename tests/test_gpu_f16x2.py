@@ -359,3 +359,57 @@ def test_head_split_modes_vs_oracle(dev, full, mode, act):
     e, e32 = rel_err(out["video"][:4].cpu(), ref), rel_err(out32["video"][:4].cpu(), ref)
     print(f"head {mode} {act}: err {e:.3e} (fp32-MFMA {e32:.3e})")
     assert e < TOL and e < 3.0 * e32 + 1e-7, (e, e32)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
+def test_two_stream_cfg_halves_are_bit_identical(dev, full, mode):
+    """split_streams runs the cond / null halves as two kernel chains on two HIP streams: every output element is the same sum in
+    the same order, so a step, a trajectory and a replayed graph must equal the single-stream results bit for bit.  (The f16x2
+    engine turns the two-stream layout on by itself at >= 6144 rows per half.)"""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd import schedule_utils as su
+    ws, _ = full
+    B = 16
+    g = torch.Generator().manual_seed(77)
+    z = torch.randn(B, 8, 12, 32, 32, generator=g).to(dev)
+    za = torch.randn(B, 8, 150, generator=g).to(dev)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    sched = su.make_sampling_schedule(1000, 4)
+    outs = {}
+    for split in (False, True):
+        core, head, av, aa = _full_modules(dev, ws)
+        eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z.shape),
+                              prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=mode, split_streams=split)
+        eng.set_prompt(za)
+        outs[split] = (eng.run(z, sched, graph=False), eng.run(z, sched, graph=True))
+    assert torch.isfinite(outs[True][0]).all()
+    assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1])
+    assert torch.equal(outs[True][0], outs[True][1])
+    core, head, av, aa = _full_modules(dev, ws)
+    auto = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z.shape),
+                           prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=mode)
+    assert auto._split_streams == (mode == "f16x2")          # 16 x 421 = 6736 rows per half
+
+
+def test_f16x2_below_and_at_the_row_threshold(dev, full):
+    """Below 6144 rows the f16x2 request keeps the fp32-MFMA kernels (the 256-row tiles would not fill the chip); at the threshold
+    (128x128 at B=32: 8512 core rows, exactly 6144 head rows) the split kernels take over — the step workspace is sized for
+    whichever path runs, and both agree with the f32 mode."""
+    import multimodal_diffusion_amd as A
+    ws, _ = full
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    for B, hw in ((4, 32), (32, 16)):
+        g = torch.Generator().manual_seed(B)
+        z = torch.randn(B, 8, 12, hw, hw, generator=g).to(dev)
+        za = torch.randn(B, 8, 150, generator=g).to(dev)
+        tn, tp = torch.full((B,), 500, device=dev), torch.full((B,), 480, device=dev)
+        outs = {}
+        for mode in ("f32", "f16x2"):
+            core, head, av, aa = _full_modules(dev, ws)
+            eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z.shape),
+                                  prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=mode)
+            eng.set_prompt(za)
+            outs[mode] = eng.step(z, tn, tp)
+        assert torch.isfinite(outs["f16x2"]).all()
+        # (not bit-equal below the threshold either: the f32 mode folds the RMSNorms into the GEMM epilogues, the fallback does not)
+        assert float((outs["f32"] - outs["f16x2"]).abs().max()) < 2e-5 * max(1.0, float(outs["f32"].abs().max()))

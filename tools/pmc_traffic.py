@@ -28,7 +28,7 @@ for counter in ("FETCH_SIZE", "WRITE_SIZE"):
     d = tempfile.mkdtemp(prefix=f"pmc_{counter}_", dir=os.path.join(root, "gpurun_out"))
     cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
            "python3", os.path.join(root, "bench.py"), "--steps", str(args.steps), "--warmup", "1",
-           "--no-cpu-baseline", "--no-roofline", "--no-alt"] + [e for e in extra if e != "--"]
+           "--no-cpu-baseline", "--no-roofline", "--no-alt", "--split-streams", "0"] + [e for e in extra if e != "--"]
     env = dict(os.environ, TMPDIR="/tmp")
     subprocess.run(cmd, check=True, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)

@@ -23,7 +23,7 @@ for counter in ("MfmaUtil", "LdsUtil", "VALUBusy", "MemUnitStalled"):
     d = tempfile.mkdtemp(prefix=f"pmc_{counter}_", dir=os.path.join(root, "gpurun_out"))
     cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
            "python3", os.path.join(root, "bench.py"), "--steps", str(args.steps), "--warmup", "1",
-           "--no-cpu-baseline", "--no-roofline", "--no-alt"] + [e for e in extra if e != "--"]
+           "--no-cpu-baseline", "--no-roofline", "--no-alt", "--split-streams", "0"] + [e for e in extra if e != "--"]
     r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if r.returncode:
         print(f"pass {counter} failed (rc {r.returncode})")
