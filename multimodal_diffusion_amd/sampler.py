@@ -54,7 +54,7 @@ def build_components(cfg: Dict, device: torch.device, vid_vae: Optional[nn.Modul
 
     The codec / VAE are built from ``cfg["video"]`` / ``cfg["audio"]`` like the reference unless the caller passes
     its own modules (anything with ``encode`` / ``decode``); they sit outside the per-step path.
-    Extension over the reference config: ``cfg["runtime"]["matmul"]`` in {"f32", "bf16x3"} selects the matrix-pipe mode of the
+    Extension over the reference config: ``cfg["runtime"]["matmul"]`` in {"f32", "bf16x3", "bf16x3_strict", "f16x2", "bf16"} selects the matrix-pipe mode of the
     MMDiT core and the VAE decoder (default "f32"; same fp32-level error either way).
     """
     matmul = str(cfg.get("runtime", {}).get("matmul", "f32"))
@@ -63,7 +63,7 @@ def build_components(cfg: Dict, device: torch.device, vid_vae: Optional[nn.Modul
     if vid_vae is None and "video" in cfg:
         from .vae_video3d import VideoVAE
         vid_vae = VideoVAE.from_config(cfg["video"]).to(device).eval()
-        vid_vae.matmul = "bf16x3" if matmul.startswith("bf16") else "f32"
+        vid_vae.matmul = "f32" if matmul == "f32" else "bf16x3"     # the decoder has fp32-MFMA and bf16x3 convolutions
     if aud_codec is None and "audio" in cfg:
         from .audio_codec import AudioCodec
         aud_codec = AudioCodec.from_config(cfg["audio"]).to(device).eval()

@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, str(__import__('pathlib').Path(__file__).resolve().parent.parent))
 import multimodal_diffusion_amd as A
 from multimodal_diffusion_amd import schedule_utils as su
 import bench
@@ -11,7 +11,7 @@ sched = su.make_sampling_schedule(1000, 50)
 B = 32
 z0 = torch.randn(B, 8, 12, 32, 32, generator=torch.Generator().manual_seed(1)).to(dev)
 za = torch.randn(B, 8, 150, generator=torch.Generator().manual_seed(2)).to(dev)
-for mode in ("f32", "bf16x3"):
+for mode in ("f32", "bf16x3", "f16x2"):
     eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=tdim, target="video", latent_shape=tuple(z0.shape),
                           prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=mode)
     eng.set_prompt(za)
