@@ -413,3 +413,24 @@ def test_f16x2_below_and_at_the_row_threshold(dev, full):
         assert torch.isfinite(outs["f16x2"]).all()
         # (not bit-equal below the threshold either: the f32 mode folds the RMSNorms into the GEMM epilogues, the fallback does not)
         assert float((outs["f32"] - outs["f16x2"]).abs().max()) < 2e-5 * max(1.0, float(outs["f32"].abs().max()))
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2"])
+def test_full_width_step_vs_reference_golden(dev, full, mode):
+    """Fixture g17: one CFG step at the bench's full model width, batch 8 (6,736 rows — every matrix-pipe mode engages, the head's
+    split path too), computed by the reference's own modules.  Every mode must reproduce the reference's next latents."""
+    import multimodal_diffusion_amd as A
+    from conftest import load_golden
+    from test_oracle_golden import g17_inputs
+    ws, _ = full
+    g = load_golden("g17_full_step_c3.npz")
+    z_v, z_a = g17_inputs()
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    core, head, av, aa = _full_modules(dev, ws)
+    eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z_v.shape),
+                          prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=mode)
+    eng.set_prompt(z_a.to(dev))
+    out = eng.step(z_v.to(dev), torch.from_numpy(g["t_now"]).to(dev), torch.from_numpy(g["t_prev"]).to(dev)).cpu()
+    e = rel_err(out[:2], g["z_next01"])
+    print(f"full-width step vs the reference, {mode}: {e:.3e}")
+    assert torch.isfinite(out).all() and e < TOL

@@ -203,6 +203,27 @@ def test_g15_add_mode_step(small_model):
     assert rel_err(Xv, g["X"][:, :tok_v.shape[1]]) < 1e-6
 
 
+def g17_inputs():
+    """The seeded inputs of fixture g17 (tools/make_golden.py G17): weights = synth_weights(0), latents from seed 1717."""
+    gen = torch.Generator().manual_seed(1717)
+    z_v = torch.randn(8, 8, 12, 32, 32, generator=gen)
+    z_a = torch.randn(8, 8, 150, generator=gen)
+    return z_v, z_a
+
+
+def test_g17_full_width_step():
+    """One CFG step at the bench's full model width (d=512, L=8, H=8, 384+37 tokens) computed by the REFERENCE's own modules
+    (weights by the seeded recipe, not stored): the oracle on the first two samples, eps tokens and next latents."""
+    g = load_golden("g17_full_step_c3.npz")
+    ws = R.synth_weights(seed=0)
+    z_v, z_a = g17_inputs()
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    z, eps = R.denoise_step_a2v(z_v[:2], z_a[:2], T(g["t_now"])[:2], T(g["t_prev"])[:2], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"],
+                                core=ws["core"], head=ws["head"], n_layers=8, n_heads=8, guidance=3.5, return_eps=True)
+    assert rel_err(eps[:1], g["eps_tok0"]) < TOL
+    assert rel_err(z, g["z_next01"]) < TOL
+
+
 def _grp(g, prefix):
     return {k[len(prefix) + 1:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix + "/")}
 

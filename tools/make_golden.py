@@ -15,6 +15,7 @@ G11 VideoVAE.decode, G12 VideoVAE.encode, G13 AudioCodec,
 G14 stream_infer splitting / cross-fade stitching,
 G15 one CFG step with the TRAINER's embedding (d-wide adapters, timestep embedding added; train/trainer.py:36-49),
 G16 drop-in corners: MMDiT with key_padding_mask, norm="layernorm", VideoVAE variational eval encode, non-GELU head.
+G17 one CFG step at the bench's full model width (d=512, L=8, 421 tokens), batch 8, weights by seeded recipe.
 """
 from __future__ import annotations
 
@@ -399,6 +400,44 @@ def main():
     g16["hann/windows"], g16["hann/y"] = _np(wnd), _np(ops.overlap_add_1d(wnd, stride=4, apply_hann=True))
     g16["hann/y_rect"] = _np(ops.overlap_add_1d(wnd, stride=3))
     _save("g16_dropin_corners.npz", **g16)
+
+    # ---- G17 one CFG step A->V at the bench's full width (mvp.yaml model: d=512, L=8, H=8, 384+37 tokens) through the
+    # reference's own modules, batch 8 (2B*N = 6,736 rows: large enough for every matrix-pipe mode of the HIP path to engage).
+    # The 26 M weights are not stored: they are the seeded recipe oracle.synth_weights(0), loaded into the reference modules with
+    # strict=True; inputs are seeded too.  Stored: the reference's eps tokens for sample 0 and its next latents for samples 0-1.
+    if ONLY is None or "g17" in ONLY:
+        sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+        from oracle import ref_cpu as R
+        ws = R.synth_weights(seed=0)
+        coreF = MMDiT(d_model=512, n_layers=8, n_heads=8, mlp_ratio=4.0).eval()
+        coreF.load_state_dict(ws["core"], strict=True)
+        headF = MultiModalNoiseHead({"video": 512, "audio": 512}, {"video": 256, "audio": 32}, hidden_dim=512).eval()
+        headF.load_state_dict(ws["head"], strict=True)
+        avF, aaF = sc.LinearAdapter(256, 256), sc.LinearAdapter(32, 256)
+        avF.load_state_dict(ws["adapt_v"], strict=True)
+        aaF.load_state_dict(ws["adapt_a"], strict=True)
+        B17 = 8
+        gen = torch.Generator().manual_seed(1717)
+        z_v = torch.randn(B17, 8, 12, 32, 32, generator=gen)
+        z_a = torch.randn(B17, 8, 150, generator=gen)
+        tn17 = torch.tensor([982, 500, 16, 999, 700, 300, 64, 5], dtype=torch.long)
+        tp17 = torch.tensor([966, 480, -1, 979, 680, 280, 48, -1], dtype=torch.long)
+        abarF = su.alphas_cumprod_from_betas(su.make_beta_schedule(1000, "cosine", 1e-4, 0.02))[1]
+        with torch.no_grad():
+            tok_v = sc.latents_to_tokens_video(z_v, t_p=2, p=4)
+            tok_a = sc.latents_to_tokens_audio(z_a, l_chunk=4, s_chunk=4)
+            Nv = tok_v.size(1)
+            Xv = sc.add_sinusoidal_timestep(avF(tok_v), tn17, 256)
+            Xa = sc.add_sinusoidal_timestep(aaF(tok_a), torch.zeros(B17, dtype=torch.long), 256)
+            hc = coreF(torch.cat([Xv, Xa], 1))
+            ec = headF({"video": hc[:, :Nv], "audio": hc[:, Nv:]})["video"]
+            hn = coreF(torch.cat([Xv, torch.zeros_like(Xa)], 1))
+            en = headF({"video": hn[:, :Nv], "audio": hn[:, Nv:]})["video"]
+            et = en + 3.5 * (ec - en)
+            el = ops.tube_unpatch_video(et, C=8, T=12, H=32, W=32, t=2, h=4, w=4)
+            zn = su.ddim_step(z_v, tn17, tp17, el, abarF, eta=0.0)
+        _save("g17_full_step_c3.npz", meta=np.array(json.dumps(dict(seed_weights=0, seed_inputs=1717, B=B17, guidance=3.5, tokens=[int(Nv), int(tok_a.size(1))]))),
+              t_now=_np(tn17), t_prev=_np(tp17), eps_tok0=_np(et[:1]), z_next01=_np(zn[:2]), z_next_absmax=np.float32(zn.abs().max()))
 
     # ---- optional: full-size live comparison oracle vs reference --------------------------
     if args.full_size_report:
