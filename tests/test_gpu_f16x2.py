@@ -434,3 +434,84 @@ def test_full_width_step_vs_reference_golden(dev, full, mode):
     e = rel_err(out[:2], g["z_next01"])
     print(f"full-width step vs the reference, {mode}: {e:.3e}")
     assert torch.isfinite(out).all() and e < TOL
+
+
+def test_full_step_v2a_f16x2(dev, full):
+    """Video -> audio direction in f16x2: 37 target + 384 prompt tokens at 256x256 (target rows first, the 32-wide audio head stays
+    on fp32 MFMA), B=10 -> 8,420 rows; oracle on the first two samples; two streams off (4,210 rows per half)."""
+    import multimodal_diffusion_amd as A
+    ws, _ = full
+    core, head, av, aa = _full_modules(dev, ws)
+    g = torch.Generator().manual_seed(78)
+    B = 10
+    z_v = torch.randn(B, 8, 12, 32, 32, generator=g)
+    z_a = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn = torch.tensor([982, 19] * 5)
+    tp = torch.tensor([966, -1] * 5)
+    ref = R.denoise_step_v2a(z_a[:2], z_v[:2], tn[:2], tp[:2], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"], core=ws["core"],
+                             head=ws["head"], n_layers=8, n_heads=8, guidance=3.0)
+    outs = {}
+    for mode in ("f16x2", "f32"):
+        eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=_full_modules(dev, ws)[0], head=head, tstep_dim=256, target="audio",
+                              latent_shape=tuple(z_a.shape), prompt_tokens=384, alpha_bar=abar, guidance=3.0, matmul=mode)
+        eng.set_prompt(z_v.to(dev))
+        outs[mode] = eng.step(z_a.to(dev), tn.to(dev), tp.to(dev))
+        assert not eng._split_streams
+    e2, e32 = rel_err(outs["f16x2"][:2].cpu(), ref), rel_err(outs["f32"][:2].cpu(), ref)
+    print(f"V->A step: f16x2 {e2:.3e}, fp32-MFMA {e32:.3e}")
+    assert e2 < TOL and not torch.equal(outs["f16x2"], outs["f32"])
+
+
+def test_full_step_f16x2_512(dev, full):
+    """BASELINE C5 geometry (512x512: 1536+37 tokens, ragged 1573 -> 1600 padded keys), B=8 -> 25,168 rows, the f16x2 engine's default
+    layout (two streams, 12,584 rows per half); sample 0 against the CPU oracle."""
+    import multimodal_diffusion_amd as A
+    ws, _ = full
+    core, head, av, aa = _full_modules(dev, ws)
+    B = 8
+    g = torch.Generator().manual_seed(512)
+    z_v = torch.randn(B, 8, 12, 64, 64, generator=g)
+    z_a = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn = torch.tensor([982, 500, 16, 999, 700, 300, 64, 5])
+    tp = torch.tensor([966, 480, -1, 979, 680, 280, 48, -1])
+    ref = R.denoise_step_a2v(z_v[:1], z_a[:1], tn[:1], tp[:1], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"],
+                             core=ws["core"], head=ws["head"], n_layers=8, n_heads=8, guidance=3.5)
+    eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video",
+                          latent_shape=tuple(z_v.shape), prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul="f16x2")
+    assert eng._split_streams
+    eng.set_prompt(z_a.to(dev))
+    out = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev))
+    e = rel_err(out[:1].cpu(), ref)
+    print(f"512x512 step, f16x2: {e:.3e}")
+    assert torch.isfinite(out).all() and e < TOL
+
+
+def test_sample_one_direction_with_f16x2_modules(dev, full):
+    """The reference-signature sampler with the core / head switched to "f16x2" on a small clip (B=1: far below 6144 rows, so the
+    request must be harmless — the fp32 kernels run) produces the frames of the f32 run to within 1 LSB."""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd.audio_codec import AudioCodec
+    ws, _ = full
+    torch.manual_seed(3)
+    vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval().to(dev)
+    codec = AudioCodec.from_config({"sr": 16000, "latent": {"channels": 8, "frames_per_clip": 150},
+                                    "codec": {"hop_samples": 320}}).eval().to(dev)
+    cfg = {"tokenizer": {"width": 512, "video": {"tube": {"t": 2, "h": 4, "w": 4}}, "audio": {"chunk": {"length": 4, "stride": 4}}},
+           "video": {"fps": 16, "size": [32, 32], "latent": {"channels": 8, "t_down": 4, "s_down": 8}},
+           "audio": {"sr": 16000, "latent": {"channels": 8, "frames_per_clip": 150}},
+           "data": {"clip_seconds": 0.5},
+           "diffusion": {m: {"steps": 1000, "sampler_steps": 3, "schedule": "cosine", "min_beta": 1e-4, "max_beta": 0.02}
+                         for m in ("video", "audio")},
+           "sampling": {"ddim_eta": 0.0, "guidance_scale": {"video": 2.0, "audio": 2.0}}}
+    wav = (0.1 * torch.randn(48000, generator=torch.Generator().manual_seed(5))).numpy()
+    frames = {}
+    for mode in ("f32", "f16x2"):
+        core, head, av, aa = _full_modules(dev, ws)
+        core.matmul = head.matmul = mode
+        torch.manual_seed(77)
+        res = A.sample_one_direction(cfg=cfg, vid_vae=vae, aud_codec=codec, adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256,
+                                     device=dev, prompt_modality="audio", prompt_video=None, prompt_audio=wav)
+        frames[mode] = res["video"].astype(np.int32)
+    assert np.abs(frames["f32"] - frames["f16x2"]).max() <= 1
