@@ -292,6 +292,9 @@ int avd_gemm_bf16x3_f32(const void* A3, const void* W3, const float* bias, const
  * multimodal_diffusion_amd/mmdt.py `_f16x2_scales`); a value past the range turns its output rows into NaN, never into a
  * silently saturated number.  Images have the split3 / qkv3 geometry (same byte counts; the third plane is unused).
  * ab_scale = (A image scale) * (W image scale); c_scale / qkv_scale / out_scale = scale of the image being written. */
+/* out2[0] = max |w|, out2[1] = max over rows of ||w_row||_2 for w [rows, cols] (a vector: rows = 1) — the quantities the scale
+ * bounds above are made of; exact, order-independent (integer atomic maxima); NaN in w makes both NaN. */
+int avd_weight_bounds_f32(const float* w, int64_t rows, int cols, float* out2, avd_stream_t stream);
 int avd_split_f16x2_f32(const float* x, void* out, int64_t rows, int K, float scale, avd_stream_t stream);
 int avd_rmsnorm_split_f16x2_f32(const float* x, const float* gamma, void* out, int64_t rows, int d, float eps, float scale,
                                 avd_stream_t stream);

@@ -1,17 +1,18 @@
-// fp32-accurate attention on the bf16 matrix pipe — the bf16x3 counterpart of attn_f32.hip
+// Attention on the 16-bit matrix pipes with split operands — the counterpart of attn_f32.hip
 // (nn.MultiheadAttention's scaled-dot-product step, avdiff/models/mmdt.py:51-61), used with gemm_bf16x3.hip.
 //
-// Both contractions run on v_mfma_f32_32x32x16_bf16 with exactly split operands (x = h + m + l, six product terms,
-// fp32 accumulation; rationale and error analysis in gemm_bf16x3.hip):
+// Both contractions run on v_mfma_f32_32x32x16_{bf16,f16} with split operands and fp32 accumulation (modes and error analysis in
+// gemm_bf16x3.hip: TERMS 6 / 9 = three exact bf16 planes, 1 = one bf16 plane, 3 = "f16x2", two scaled fp16 planes):
 //   S^T = K Q^T : K and Q planes come from the qkv3 image the in_proj GEMM epilogue wrote (q pre-multiplied by
-//                 scale * log2 e, so the scores are already in the exp2 domain);
+//                 scale * log2 e, so the scores are already in the exp2 domain; f16x2: the image's scale^2 is divided out);
 //   softmax     : in registers, as in attn_f32.hip (a lane holds 16 + 16 keys of ONE query column);
-//   O^T = V^T P^T: P is split in registers (v_cvt_pk_bf16_f32) and, because an MFMA may sum k in any order, the score
-//                 accumulators feed the B operand without moving between lanes; V stays row-major [key][d] in LDS and is
-//                 read transposed by ds_read_b64_tr_b16 (4 keys x 16 d per 16-lane group) in the key order P has.
+//   O^T = V^T P^T: P is split in registers (v_cvt_pk_bf16_f32; f16x2: at scale 2^15, p <= 1) and, because an MFMA may sum k in any
+//                 order, the score accumulators feed the B operand without moving between lanes; V stays row-major [key][d] in LDS
+//                 and is read transposed by ds_read_b64_tr_b16 (4 keys x 16 d per 16-lane group) in the key order P has.
 // K/V tiles of 64 keys are 24 KiB contiguous, pre-swizzled pieces of the image: the global->LDS DMA is a linear copy.
-// Measured (B=64, N=421, H=8): 153 us against 232 us for the fp32-MFMA kernel, i.e. ~0.9 PFLOP/s of bf16 MFMA issue,
-// which is where softmax VALU work and the power-limited clock leave a bf16 attention loop on this chip.
+// Measured (B=64, N=421, H=8): bf16x3 164 us, f16x2 120 us, against 228 us for the fp32-MFMA kernel; at N=1573 f16x2 reaches
+// 263 fp32-equivalent TFLOP/s.  Staggering the two co-resident blocks, a double-buffered V tile and software-pipelined fragment
+// reads were measured and change nothing: the step runs on the socket power cap.
 #include "avd_common.h"
 
 namespace avd {

@@ -233,6 +233,7 @@ int rmsnorm_f32(const float* x, RowMap xm, const float* scale, float* y, RowMap 
                 hipStream_t st);
 int layernorm_act_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int d, float eps,
                       int act, hipStream_t st);
+int weight_bounds_f32(const float* x, int64_t rows, int d, float* out2, hipStream_t st);
 
 // bf16x3 path (gemm_bf16x3.hip)
 int64_t split3_bytes(int64_t rows, int K);

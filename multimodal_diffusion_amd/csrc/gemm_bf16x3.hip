@@ -1,28 +1,30 @@
-// fp32-accurate Linear on the bf16 matrix pipe ("bf16x3") — an alternative to gemm_f32.hip for the four big
-// projections of a Block (avdiff/models/mmdt.py:60,77-83) when the batch is large.
+// Linear layers on the 16-bit matrix pipes with split operands — an alternative to gemm_f32.hip for the projections of a Block
+// (avdiff/models/mmdt.py:60,77-83) and of the noise head (heads/noise_heads.py:141-147, 206-223) when the batch is large.
 //
-// Why: on gfx950 v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate (157 vs 2,516 TFLOP/s).  Every fp32 value
-// splits EXACTLY into three bf16 planes, x = h + m + l (8 significant bits each, bf16 has fp32's exponent range, so no
-// scaling is needed).  A product keeps the six terms down to 2^-16 — hh, hm, mh, hl, lh, mm — and drops ml, lm, ll
-// (<= 2^-24 relative), each term accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Measured against an fp64 result the
-// error is the same as (slightly below) the fp32 FMA chain's: 3.5e-6 vs 3.8e-6 max at K=512, 6.5e-4 vs 7.5e-4 at
-// K=2048 with |C| ~ 460 (tools/micro/split_lab2.hip check).  Six bf16 MFMAs of 32 cycles replace eight fp32 MFMAs of 64
-// cycles per k=16: 2.67x fewer matrix-pipe cycles.
+// Why: on gfx950 v_mfma_f32_32x32x2_f32 runs at 1/16 of the 16-bit MFMA rate (157 vs 2,516 TFLOP/s).  Modes (`terms`):
+//   6  "bf16x3": every fp32 value splits EXACTLY into three bf16 planes, x = h + m + l (8 significant bits each, bf16 has fp32's
+//      exponent range, so no scaling is needed).  A product keeps the six terms down to 2^-16 — hh, hm, mh, hl, lh, mm — and drops
+//      ml, lm, ll (<= 2^-24 relative), each term accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  Against fp64 the error is that
+//      of the fp32 FMA chain (3.5e-6 vs 3.8e-6 max at K=512, tools/micro/split_lab2.hip check).  Six bf16 MFMAs of 32 cycles
+//      replace eight fp32 MFMAs of 64 cycles per k=16: 2.67x fewer matrix-pipe cycles.
+//   9  "bf16x3_strict": all nine terms, nothing dropped.      1  "bf16": the h plane only — reduced precision, reported error.
+//   3  "f16x2": two fp16 planes of a value scaled by a caller-chosen power of two (22 significant bits, avd_common.h), three terms
+//      hl, lh, hh on v_mfma_f32_32x32x16_f16: half the matrix-pipe work of bf16x3, measured error at or below the fp32 kernels'.
 //
 // Operand image ("split3"): X[rows][K] fp32 -> T[ceil(rows/128)][K/16][3 planes][128 rows][32 B]; inside a 12 KiB chunk
 // the 16 bytes of (plane p, row r, half = (k%16)/8) sit at p*4096 + r*32 + (half ^ ((r>>3)&1))*16.  One block's K-tile of
-// an operand is then one contiguous, already bank-swizzled chunk — the global->LDS DMA is a linear copy of whole cache lines,
-// the ds_read_b128 of fragment rows is conflict free — and a producer's store of one plane for consecutive rows is
-// contiguous too.  Producers write the image directly (rmsnorm_split3_kernel here, the attention epilogue in
-// attn_bf16x3.hip, the fc1 bias+GELU epilogue below), so no fp32 copy of those activations exists in this mode; the in_proj
-// epilogue writes the "qkv3" image the attention kernel reads (layout in avd_common.h).
+// an operand is then contiguous, already bank-swizzled pieces — the global->LDS DMA copies whole 1 KiB pieces (only the planes the
+// mode uses), the ds_read_b128 of fragment rows is conflict free — and a producer's store of one plane for consecutive rows is
+// contiguous too.  Producers write the image directly (rmsnorm_split3_kernel and layernorm_act_split3_kernel here, the attention
+// epilogue in attn_bf16x3.hip, the bias / bias+GELU epilogues below), so no fp32 copy of those activations exists in these modes;
+// the in_proj epilogue writes the "qkv3" image the attention kernel reads (layout in avd_common.h).
 //
-// Kernels (wave tile 128x64 = 4x2 accumulators, 18 ds_read_b128 per 48 MFMAs, K-tile 16, XCD-contiguous super-tiles):
-//   gemm_bf16x3_kernel    256x256, 8 waves, one block per CU, three 48 KiB LDS stages, counted vmcnt (two tiles in flight);
-//   gemm_bf16x3_b_kernel  256x128, 4 waves, two blocks per CU, two 36 KiB stages, fragments one K-tile ahead in registers —
-//                         for the heavy epilogues (split3 / qkv3 outputs) and for batches that do not fill 256-row tiles.
-// The main loop is MFMA-paced (3,180 cycles per K-step against 3,072 of pure MFMA issue); what caps the rate near 190-200
-// fp32-equivalent TFLOP/s is power: the in-kernel clock is 2.07 GHz with every CU busy, 2.25 GHz with 212 of 256.
+// Kernels (wave tile 128x64 = 4x2 accumulators, K-tile 16, XCD-contiguous super-tiles, LDS stage = the planes moved, compact):
+//   gemm_bf16x3_kernel    256x256, 8 waves, one block per CU, 3 / 4 / 6 stages (3 / 2 / 1 planes), counted vmcnt;
+//   gemm_bf16x3_b_kernel  256x128, 4 waves, two blocks per CU, 2 / 3 / 4 stages, fragments one K-tile ahead in registers —
+//                         for the heavy epilogues (image outputs) and for batches that do not fill 256-row tiles.
+// What caps the rate is power: bf16x3 holds 2.07 GHz at 1.33 kW, f16x2 1.91 GHz at the 1.4 kW cap (DESIGN.md 4.5 / 4.6;
+// tools/micro/s3_stamps.py shows the K loops at 79-91 % of the matrix pipe's issue rate at that clock).
 #include "avd_common.h"
 
 #include <stdlib.h>
@@ -184,9 +186,11 @@ struct S3Args {
 // wave 0 of every block sums, over its K loop, the core-clock cycles between the loop top, the DMA wait, the barrier, the DMA
 // issue and the end of the step; plus stamps at block entry, loop start, loop end, block end
 #define S3_T() __builtin_amdgcn_s_memtime()
+#define S3_RT() __builtin_amdgcn_s_memrealtime()
 #define S3_DBG(i, v) do { if (threadIdx.x == 0) g.dbg[(size_t)blockIdx.x * 16 + (i)] = (v); } while (0)
 #else
 #define S3_T() 0ull
+#define S3_RT() 0ull
 #define S3_DBG(i, v) do { } while (0)
 #endif
 
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
     constexpr bool sk = SK;
-    [[maybe_unused]] const unsigned long long t_entry = S3_T();
+    [[maybe_unused]] const unsigned long long t_entry = S3_T(), rt_entry = S3_RT();
     [[maybe_unused]] unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_body = 0;
     int bm, bn;
     SkRange skr{};
@@ -626,7 +630,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16x3_kernel(S3Args g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         S3_DBG(0, t_entry); S3_DBG(1, t_loop); S3_DBG(2, t_end); S3_DBG(3, S3_T());
         S3_DBG(4, c_wait); S3_DBG(5, c_bar); S3_DBG(6, c_issue); S3_DBG(7, c_body); S3_DBG(8, (unsigned long long)nk);
-        S3_DBG(9, __builtin_amdgcn_s_memrealtime());
+        S3_DBG(9, S3_RT()); S3_DBG(10, rt_entry);
 #endif
         if (!sk) break;
         __syncthreads();      // slabs drained before the next segment's DMA lands on them
@@ -659,7 +663,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
     constexpr bool sk = SK;
-    [[maybe_unused]] const unsigned long long t_entry = S3_T();
+    [[maybe_unused]] const unsigned long long t_entry = S3_T(), rt_entry = S3_RT();
     [[maybe_unused]] unsigned long long c_wait = 0, c_bar = 0, c_issue = 0, c_body = 0;
     int bm, bn;
     SkRange skr{};
@@ -872,7 +876,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     S3_DBG(0, t_entry); S3_DBG(1, t_loop); S3_DBG(2, t_end); S3_DBG(3, S3_T());
     S3_DBG(4, c_wait); S3_DBG(5, c_bar); S3_DBG(6, c_issue); S3_DBG(7, c_body); S3_DBG(8, (unsigned long long)nk);
-    S3_DBG(9, __builtin_amdgcn_s_memrealtime());
+    S3_DBG(9, S3_RT()); S3_DBG(10, rt_entry);
 #endif
     if (!sk) break;
     __syncthreads();      // slabs drained before the next segment's DMA lands on them

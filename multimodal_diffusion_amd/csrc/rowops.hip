@@ -147,6 +147,44 @@ int rowss_f32(const float* x, float* ss, int64_t rows, int d, hipStream_t st) {
     return AVD_OK;
 }
 
+// max |x| and max row 2-norm of a [rows][d] matrix -> out[0], out[1] (the weight bounds the f16x2 image scales are derived from).
+// One wave per row; the two maxima are folded with integer atomicMax on the bit patterns (both are non-negative floats), so the
+// result is exact and order-independent.  NaN anywhere makes both outputs NaN (the caller refuses non-finite bounds).
+__global__ __launch_bounds__(256) void bounds_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t rows, int d) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * d;
+    float s = 0.f, m = 0.f;
+    bool bad = false;
+    for (int c = lane; c < d; c += 64) {
+        const float v = xr[c];
+        s += v * v;
+        m = fmaxf(m, fabsf(v));
+        bad = bad || v != v;
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    bad = __any(bad);
+    if (lane == 0) {
+        const float nrm = bad ? __builtin_nanf("") : sqrtf(s);
+        const float mx = bad ? __builtin_nanf("") : m;
+        // NaN's bit pattern (0x7fc00000) is above every finite non-negative float and +inf: it wins the integer maximum
+        atomicMax(reinterpret_cast<unsigned int*>(out), __float_as_uint(mx));
+        atomicMax(reinterpret_cast<unsigned int*>(out) + 1, __float_as_uint(nrm));
+    }
+}
+__global__ void bounds_init_kernel(float* out) { out[threadIdx.x] = 0.f; }
+
+int weight_bounds_f32(const float* x, int64_t rows, int d, float* out2, hipStream_t st) {
+    AVD_REQUIRE(x && out2 && rows > 0 && d > 0, AVD_EINVAL, "weight_bounds: bad arguments");
+    hipLaunchKernelGGL(bounds_init_kernel, dim3(1), dim3(2), 0, st, out2);
+    hipLaunchKernelGGL(bounds_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, out2, rows, d);
+    AVD_CHECK_LAUNCH("weight_bounds");
+    return AVD_OK;
+}
+
 int layernorm_act_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows, int d, float eps,
                       int act, hipStream_t st) {
     AVD_REQUIRE(x && gamma && beta && y, AVD_EINVAL, "layernorm: null pointer");
@@ -174,6 +212,10 @@ extern "C" int avd_rmsnorm_f32(const float* x, const float* scale, float* y, int
                                avd_stream_t stream) {
     return avd::rmsnorm_f32(x, avd::RowMap{d, 0, 0}, scale, y, avd::RowMap{d, 0, 0}, rows, d, eps,
                             static_cast<hipStream_t>(stream));
+}
+
+extern "C" int avd_weight_bounds_f32(const float* w, int64_t rows, int cols, float* out2, avd_stream_t stream) {
+    return avd::weight_bounds_f32(w, rows, cols, out2, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int avd_layernorm_act_f32(const float* x, const float* gamma, const float* beta, float* y, int64_t rows,

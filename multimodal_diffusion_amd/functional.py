@@ -254,6 +254,20 @@ def f16x2_scale(bound: float) -> float:
     return float(2.0 ** max(-100, min(100, e)))
 
 
+def weight_bounds(tensors) -> list:
+    """[(max|w|, max row 2-norm), ...] for a list of fp32 device tensors (vectors count as one row), computed by the library
+    (``avd_weight_bounds_f32``); one device-to-host copy for the whole list."""
+    tensors = [L.dev_f32(t.detach(), "weight") for t in tensors]
+    if not tensors:
+        return []
+    out = torch.empty(len(tensors), 2, dtype=torch.float32, device=tensors[0].device)
+    for i, t in enumerate(tensors):
+        cols = t.shape[-1]
+        rows = t.numel() // cols
+        L.check(L.lib().avd_weight_bounds_f32(t.data_ptr(), rows, cols, out[i].data_ptr(), _st(t)))
+    return [(float(a), float(b)) for a, b in out.cpu().tolist()]
+
+
 def split_f16x2(x: Tensor, scale: Optional[float] = None, out: Optional[Tensor] = None):
     """fp32 [rows, K] -> (f16x2 image, scale).  scale None: derived from max|x| (one device sync)."""
     x = L.dev_f32(x, "x")
@@ -263,7 +277,7 @@ def split_f16x2(x: Tensor, scale: Optional[float] = None, out: Optional[Tensor] 
     if nbytes < 0:
         raise L.AvdError(f"split_f16x2: K={k} must be a multiple of 16")
     if scale is None:
-        scale = f16x2_scale(float(x.abs().max()))
+        scale = f16x2_scale(weight_bounds([x.reshape(rows, k)])[0][0])
     if out is None or out.numel() != nbytes or out.device != x.device:
         out = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
     L.check(L.lib().avd_split_f16x2_f32(x.data_ptr(), out.data_ptr(), rows, k, scale, _st(x)))
@@ -277,7 +291,7 @@ def rmsnorm_split_f16x2(x: Tensor, gamma: Tensor, eps: float = 1e-6, scale: Opti
     d = x.shape[-1]
     rows = x.numel() // d
     if scale is None:
-        scale = f16x2_scale(float(gamma.abs().max()) * d ** 0.5)
+        scale = f16x2_scale(weight_bounds([gamma])[0][0] * d ** 0.5)
     out = torch.empty(L.lib().avd_split3_bytes(rows, d), dtype=torch.uint8, device=x.device)
     L.check(L.lib().avd_rmsnorm_split_f16x2_f32(x.data_ptr(), gamma.data_ptr(), out.data_ptr(), rows, d, eps, scale, _st(x)))
     return out, scale

@@ -203,12 +203,11 @@ class MMDiT(nn.Module):
         if hit is None or hit[0] != key:
             from . import functional as Fn
             d = self.cfg.d_model
-            with torch.no_grad():
-                q = torch.stack([ps["norm1_scale"].abs().max(), ps["in_proj_weight"].norm(dim=1).max(), ps["in_proj_bias"].abs().max(),
-                                 ps["norm2_scale"].abs().max(), ps["fc1_weight"].norm(dim=1).max(), ps["fc1_bias"].abs().max(),
-                                 ps["in_proj_weight"].abs().max(), ps["out_proj_weight"].abs().max(), ps["fc1_weight"].abs().max(),
-                                 ps["fc2_weight"].abs().max()]).double().cpu().tolist()
-            g1, win, bin_, g2, wfc1, bfc1, m_in, m_out, m_fc1, m_fc2 = q
+            bd = dict(zip(names, Fn.weight_bounds([ps[k] for k in names])))      # (max |w|, max row norm) per tensor, one sync
+            g1, g2 = bd["norm1_scale"][0], bd["norm2_scale"][0]
+            win, wfc1 = bd["in_proj_weight"][1], bd["fc1_weight"][1]
+            bin_, bfc1 = bd["in_proj_bias"][0], bd["fc1_bias"][0]
+            m_in, m_out, m_fc1, m_fc2 = (bd[k][0] for k in ("in_proj_weight", "out_proj_weight", "fc1_weight", "fc2_weight"))
             n1 = d ** 0.5 * g1
             n2 = d ** 0.5 * g2
             sc = [Fn.f16x2_scale(m_in), Fn.f16x2_scale(m_out), Fn.f16x2_scale(m_fc1), Fn.f16x2_scale(m_fc2),

@@ -103,7 +103,7 @@ class MultiModalNoiseHead(nn.Module):
 
     def _f16x2_scales(self, m: str, blocks, in_bound: float, in_norm: float):
         """Power-of-two scales of the f16x2 images of modality m's path, from bounds that hold for every input row x with
-        |x_i| <= in_bound, ||x||_2 <= in_norm:  input_proj output  |o_n| <= ||x|| ||w_n|| + |b_n|,  ||o|| <= ||x|| sigma_max(W) + ||b||;
+        |x_i| <= in_bound, ||x||_2 <= in_norm:  input_proj output  |o_n| <= ||x|| ||w_n|| + |b_n|  (Cauchy-Schwarz);
         LayerNorm output  |y_i| <= sqrt(hidden) |gamma_i| + |beta_i|  (every activation here satisfies |act(y)| <= |y|)."""
         from . import functional as Fn
         ps = [self.input_proj[m].weight, self.input_proj[m].bias] + [q for b in blocks for q in (b[0].weight, b[1].weight, b[1].bias)] + \
@@ -111,13 +111,10 @@ class MultiModalNoiseHead(nn.Module):
         key = (tuple((q.data_ptr(), q._version) for q in ps), float(in_bound), float(in_norm))
         hit = self._images.get(f"{m}.f16x2")
         if hit is None or hit[0] != key:
-            with torch.no_grad():
-                wi, bi = self.input_proj[m].weight, self.input_proj[m].bias
-                vals = [wi.abs().max(), wi.norm(dim=1).max(), bi.abs().max()]
-                for b in blocks:
-                    vals += [b[0].weight.abs().max(), b[1].weight.abs().max(), b[1].bias.abs().max()]
-                vals.append(self.out_proj[m].weight.abs().max())
-                q = torch.stack([v.double() for v in vals]).cpu().tolist()
+            wi, bi = self.input_proj[m].weight, self.input_proj[m].bias
+            ts = [wi, bi] + [t for b in blocks for t in (b[0].weight, b[1].weight, b[1].bias)] + [self.out_proj[m].weight]
+            bd = Fn.weight_bounds(ts)                      # (max |w|, max row norm) per tensor, one sync
+            q = [bd[0][0], bd[0][1], bd[1][0]] + [bd[2 + j][0] for j in range(3 * len(blocks))] + [bd[-1][0]]
             w_in, wn_in, b_in = q[0], q[1], q[2]
             w_sc = [Fn.f16x2_scale(w_in)] + [Fn.f16x2_scale(q[3 + 3 * j]) for j in range(len(blocks))] + [Fn.f16x2_scale(q[-1])]
             a_sc = [Fn.f16x2_scale(in_bound), Fn.f16x2_scale(in_norm * wn_in + b_in)]
@@ -188,7 +185,8 @@ class MultiModalNoiseHead(nn.Module):
                 raise RuntimeError(f"{m}: expected last dim {self.input_dims[m]}, got {d_in}")
             rows = x.numel() // d_in
             if self.matmul == "f16x2":      # standalone call: bound the rows from the data (one device sync)
-                amax = float(x.abs().max())
+                from . import functional as Fn
+                amax = Fn.weight_bounds([x.reshape(rows, d_in)])[0][0]
                 hw, keep = self.weight_table(m, in_bound=amax, in_norm=amax * d_in ** 0.5)
             else:
                 hw, keep = self.weight_table(m)

@@ -195,12 +195,12 @@ class DenoiseEngine:
         hb = hn = None
         if self.matmul == "f16x2":
             fn_ = core.final_norm
-            with torch.no_grad():
-                g = fn_.weight if hasattr(fn_, "bias") and fn_.bias is not None else fn_.scale
-                gmax = float(g.abs().max()) * core.cfg.d_model ** 0.5
-                bias = getattr(fn_, "bias", None)
-                hb = gmax + (float(bias.abs().max()) if bias is not None else 0.0)
-                hn = gmax + (float(bias.norm()) if bias is not None else 0.0)
+            bias = getattr(fn_, "bias", None)
+            g = fn_.weight if bias is not None else fn_.scale
+            bd = Fn.weight_bounds([g] + ([bias] if bias is not None else []))
+            gmax = bd[0][0] * core.cfg.d_model ** 0.5
+            hb = gmax + (bd[1][0] if bias is not None else 0.0)
+            hn = gmax + (bd[1][1] if bias is not None else 0.0)
         self._head_tab, self._keep_head = head.weight_table(self.target, matmul=self.matmul, in_bound=hb, in_norm=hn)
         self._aw = L.dev_f32(self.adapt_t.proj.weight.detach(), "adapter weight")
         self._ab = L.dev_f32(self.adapt_t.proj.bias.detach(), "adapter bias")

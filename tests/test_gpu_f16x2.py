@@ -515,3 +515,23 @@ def test_sample_one_direction_with_f16x2_modules(dev, full):
                                      device=dev, prompt_modality="audio", prompt_video=None, prompt_audio=wav)
         frames[mode] = res["video"].astype(np.int32)
     assert np.abs(frames["f32"] - frames["f16x2"]).max() <= 1
+
+
+def test_weight_bounds_kernel(dev):
+    """avd_weight_bounds_f32 (what the f16x2 scales are derived from): max |w| and the largest row 2-norm, exact against fp64;
+    NaN anywhere is reported as NaN, and f16x2_scale refuses a non-finite bound."""
+    from multimodal_diffusion_amd import functional as Fn, _lib as L
+    g = torch.Generator().manual_seed(3)
+    ws = [torch.randn(1536, 512, generator=g) * 0.05, torch.randn(7, 13, generator=g), torch.randn(2048, generator=g), torch.zeros(4, 16)]
+    ws[0][77, 5] = -9.5
+    got = Fn.weight_bounds([w.to(dev) for w in ws])
+    for w, (amax, nrm) in zip(ws, got):
+        w2 = w.double().reshape(-1, w.shape[-1])
+        assert amax == float(w.abs().max())
+        assert abs(nrm - float(w2.norm(dim=1).max())) <= 1e-6 * max(1.0, nrm)
+    bad = torch.randn(8, 32, generator=g)
+    bad[3, 4] = float("nan")
+    a, n = Fn.weight_bounds([bad.to(dev)])[0]
+    assert math.isnan(a) and math.isnan(n)
+    with pytest.raises(L.AvdError):
+        Fn.f16x2_scale(a)

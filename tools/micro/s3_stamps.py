@@ -82,9 +82,8 @@ for mode, terms in (("f16x2", 3), ("bf16x3", 6), ("bf16", 1)):
         life = (d[:, 3] - d[:, 0]).astype(np.float64)
         pro, loop, epil = (d[:, 1] - d[:, 0]) / life, (d[:, 2] - d[:, 1]) / life, (d[:, 3] - d[:, 2]) / life
         steps = d[:, 8].astype(np.float64)
-        span_cyc = d[:, 3].max() - d[:, 0].min()
-        span_rt = (d[:, 9].max() - d[:, 9].min()) / 100e6        # s_memrealtime: 100 MHz
-        ghz = span_cyc / 1e9 / max(span_rt, 1e-9) if span_rt > 0 else float("nan")
+        rt = (d[:, 9] - d[:, 10]).astype(np.float64) / 100e6      # s_memrealtime: 100 MHz, block entry -> exit
+        ghz = float(np.median(life / 1e9 / np.maximum(rt, 1e-9)))
         per = lambda c: float((d[:, c] / steps).mean())
         tot = per(4) + per(5) + per(6) + per(7)
         print(f"{mode:6s} {name:34s} {us:7.1f} us  blocks {len(d):4d}  clock ~{ghz:.2f} GHz | block life: prologue {pro.mean():.2f} loop {loop.mean():.2f} "
