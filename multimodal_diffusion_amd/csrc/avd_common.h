@@ -84,6 +84,25 @@ struct RowMap {
     }
 };
 
+// A operand of a GEMM gathered straight from a video latent [B, C, T, H, W] in tube-token order (ops.py:100-127
+// tube_patch_video: token n = ((T/t index) * H/h + H/h index) * W/w + W/w index, element k = ((c * t + dt) * h + dy) * w + dx):
+// logical A[row = b * Nt + n][k] = z[b][c][nt*t + dt][ny*h + dy][nx*w + dx].  w % 4 == 0 and W % 4 == 0 keep every float4 along k
+// one aligned 16-byte run of the latent.
+struct TubeGather {
+    int T, H, W, t, h, w, Ht, Wt, Nt;
+    int64_t per;       // C*T*H*W
+    __host__ __device__ __forceinline__ int64_t row_off(int64_t row) const {
+        const int64_t b = row / Nt;
+        const int n = (int)(row - b * Nt);
+        const int nx = n % Wt, ny = (n / Wt) % Ht, nt = n / (Wt * Ht);
+        return b * per + ((int64_t)(nt * t) * H + ny * h) * W + nx * w;
+    }
+    __host__ __device__ __forceinline__ int64_t k_off(int k) const {
+        const int dx = k % w, dy = (k / w) % h, dt = (k / (w * h)) % t, c = k / (w * h * t);
+        return (((int64_t)c * T + dt) * H + dy) * W + dx;
+    }
+};
+
 // ---- split3 operand image of the bf16x3 matmul path (layout and rationale: gemm_bf16x3.hip) ----
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -216,6 +235,9 @@ struct ProfScope {
 // internal launchers used by the composites (same kernels as the public entry points)
 int gemm_f32(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm,
              float* C, RowMap cm, int64_t M, int N, int K, int act, hipStream_t st);
+// C = A W^T + bias with A gathered from the latent z through tg (the tube patch fused into the A-operand load)
+int gemm_f32_tube(const float* z, const TubeGather& tg, const float* W, const float* bias, float* C, RowMap cm, int64_t M, int N, int K,
+                  hipStream_t st);
 
 extern int g_gemm_persist;       // 1 = persistent tile-queue launch for big GEMM grids (avd_tune_set "gemm_persist")
 extern int g_gemm_stages;        // 2 or 3 LDS stages for the 128x64 / 64x64 tiles (avd_tune_set "gemm_stages")

@@ -383,8 +383,11 @@ static int embed_cfg_pair(const avd_embed_desc* e, const float* z, const float* 
     const int B = e->B, d = e->d, N = e->Nt + e->Np, D = embed_tok_dim(e);
     float* tok = tok_ws;
     float* temb = tok_ws + align_up((int64_t)B * e->Nt * D * 4) / 4;
+    // video target in the sampler's concat mode: the tube patch is the adapter GEMM's A-operand load (no token matrix is written)
+    const bool fuse_patch = e->target_kind == 0 && !e->temb_add && e->p2 % 4 == 0 && e->W % 4 == 0 && D % 4 == 0 && aligned16(z);
     if (e->target_kind == 0) {
-        if (int rc = tube_patch_f32(z, tok, B, e->C, e->T, e->H, e->W, e->p0, e->p1, e->p2, st)) return rc;
+        if (!fuse_patch)
+            if (int rc = tube_patch_f32(z, tok, B, e->C, e->T, e->H, e->W, e->p0, e->p1, e->p2, st)) return rc;
     } else {
         if (int rc = audio_tokens_f32(z, tok, B, e->C, e->T, e->p0, e->p1, st)) return rc;
     }
@@ -400,7 +403,12 @@ static int embed_cfg_pair(const avd_embed_desc* e, const float* z, const float* 
         if (int rc = gemm_f32(tok, RowMap{D, 0, 0}, Wt, bt, temb, rm, c0, cm, (int64_t)B * e->Nt, d, D, AVD_ACT_NONE, st)) return rc;
         return assemble_f32(X2, temb, Xp, B, N, d, 0, e->Nt, e->Np, e->target_first, st);
     }
-    if (int rc = gemm_f32(tok, RowMap{D, 0, 0}, Wt, bt, nullptr, cm, c0, cm, (int64_t)B * e->Nt, d - e->tdim, D, AVD_ACT_NONE, st)) return rc;
+    if (fuse_patch) {
+        const TubeGather tg{e->T, e->H, e->W, e->p0, e->p1, e->p2, e->H / e->p1, e->W / e->p2, e->Nt, (int64_t)e->C * e->T * e->H * e->W};
+        if (int rc = gemm_f32_tube(z, tg, Wt, bt, c0, cm, (int64_t)B * e->Nt, d - e->tdim, D, st)) return rc;
+    } else {
+        if (int rc = gemm_f32(tok, RowMap{D, 0, 0}, Wt, bt, nullptr, cm, c0, cm, (int64_t)B * e->Nt, d - e->tdim, D, AVD_ACT_NONE, st)) return rc;
+    }
     // timestep columns, null-half copies, prompt rows and the rows' sums of squares in one pass
     return assemble_rows_f32(X2, t_now, e->temb_freqs, Xp, ss_out, B, N, d, e->tdim, e->Nt, e->Np, e->target_first, 10000.f, st);
 }

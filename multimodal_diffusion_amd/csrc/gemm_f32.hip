@@ -63,6 +63,7 @@ struct GemmArgs {
     // one re-zeroes the slot for its next use).  ntiles = row blocks x column blocks.
     unsigned int* queue;
     int ntiles;
+    TubeGather tg;          // gemm_f32_reg_kernel<..., GATHER = true> only: A rows are tube tokens of the latent at A
 #ifdef AVD_GEMM_STAMPS      // diagnostic build only (tools/micro/gemm_stamps.py): per-block phase stamps, never in the product library
     unsigned long long* dbg;
 #endif
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
 // =====================================================================================================
 // generic fallback: register-staged double buffering, runtime-checked scalar epilogue
 // =====================================================================================================
-template <int BM, int BN, int WM, int WN, bool KTAIL>
+template <int BM, int BN, int WM, int WN, bool KTAIL, bool GATHER = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_reg_kernel(GemmArgs g) {
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * WAVES_N == 4, "4 waves per block");
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_reg_kernel(GemmArgs g) {
     for (int i = 0; i < A_IT; ++i) {
         int64_t row = (int64_t)bm * BM + lrow + 32 * i;
         row = row < g.M ? row : g.M - 1;
-        a_src[i] = g.A + g.am.off(row) + lkc;
+        a_src[i] = GATHER ? g.A + g.tg.row_off(row) : g.A + g.am.off(row) + lkc;
     }
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
@@ -467,16 +468,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_reg_kernel(GemmArgs g) {
     // vmcnt(0) and the prefetch stops overlapping the MFMAs.  KTAIL=true: per-chunk guard (K % 4 == 0).
     auto load_tile = [&](int kt) {
         const int k0 = kt * GEMM_BK;
+        // GATHER: this thread's float4 of tile kt is element k0 + lkc of the token -> (c, dt, dy, dx) of the latent
+        const int64_t ka = GATHER ? g.tg.k_off((k0 + lkc) < g.K ? k0 + lkc : 0) : (int64_t)k0;
         if constexpr (!KTAIL) {
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + k0);
+            for (int i = 0; i < A_IT; ++i) ra[i] = *reinterpret_cast<const f32x4*>(a_src[i] + ka);
 #pragma unroll
             for (int i = 0; i < B_IT; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_src[i] + k0);
         } else {
             const bool in = (k0 + lkc) < g.K;
 #pragma unroll
             for (int i = 0; i < A_IT; ++i)
-                ra[i] = in ? *reinterpret_cast<const f32x4*>(a_src[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
+                ra[i] = in ? *reinterpret_cast<const f32x4*>(a_src[i] + ka) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < B_IT; ++i)
                 rb[i] = in ? *reinterpret_cast<const f32x4*>(b_src[i] + k0) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -609,17 +612,18 @@ static int launch_dma_epi(const GemmArgs& a, hipStream_t st) {
     return launch_dma<BM, BN, WM, WN, EPI_BIAS, WPS, NST>(a, st);
 }
 
-template <int BM, int BN, int WM, int WN, bool KTAIL>
+template <int BM, int BN, int WM, int WN, bool KTAIL, bool GATHER = false>
 static int launch_reg(const GemmArgs& a, hipStream_t st) {
     constexpr int lds = 2 * (BM + BN) * GEMM_LD * 4;
     static LdsAttr attr;
-    auto kern = gemm_f32_reg_kernel<BM, BN, WM, WN, KTAIL>;
+    auto kern = gemm_f32_reg_kernel<BM, BN, WM, WN, KTAIL, GATHER>;
     if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), lds, "gemm_f32_reg")) return rc;
     GemmArgs g = a;
     g.nbn = (a.N + BN - 1) / BN;
     const int64_t nwg = ((a.M + BM - 1) / BM) * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm grid too large");
-    static const int tag = prof_tag_id("gemm_f32_reg_kernel<%d, %d, %d, %d, %s>", BM, BN, WM, WN, KTAIL ? "true" : "false");
+    static const int tag = GATHER ? prof_tag_id("gemm_f32_reg_kernel<%d, %d, %d, %d, %s, true>", BM, BN, WM, WN, KTAIL ? "true" : "false")
+                                  : prof_tag_id("gemm_f32_reg_kernel<%d, %d, %d, %d, %s, false>", BM, BN, WM, WN, KTAIL ? "true" : "false");
     ProfScope prof(tag, 2.0 * (double)a.M * a.N * a.K, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, g);
     AVD_CHECK_LAUNCH("gemm_f32_reg");
@@ -696,6 +700,18 @@ int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, 
     if (N <= 32) return launch_reg_k<128, 32, 32, 32>(g, st);
     if (N >= 128 && mb128 * ((N + 127) / 128) >= 512) return launch_reg_k<128, 128, 64, 64>(g, st);
     return launch_reg_k<64, 64, 32, 32>(g, st);
+}
+
+int gemm_f32_tube(const float* z, const TubeGather& tg, const float* W, const float* bias, float* C, RowMap cm, int64_t M, int N, int K,
+                  hipStream_t st) {
+    AVD_REQUIRE(z && W && C && M > 0 && N > 0 && K > 0, AVD_EINVAL, "gemm_tube: bad arguments");
+    AVD_REQUIRE(tg.w % 4 == 0 && tg.W % 4 == 0 && K % 4 == 0 && aligned16(z) && aligned16(W), AVD_EUNSUPPORTED,
+                "gemm_tube: the gathered A load needs w %% 4 == 0, W %% 4 == 0, K %% 4 == 0 and 16-byte aligned operands");
+    GemmArgs g{z, RowMap{K, 0, 0}, W, bias, nullptr, cm, C, cm, M, N, K, AVD_ACT_NONE, 0, nullptr, 0, 1.f, 0.f, nullptr, 0, nullptr, 0, tg};
+#ifdef AVD_GEMM_STAMPS
+    g.dbg = g_gemm_dbg;
+#endif
+    return (K % GEMM_BK) ? launch_reg<64, 64, 32, 32, true, true>(g, st) : launch_reg<64, 64, 32, 32, false, true>(g, st);
 }
 
 }  // namespace avd
