@@ -18,10 +18,12 @@ ROOT = HERE.parent.parent
 ap = argparse.ArgumentParser()
 ap.add_argument("--build", action="store_true")
 ap.add_argument("--rows", type=int, default=64 * 421)
+ap.add_argument("--variant", default="", help="extra -D flags for the diagnostic build, e.g. AVD_LAB_HALFLDS")
 args = ap.parse_args()
-so = HERE / "libs3_stamps.so"
+so = HERE / ("libs3_stamps" + ("_" + args.variant.replace(",", "_") if args.variant else "") + ".so")
 if args.build or not so.exists():
-    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared", "-DAVD_S3_STAMPS", "-o", str(so),
+    subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-shared", "-DAVD_S3_STAMPS"] +
+                   ["-D" + v for v in args.variant.split(",") if v] + ["-o", str(so),
                     str(ROOT / "multimodal_diffusion_amd/csrc/gemm_bf16x3.hip"), str(HERE / "lab_stub.hip")], check=True)
 lib = C.CDLL(str(so))
 P, I, L, F = C.c_void_p, C.c_int, C.c_int64, C.c_float
