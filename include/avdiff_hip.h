@@ -360,10 +360,16 @@ typedef struct {
     const float* to_img_b;             /* to_img.bias   [out_ch] */
     const void* const* conv_w3;        /* optional HOST array [n_blocks] of avd_conv3_weight_f32 images: the convolutions then run
                                         * on the bf16 matrix pipe with exactly split operands (fp32-level error, see "bf16x3"); NULL = fp32 MFMA */
+    int conv_terms;                    /* with conv_w3: 0 or 6 = bf16x3; 3 = f16x2 (images from avd_conv3_weight_f16x2_f32, see "f16x2") */
+    const float* conv_w_scale;         /* conv_terms 3: HOST array [n_blocks], power-of-two scales of the weight images */
+    const float* conv_a_scale;         /* conv_terms 3: HOST array [n_blocks], scales of each block's INPUT image: entry i >= 1 from the bound
+                                        * |GroupNorm output| <= sqrt(n - 1) max|gamma| + max|beta| (n = elements of one group of one sample);
+                                        * entry 0 is ignored — the first image's scale is derived on the device from max |from_lat(z)| */
 } avd_vae_decode_desc;
-/* weight image of one 3x3x3 64->64 convolution for the bf16x3 decoder: w_tap_major is [out][kt][kh][kw][in] fp32 */
+/* weight image of one 3x3x3 64->64 convolution for the split-operand decoders: w_tap_major is [out][kt][kh][kw][in] fp32 */
 int64_t avd_conv3_weight_bytes(void);
 int avd_conv3_weight_f32(const float* w_tap_major, void* img, avd_stream_t stream);
+int avd_conv3_weight_f16x2_f32(const float* w_tap_major, void* img, float scale, avd_stream_t stream);
 int64_t avd_vae_decode_workspace_bytes(const avd_vae_decode_desc* d);
 int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, float* out, void* workspace,
                        int64_t workspace_bytes, avd_stream_t stream);
@@ -386,6 +392,9 @@ typedef struct {
     const float* to_lat_b;
     const void* const* conv_w3;        /* optional HOST array [n_blocks] (entry 0 unused): avd_conv3_weight_f32 images of the 64->64
                                         * convolutions, which then run on the bf16 matrix pipe (as in avd_vae_decode_desc); NULL = fp32 */
+    int conv_terms;                    /* as in the decode descriptor; entries 0 of the scale arrays are unused (block 0 is the fp32 4 -> 64 conv) */
+    const float* conv_w_scale;
+    const float* conv_a_scale;
 } avd_vae_encode_desc;
 int64_t avd_vae_encode_workspace_bytes(const avd_vae_encode_desc* d);
 int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, float* z, void* workspace,

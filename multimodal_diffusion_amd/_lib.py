@@ -72,7 +72,8 @@ class VaeDecodeDesc(C.Structure):
                 ("conv_w", C.POINTER(C.c_void_p)), ("conv_b", C.POINTER(C.c_void_p)),
                 ("gn_w", C.POINTER(C.c_void_p)), ("gn_b", C.POINTER(C.c_void_p)),
                 ("to_img_w", C.c_void_p), ("to_img_b", C.c_void_p),
-                ("conv_w3", C.POINTER(C.c_void_p))]
+                ("conv_w3", C.POINTER(C.c_void_p)), ("conv_terms", C.c_int),
+                ("conv_w_scale", C.POINTER(C.c_float)), ("conv_a_scale", C.POINTER(C.c_float))]
 
 
 class VaeEncodeDesc(C.Structure):
@@ -82,7 +83,8 @@ class VaeEncodeDesc(C.Structure):
                 ("conv_w", C.POINTER(C.c_void_p)), ("conv_b", C.POINTER(C.c_void_p)),
                 ("gn_w", C.POINTER(C.c_void_p)), ("gn_b", C.POINTER(C.c_void_p)),
                 ("to_lat_w", C.c_void_p), ("to_lat_b", C.c_void_p),
-                ("conv_w3", C.POINTER(C.c_void_p))]
+                ("conv_w3", C.POINTER(C.c_void_p)), ("conv_terms", C.c_int),
+                ("conv_w_scale", C.POINTER(C.c_float)), ("conv_a_scale", C.POINTER(C.c_float))]
 
 
 ABI_VERSION = 4
@@ -134,6 +136,7 @@ SIGNATURES = {
     "avd_attn_fwd_qkv_f16x2_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "avd_conv3_weight_bytes": (_L, []),
     "avd_conv3_weight_f32": (_I, [_P, _P, _P]),
+    "avd_conv3_weight_f16x2_f32": (_I, [_P, _P, _F, _P]),
     "avd_vae_decode_workspace_bytes": (_L, [C.POINTER(VaeDecodeDesc)]),
     "avd_vae_decode_f32": (_I, [C.POINTER(VaeDecodeDesc), _P, _P, _P, _L, _P]),
     "avd_vae_encode_workspace_bytes": (_L, [C.POINTER(VaeEncodeDesc)]),

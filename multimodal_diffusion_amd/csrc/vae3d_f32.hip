@@ -408,11 +408,30 @@ struct Conv3Args {
     float* Y;                  // NDHWC fp32 [B, T, H, W, 64]
     float* part;
     int T, H, W, tiles;
+    // f16x2 (TERMS 3, two fp16 planes at a power-of-two scale, avd_common.h): the sums are multiplied by ab_inv = 1 / (s_act s_w);
+    // when the activation scale was derived on the device (decoder block 0) a_inv_dev points at 1 / s_act and ab_inv is 1 / s_w
+    float ab_inv;
+    const float* a_inv_dev;
 };
+
+// scale slot in the workspace: [0] max |x|, [1] (max row norm, unused), [2] s, [3] 1 / s
+__global__ void pow2_scale_kernel(float* ws) {
+    const float amax = ws[0] * 1.01f;
+    float s = 1.0f;
+    if (amax > 0.f) {
+        float e = 15.0f - ceilf(log2f(amax));
+        e = fminf(fmaxf(e, -100.f), 100.f);
+        s = exp2f(e);
+    }
+    if (!(amax == amax) || amax > 3.0e38f) s = __builtin_nanf("");      // NaN / inf input: poison the image, never saturate silently
+    ws[2] = s;
+    ws[3] = 1.0f / s;
+}
 
 // Wt [64 out][27 taps][64 in] fp32 -> weight image: stage kt = 2*tap + half holds [plane][out][4 chunks of 8 in-channels],
 // chunk c of row `out` at slot c ^ ((out>>2)&3)
-__global__ __launch_bounds__(256) void conv3_weight_kernel(const float* __restrict__ Wt, unsigned char* __restrict__ img) {
+template <bool F16>
+__global__ __launch_bounds__(256) void conv3_weight_kernel(const float* __restrict__ Wt, unsigned char* __restrict__ img, float sc) {
     const int i = blockIdx.x * 256 + threadIdx.x;          // one thread = 8 in-channels of one (stage, out)
     if (i >= 54 * 64 * 4) return;
     const int c = i & 3, out = (i >> 2) & 63, kt = i >> 8;
@@ -421,27 +440,43 @@ __global__ __launch_bounds__(256) void conv3_weight_kernel(const float* __restri
     const float* src = Wt + ((int64_t)out * 27 + tap) * VC + half * 32 + c * 8;
     *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(src);
     *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(src + 4);
-    u32x4 Hh, Mi, Lo;
-    split8(v, Hh, Mi, Lo);
     unsigned char* dst = img + (int64_t)kt * W3_STAGE + out * 64 + ((c ^ ((out >> 2) & 3)) << 4);
-    *reinterpret_cast<u32x4*>(dst) = Hh;
-    *reinterpret_cast<u32x4*>(dst + 4096) = Mi;
-    *reinterpret_cast<u32x4*>(dst + 8192) = Lo;
+    if constexpr (F16) {
+        u32x4 Hh, Lo;
+        split8_h2(v, sc, Hh, Lo);
+        *reinterpret_cast<u32x4*>(dst) = Hh;
+        *reinterpret_cast<u32x4*>(dst + 4096) = Lo;
+    } else {
+        u32x4 Hh, Mi, Lo;
+        split8(v, Hh, Mi, Lo);
+        *reinterpret_cast<u32x4*>(dst) = Hh;
+        *reinterpret_cast<u32x4*>(dst + 4096) = Mi;
+        *reinterpret_cast<u32x4*>(dst + 8192) = Lo;
+    }
 }
 
-__device__ __forceinline__ void store_act3(unsigned char* X3, int64_t pv, int c8, const float* v) {
-    u32x4 Hh, Mi, Lo;
-    split8(v, Hh, Mi, Lo);
+template <bool F16>
+__device__ __forceinline__ void store_act3(unsigned char* X3, int64_t pv, int c8, const float* v, float sc) {
     unsigned char* dst = X3 + pv * A3_ROWB + c8 * 16;
-    *reinterpret_cast<u32x4*>(dst) = Hh;
-    *reinterpret_cast<u32x4*>(dst + 128) = Mi;
-    *reinterpret_cast<u32x4*>(dst + 256) = Lo;
+    if constexpr (F16) {
+        u32x4 Hh, Lo;
+        split8_h2(v, sc, Hh, Lo);
+        *reinterpret_cast<u32x4*>(dst) = Hh;
+        *reinterpret_cast<u32x4*>(dst + 128) = Lo;
+    } else {
+        u32x4 Hh, Mi, Lo;
+        split8(v, Hh, Mi, Lo);
+        *reinterpret_cast<u32x4*>(dst) = Hh;
+        *reinterpret_cast<u32x4*>(dst + 128) = Mi;
+        *reinterpret_cast<u32x4*>(dst + 256) = Lo;
+    }
 }
 
 // trilinear upsample into the interior of the act3 buffer (same arithmetic as upsample_pad_kernel, 8 channels per thread)
+template <bool F16>      // F16: the image scale is read from the device (sc_dev[0], written by pow2_scale_kernel)
 __global__ __launch_bounds__(256) void upsample_pad3_kernel(const float* __restrict__ hlow, unsigned char* __restrict__ X3,
                                                             int Tp, int Hp_, int Wp_, int T, int H, int W, float st,
-                                                            float sh, float sw, int64_t total8) {
+                                                            float sh, float sw, int64_t total8, const float* __restrict__ sc_dev) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total8) return;
     const int c8 = (int)(i & 7);
@@ -466,13 +501,14 @@ __global__ __launch_bounds__(256) void upsample_pad3_kernel(const float* __restr
         o[4 * q] = r[0]; o[4 * q + 1] = r[1]; o[4 * q + 2] = r[2]; o[4 * q + 3] = r[3];
     }
     const int64_t pv = (((int64_t)smp * (T + 2) + t + 1) * (H + 2) + h + 1) * (W + 2) + w + 1;
-    store_act3(X3, pv, c8, o);
+    store_act3<F16>(X3, pv, c8, o, F16 ? sc_dev[0] : 0.f);
 }
 
 // GroupNorm apply: Y (NDHWC fp32) -> interior of the act3 buffer feeding the next conv (a chunk of 8 channels = one group)
+template <bool F16>
 __global__ __launch_bounds__(256) void gn_apply_pad3_kernel(const float* __restrict__ Y, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            unsigned char* __restrict__ X3, int T, int H, int W, int64_t total8) {
+                                                            unsigned char* __restrict__ X3, int T, int H, int W, int64_t total8, float sc) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total8) return;
     const int c8 = (int)(i & 7);
@@ -491,14 +527,17 @@ __global__ __launch_bounds__(256) void gn_apply_pad3_kernel(const float* __restr
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = (y[e] - mean) * rstd * gm[e] + bt[e];
     const int64_t pv = (((int64_t)smp * (T + 2) + t + 1) * (H + 2) + h + 1) * (W + 2) + w + 1;
-    store_act3(X3, pv, c8, o);
+    store_act3<F16>(X3, pv, c8, o, sc);
 }
 
 // conv 3x3x3 64 -> 64 + bias + GELU + GroupNorm partial statistics, bf16x3.  128 voxels x 64 out per block, 4 waves (64 x 32 each),
 // K-stage = half a tap (32 channels = two MFMA k-steps), two 36 KiB LDS stages, two blocks per CU.
 // LDS image of a stage: A [plane][128 voxels][64 B], W [plane][64 out][64 B]; 16-byte chunk c of row r at slot c ^ ((r>>2)&3).
+template <int TERMS>     // 6: bf16x3; 3: f16x2 (planes h, l of the same buffers; the third plane is neither moved nor read)
 __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
     constexpr int BM = VBM, WM = 64, WN = 32, TM = 2;
+    constexpr int NPL = s3_planes(TERMS);
+    constexpr bool F16 = TERMS == 3;
     constexpr int A_ST = 3 * BM * 64, STAGE = A_ST + W3_STAGE;       // 24 KiB + 12 KiB
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
@@ -534,13 +573,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
         const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
         const int64_t offA = (int64_t)((dt * Hp + dh) * Wp + dw) * A3_ROWB + half * 64;   // same shift for every voxel of the tile
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 2 * NPL; ++i) {
             const int plane = i >> 1, rs = i & 1;
             __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(a_src[rs] + offA + plane * 128),
                                              AVD_LDS_PTR(as + plane * (BM * 64) + (wave + 4 * rs) * 1024), 16, 0, 0);
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < NPL; ++j) {
             const int r = wave + 4 * j;
             __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(g.W3 + (int64_t)kt * W3_STAGE + r * 1024 + lane * 16),
                                              AVD_LDS_PTR(as + A_ST + r * 1024), 16, 0, 0);
@@ -574,20 +613,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
         const unsigned char* st = smem3 + cur * STAGE;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            bf16x8 af[TM][3], bf[3];
+            bf16x8 af[TM][NPL], bf[NPL];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int p = 0; p < 3; ++p)
+                for (int p = 0; p < NPL; ++p)
                     af[i][p] = *reinterpret_cast<const bf16x8*>(st + p * (BM * 64) + a_row[i] + (((2 * s + hi) ^ a_sw[i]) << 4));
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(st + p * 4096 + b_row + (((2 * s + hi) ^ b_sw) << 4));
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+            for (int p = 0; p < NPL; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(st + p * 4096 + b_row + (((2 * s + hi) ^ b_sw) << 4));
+            constexpr int NT = F16 ? 3 : 6;
+            constexpr int PA[6] = {F16 ? 0 : 2, F16 ? 1 : 0, F16 ? 0 : 1, 1, 0, 0};      // f16x2: hl, lh, hh
+            constexpr int PB[6] = {F16 ? 1 : 0, F16 ? 0 : 2, F16 ? 0 : 1, 0, 1, 0};
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA[t]], bf[PB[t]], acc[i], 0, 0, 0);
+                for (int i = 0; i < TM; ++i) acc[i] = mma16<F16>(af[i][PA[t]], bf[PB[t]], acc[i]);
         }
         __builtin_amdgcn_s_waitcnt(0x0f70);
         __syncthreads();
@@ -606,11 +646,13 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
     const int cr = lane / LPR, cc = (lane % LPR) * 4;
     const int n = wn * WN + cc;
     const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+    const float ab_inv = F16 ? g.ab_inv * (g.a_inv_dev ? g.a_inv_dev[0] : 1.0f) : 1.0f;
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int v = tile * BM + wm * WM + cr + it * RPI;
         f32x4 y = *reinterpret_cast<const f32x4*>(slab + (cr + it * RPI) * CLD + cc);
+        if constexpr (F16) y *= ab_inv;
         y += bv;
 #pragma unroll
         for (int e = 0; e < 4; ++e) y[e] = gelu_erf(y[e]);
@@ -631,14 +673,42 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
     }
 }
 
+// launch of one 64 -> 64 convolution on the 16-bit matrix pipe (terms 0 / 6: bf16x3, 3: f16x2)
+static LdsAttr g_conv3_attr[2];      // dynamic-LDS limit of conv3d_k3_bf16x3_kernel<6> / <3> (per device)
+static int conv3_launch(const Conv3Args& a3, int terms, int B, int tiles, double flops, hipStream_t st) {
+    constexpr int lds3 = 2 * (3 * VBM * 64 + W3_STAGE);
+    if (terms == 3) {
+        if (int rc = g_conv3_attr[1].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<3>), lds3, "conv3d f16x2")) return rc;
+        static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<3>");
+        ProfScope prof(tag, flops, st);
+        hipLaunchKernelGGL(conv3d_k3_bf16x3_kernel<3>, dim3((unsigned)(B * tiles)), dim3(256), lds3, st, a3);
+    } else {
+        if (int rc = g_conv3_attr[0].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<6>), lds3, "conv3d bf16x3")) return rc;
+        static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<6>");
+        ProfScope prof(tag, flops, st);
+        hipLaunchKernelGGL(conv3d_k3_bf16x3_kernel<6>, dim3((unsigned)(B * tiles)), dim3(256), lds3, st, a3);
+    }
+    AVD_CHECK_LAUNCH("conv3d (split operands)");
+    return AVD_OK;
+}
+static int check_conv_terms(int terms, const float* w_scale, const float* a_scale, int n_blocks, int first, bool first_runtime) {
+    AVD_REQUIRE(terms == 0 || terms == 6 || terms == 3, AVD_EINVAL, "vae: conv_terms must be 0 / 6 (bf16x3) or 3 (f16x2), got %d", terms);
+    if (terms != 3) return AVD_OK;
+    AVD_REQUIRE(w_scale && a_scale, AVD_EINVAL, "vae: conv_terms 3 (f16x2) needs conv_w_scale and conv_a_scale");
+    for (int b = first; b < n_blocks; ++b) {
+        AVD_REQUIRE(w_scale[b] > 0.f && w_scale[b] < __builtin_inff(), AVD_EINVAL, "vae: conv_w_scale[%d] must be positive and finite", b);
+        if (!(first_runtime && b == first))
+            AVD_REQUIRE(a_scale[b] > 0.f && a_scale[b] < __builtin_inff(), AVD_EINVAL, "vae: conv_a_scale[%d] must be positive and finite", b);
+    }
+    return AVD_OK;
+}
+
 static inline int64_t a256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 struct VaePlan {
     int T, H, W, tiles;
     int64_t THW, pad_b, y_b, hlow_b, part_b, stats_b, total;
 };
-
-static LdsAttr g_conv3_attr;      // dynamic-LDS limit of conv3d_k3_bf16x3_kernel (per device)
 
 static int vae_plan(const avd_vae_decode_desc* d, VaePlan& p) {
     AVD_REQUIRE(d, AVD_EINVAL, "vae_decode: null descriptor");
@@ -656,7 +726,7 @@ static int vae_plan(const avd_vae_decode_desc* d, VaePlan& p) {
     p.y_b = a256((int64_t)d->B * p.THW * VC * 4);
     p.hlow_b = a256((int64_t)d->B * d->Tp * d->Hp * d->Wp * VC * 4);
     p.part_b = a256((int64_t)d->B * p.tiles * 2 * VG * 2 * 4);
-    p.stats_b = a256((int64_t)d->B * VG * 2 * 4);
+    p.stats_b = a256((int64_t)d->B * VG * 2 * 4) + 256;       // + the scale slot of the f16x2 decoder (4 floats)
     p.total = p.pad_b + p.y_b + p.hlow_b + p.part_b + p.stats_b;
     return AVD_OK;
 }
@@ -668,8 +738,16 @@ using namespace avd;
 extern "C" int64_t avd_conv3_weight_bytes(void) { return W3_BYTES; }
 extern "C" int avd_conv3_weight_f32(const float* w_tap_major, void* img, avd_stream_t stream) {
     AVD_REQUIRE(w_tap_major && img && aligned16(w_tap_major) && aligned16(img), AVD_EINVAL, "conv3_weight: bad pointer");
-    hipLaunchKernelGGL(conv3_weight_kernel, dim3(54), dim3(256), 0, static_cast<hipStream_t>(stream), w_tap_major,
-                       static_cast<unsigned char*>(img));
+    hipLaunchKernelGGL(conv3_weight_kernel<false>, dim3(54), dim3(256), 0, static_cast<hipStream_t>(stream), w_tap_major,
+                       static_cast<unsigned char*>(img), 0.f);
+    AVD_CHECK_LAUNCH("conv3_weight");
+    return AVD_OK;
+}
+extern "C" int avd_conv3_weight_f16x2_f32(const float* w_tap_major, void* img, float scale, avd_stream_t stream) {
+    AVD_REQUIRE(w_tap_major && img && aligned16(w_tap_major) && aligned16(img), AVD_EINVAL, "conv3_weight: bad pointer");
+    AVD_REQUIRE(scale > 0.f && scale < __builtin_inff(), AVD_EINVAL, "conv3_weight: the f16x2 image scale must be positive and finite");
+    hipLaunchKernelGGL(conv3_weight_kernel<true>, dim3(54), dim3(256), 0, static_cast<hipStream_t>(stream), w_tap_major,
+                       static_cast<unsigned char*>(img), scale);
     AVD_CHECK_LAUNCH("conv3_weight");
     return AVD_OK;
 }
@@ -697,10 +775,14 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
     float* stats = reinterpret_cast<float*>(w + p.pad_b + p.y_b + p.hlow_b + p.part_b);
     const int B = d->B;
 
-    const bool s3 = d->conv_w3 != nullptr;                  // bf16x3 convolutions: Xp is the act3 buffer (384 B per voxel)
+    const bool s3 = d->conv_w3 != nullptr;                  // split-operand convolutions: Xp is the act3 buffer (384 B per voxel)
+    const bool h2 = s3 && d->conv_terms == 3;               // f16x2: two fp16 planes of that buffer, scaled
     unsigned char* X3 = reinterpret_cast<unsigned char*>(w);
-    if (s3)
+    float* scale_ws = reinterpret_cast<float*>(w + p.total - 256);     // {max |from_lat(z)|, -, s, 1 / s} of the f16x2 decoder's first image
+    if (s3) {
         for (int blk = 0; blk < d->n_blocks; ++blk) AVD_REQUIRE(d->conv_w3[blk], AVD_EINVAL, "vae_decode: null conv_w3[%d]", blk);
+        if (int rc = check_conv_terms(d->conv_terms, d->conv_w_scale, d->conv_a_scale, d->n_blocks, 0, true)) return rc;
+    }
     // zero halo (whole padded buffer; interiors are overwritten below, the halo stays zero for every conv)
     {
         hipError_t e = hipMemsetAsync(Xp, 0, (size_t)B * (p.T + 2) * (p.H + 2) * (p.W + 2) * (s3 ? A3_ROWB : VC * 4), st);
@@ -716,11 +798,24 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
         AVD_CHECK_LAUNCH("fromlat");
     }
     if (s3) {
+        if (h2) {
+            // The first conv's input is a trilinear interpolation (a convex combination) of from_lat(z): its magnitude is bounded by
+            // max |from_lat(z)|, which depends on the data — the power-of-two image scale is derived from it on the device
+            if (int rc = weight_bounds_f32(hlow, (int64_t)B * d->Tp * d->Hp * d->Wp, VC, scale_ws, st)) return rc;
+            hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, st, scale_ws);
+            AVD_CHECK_LAUNCH("pow2_scale");
+        }
         const int64_t total8 = (int64_t)B * p.THW * 8;
         static const int tag = prof_tag_id("upsample_pad3_kernel");
         ProfScope prof(tag, 6.0 * (double)B * p.THW * VC, st);
-        hipLaunchKernelGGL(upsample_pad3_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, hlow, X3, d->Tp, d->Hp, d->Wp,
-                           p.T, p.H, p.W, (float)d->Tp / (float)p.T, (float)d->Hp / (float)p.H, (float)d->Wp / (float)p.W, total8);
+        if (h2)
+            hipLaunchKernelGGL(upsample_pad3_kernel<true>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, hlow, X3, d->Tp, d->Hp,
+                               d->Wp, p.T, p.H, p.W, (float)d->Tp / (float)p.T, (float)d->Hp / (float)p.H, (float)d->Wp / (float)p.W, total8,
+                               scale_ws + 2);
+        else
+            hipLaunchKernelGGL(upsample_pad3_kernel<false>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, hlow, X3, d->Tp, d->Hp,
+                               d->Wp, p.T, p.H, p.W, (float)d->Tp / (float)p.T, (float)d->Hp / (float)p.H, (float)d->Wp / (float)p.W, total8,
+                               nullptr);
         AVD_CHECK_LAUNCH("upsample_pad3");
     } else {
         const int64_t total4 = (int64_t)B * p.THW * (VC / 4);
@@ -733,17 +828,15 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
     }
     constexpr int stage_lds = 2 * (VBM + VC) * VBK * 4, epi_lds = 4 * 64 * 36 * 4;
     constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
-    constexpr int lds3 = 2 * (3 * VBM * 64 + W3_STAGE);
-    if (s3)
-        if (int rc = g_conv3_attr.ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel), lds3, "vae_decode")) return rc;
     for (int blk = 0; blk < d->n_blocks; ++blk) {
         ConvArgs a{Xp, d->conv_w[blk], d->conv_b[blk], Y, part, p.T, p.H, p.W, p.tiles};
         if (s3) {
-            Conv3Args a3{X3, static_cast<const unsigned char*>(d->conv_w3[blk]), d->conv_b[blk], Y, part, p.T, p.H, p.W, p.tiles};
-            static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel");
-            ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st);
-            hipLaunchKernelGGL(conv3d_k3_bf16x3_kernel, dim3((unsigned)(B * p.tiles)), dim3(256), lds3, st, a3);
-            AVD_CHECK_LAUNCH("conv3d_bf16x3");
+            Conv3Args a3{X3, static_cast<const unsigned char*>(d->conv_w3[blk]), d->conv_b[blk], Y, part, p.T, p.H, p.W, p.tiles, 1.f, nullptr};
+            if (h2) {
+                a3.ab_inv = blk == 0 ? 1.0f / d->conv_w_scale[0] : 1.0f / (d->conv_w_scale[blk] * d->conv_a_scale[blk]);
+                a3.a_inv_dev = blk == 0 ? scale_ws + 3 : nullptr;
+            }
+            if (int rc = conv3_launch(a3, h2 ? 3 : 6, B, p.tiles, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st)) return rc;
         } else {
             static const int tag = prof_tag_id("conv3d_k3_gelu_stats_kernel<64>");
             ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st);
@@ -757,8 +850,12 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
             const int64_t total8 = (int64_t)B * p.THW * 8;
             static const int tag = prof_tag_id("gn_apply_pad3_kernel");
             ProfScope prof(tag, 10.0 * (double)B * p.THW * VC, st);
-            hipLaunchKernelGGL(gn_apply_pad3_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
-                               d->gn_b[blk], X3, p.T, p.H, p.W, total8);
+            if (h2)
+                hipLaunchKernelGGL(gn_apply_pad3_kernel<true>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
+                                   d->gn_b[blk], X3, p.T, p.H, p.W, total8, d->conv_a_scale[blk + 1]);
+            else
+                hipLaunchKernelGGL(gn_apply_pad3_kernel<false>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
+                                   d->gn_b[blk], X3, p.T, p.H, p.W, total8, 0.f);
             AVD_CHECK_LAUNCH("gn_apply_pad3");
         } else if (blk + 1 < d->n_blocks) {
             const int64_t total4 = (int64_t)B * p.THW * (VC / 4);
@@ -836,10 +933,13 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
     const int B = d->B, T = d->T, H = d->H, W = d->W;
     const int64_t padvox = (int64_t)B * (T + 2) * (H + 2) * (W + 2);
 
-    const bool s3 = d->conv_w3 != nullptr && d->n_blocks > 1;     // bf16x3 for the 64 -> 64 convolutions (block 0 is 4 -> 64, fp32)
+    const bool s3 = d->conv_w3 != nullptr && d->n_blocks > 1;     // split operands for the 64 -> 64 convolutions (block 0 is 4 -> 64, fp32)
+    const bool h2 = s3 && d->conv_terms == 3;
     unsigned char* X3 = reinterpret_cast<unsigned char*>(Xp);
-    if (s3)
+    if (s3) {
         for (int blk = 1; blk < d->n_blocks; ++blk) AVD_REQUIRE(d->conv_w3[blk], AVD_EINVAL, "vae_encode: null conv_w3[%d]", blk);
+        if (int rc = check_conv_terms(d->conv_terms, d->conv_w_scale, d->conv_a_scale, d->n_blocks, 1, false)) return rc;
+    }
     hipError_t e = hipMemsetAsync(Xp4, 0, (size_t)padvox * 16, st);
     if (e == hipSuccess && d->n_blocks > 1) e = hipMemsetAsync(Xp, 0, (size_t)padvox * (s3 ? A3_ROWB : VC * 4), st);
     if (e != hipSuccess) return set_error(AVD_ELAUNCH, "vae_encode memset: %s", hipGetErrorString(e));
@@ -851,16 +951,12 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
     }
     constexpr int stage_lds = 2 * (VBM + VC) * VBK * 4, epi_lds = 4 * 64 * 36 * 4;
     constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
-    constexpr int lds3 = 2 * (3 * VBM * 64 + W3_STAGE);
-    if (s3)
-        if (int rc = g_conv3_attr.ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel), lds3, "vae_encode")) return rc;
     for (int blk = 0; blk < d->n_blocks; ++blk) {
         ConvArgs a{blk == 0 ? Xp4 : Xp, d->conv_w[blk], d->conv_b[blk], Y, part, T, H, W, p.tiles};
         if (blk > 0 && s3) {
-            Conv3Args a3{X3, static_cast<const unsigned char*>(d->conv_w3[blk]), d->conv_b[blk], Y, part, T, H, W, p.tiles};
-            static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel");
-            ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st);
-            hipLaunchKernelGGL(conv3d_k3_bf16x3_kernel, dim3((unsigned)(B * p.tiles)), dim3(256), lds3, st, a3);
+            Conv3Args a3{X3, static_cast<const unsigned char*>(d->conv_w3[blk]), d->conv_b[blk], Y, part, T, H, W, p.tiles,
+                         h2 ? 1.0f / (d->conv_w_scale[blk] * d->conv_a_scale[blk]) : 1.f, nullptr};
+            if (int rc = conv3_launch(a3, h2 ? 3 : 6, B, p.tiles, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st)) return rc;
         } else if (blk == 0) {
             static const int tag = prof_tag_id("conv3d_k3_gelu_stats_kernel<4>");
             ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * d->in_ch, st);
@@ -878,8 +974,12 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
             const int64_t total8 = (int64_t)B * p.THW * 8;
             static const int tag = prof_tag_id("gn_apply_pad3_kernel");
             ProfScope prof(tag, 10.0 * (double)B * p.THW * VC, st);
-            hipLaunchKernelGGL(gn_apply_pad3_kernel, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
-                               d->gn_b[blk], X3, T, H, W, total8);
+            if (h2)
+                hipLaunchKernelGGL(gn_apply_pad3_kernel<true>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
+                                   d->gn_b[blk], X3, T, H, W, total8, d->conv_a_scale[blk + 1]);
+            else
+                hipLaunchKernelGGL(gn_apply_pad3_kernel<false>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
+                                   d->gn_b[blk], X3, T, H, W, total8, 0.f);
             AVD_CHECK_LAUNCH("gn_apply_pad3");
         } else if (blk + 1 < d->n_blocks) {
             const int64_t total4 = (int64_t)B * p.THW * (VC / 4);

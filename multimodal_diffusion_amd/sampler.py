@@ -63,7 +63,7 @@ def build_components(cfg: Dict, device: torch.device, vid_vae: Optional[nn.Modul
     if vid_vae is None and "video" in cfg:
         from .vae_video3d import VideoVAE
         vid_vae = VideoVAE.from_config(cfg["video"]).to(device).eval()
-        vid_vae.matmul = "f32" if matmul == "f32" else "bf16x3"     # the decoder has fp32-MFMA and bf16x3 convolutions
+        vid_vae.matmul = matmul if matmul in ("f32", "bf16x3", "f16x2") else "bf16x3"     # bf16 / strict: the exact three-plane convolutions
     if aud_codec is None and "audio" in cfg:
         from .audio_codec import AudioCodec
         aud_codec = AudioCodec.from_config(cfg["audio"]).to(device).eval()

@@ -73,7 +73,8 @@ class VideoVAE(nn.Module):
         self._ws: Optional[torch.Tensor] = None
         self._relaid = {}
         self._conv3 = {}
-        # "f32": convolutions on fp32 MFMA; "bf16x3": decoder convolutions on the bf16 matrix pipe with exactly split operands
+        # "f32": convolutions on fp32 MFMA; "bf16x3": the 64 -> 64 convolutions on the bf16 matrix pipe with exactly split operands;
+        # "f16x2": the same convolutions with two scaled fp16 planes per operand and three product terms (csrc/vae3d_f32.hip)
         self.matmul = "f32"
 
     @classmethod
@@ -157,12 +158,10 @@ class VideoVAE(nn.Module):
         d.conv_w, d.conv_b = C.cast(cw, C.POINTER(C.c_void_p)), C.cast(cb, C.POINTER(C.c_void_p))
         d.gn_w, d.gn_b = C.cast(gw, C.POINTER(C.c_void_p)), C.cast(gb, C.POINTER(C.c_void_p))
         d.to_lat_w, d.to_lat_b = tlw.data_ptr(), tlb.data_ptr()
-        if self.matmul == "bf16x3" and nb > 1:
-            imgs = [self._conv3_image(i, enc=True) for i in range(1, nb)]
-            keep.extend(imgs)
-            c3 = (C.c_void_p * nb)(None, *[t.data_ptr() for t in imgs])
-            keep.append(c3)
-            d.conv_w3 = C.cast(c3, C.POINTER(C.c_void_p))
+        if self.matmul not in ("f32", "bf16x3", "f16x2"):
+            raise ValueError(f"matmul must be 'f32', 'bf16x3' or 'f16x2', got {self.matmul!r}")
+        if self.matmul != "f32" and nb > 1:
+            self._split_conv_desc(d, keep, nb, 1, True, (self.cfg.enc_base // 8) * T2 * H2 * W2)
         d.B = 1
         per = L.lib().avd_vae_encode_workspace_bytes(C.byref(d))
         if per < 0:
@@ -195,17 +194,53 @@ class VideoVAE(nn.Module):
         return 0.5 * torch.mean(-1 - logv + mu.pow(2) + logv.exp())
 
     # conv weight [out,in,kt,kh,kw] -> [out][kt][kh][kw][in] (K = tap-major, channel-minor), cached per parameter version
-    def _conv3_image(self, i: int, enc: bool = False) -> torch.Tensor:
-        """bf16x3 weight image of decoder (or encoder) conv i (csrc/vae3d_f32.hip), rebuilt when the parameter changes."""
+    def _conv3_image(self, i: int, enc: bool = False, f16x2: bool = False):
+        """Weight image of decoder (or encoder) conv i for the split-operand convolutions (csrc/vae3d_f32.hip): three bf16 planes,
+        or (f16x2) two fp16 planes at a power-of-two scale derived from max|w|.  Rebuilt when the parameter changes.
+        Returns (image, scale); scale is 0.0 for bf16x3."""
         w = (self.enc_net if enc else self.dec_net)[i][0].weight
-        key = (enc, i, w.data_ptr(), w._version, str(w.device))
-        hit = self._conv3.get((enc, i))
+        key = (enc, i, w.data_ptr(), w._version, str(w.device), f16x2)
+        hit = self._conv3.get((enc, i, f16x2))
         if hit is None or hit[0] != key:
             img = torch.empty(L.lib().avd_conv3_weight_bytes(), dtype=torch.uint8, device=w.device)
             src = self._enc_weight(i) if enc else self._tap_major(i)
-            L.check(L.lib().avd_conv3_weight_f32(src.data_ptr(), img.data_ptr(), L.stream_ptr(w.device)))
-            self._conv3[(enc, i)] = (key, img)
-        return self._conv3[(enc, i)][1]
+            scale = 0.0
+            if f16x2:
+                from . import functional as Fn
+                scale = Fn.f16x2_scale(Fn.weight_bounds([src.reshape(src.shape[0], -1)])[0][0])
+                L.check(L.lib().avd_conv3_weight_f16x2_f32(src.data_ptr(), img.data_ptr(), scale, L.stream_ptr(w.device)))
+            else:
+                L.check(L.lib().avd_conv3_weight_f32(src.data_ptr(), img.data_ptr(), L.stream_ptr(w.device)))
+            self._conv3[(enc, i, f16x2)] = (key, img, scale)
+        hit = self._conv3[(enc, i, f16x2)]
+        return hit[1], hit[2]
+
+    def _gn_scales(self, net, first: int, group_elems: int):
+        """f16x2 scales of the images the GroupNorm-apply pass writes (the input of conv first, first + 1, ...):
+        |(x - mean) / sqrt(var + eps)| <= sqrt(n - 1) over the n elements of one group of one sample, so
+        |GroupNorm(x)| <= sqrt(n - 1) max|gamma| + max|beta| for every input.  Entries below `first` are placeholders."""
+        from . import functional as Fn
+        out = [1.0] * first
+        for i in range(first, len(net)):
+            (g, _), (b, _) = Fn.weight_bounds([net[i - 1][2].weight, net[i - 1][2].bias])
+            out.append(Fn.f16x2_scale(max(group_elems - 1, 1) ** 0.5 * g + b))
+        return out
+
+    def _split_conv_desc(self, d, keep, nb: int, first: int, enc: bool, group_elems: int) -> None:
+        """conv_w3 (+ the f16x2 scale tables) of a decode / encode descriptor for blocks first .. nb - 1."""
+        h2 = self.matmul == "f16x2"
+        pairs = [self._conv3_image(i, enc=enc, f16x2=h2) for i in range(first, nb)]
+        keep.extend(p[0] for p in pairs)
+        c3 = (C.c_void_p * nb)(*([None] * first + [p[0].data_ptr() for p in pairs]))
+        keep.append(c3)
+        d.conv_w3 = C.cast(c3, C.POINTER(C.c_void_p))
+        if h2:
+            ws = (C.c_float * nb)(*([1.0] * first + [p[1] for p in pairs]))
+            as_ = (C.c_float * nb)(*self._gn_scales(self.enc_net if enc else self.dec_net, max(first, 1), group_elems))
+            keep.extend([ws, as_])
+            d.conv_terms = 3
+            d.conv_w_scale = C.cast(ws, C.POINTER(C.c_float))
+            d.conv_a_scale = C.cast(as_, C.POINTER(C.c_float))
 
     def _tap_major(self, i: int) -> torch.Tensor:
         w = self.dec_net[i][0].weight
@@ -250,14 +285,10 @@ class VideoVAE(nn.Module):
         d.conv_w, d.conv_b = C.cast(cw, C.POINTER(C.c_void_p)), C.cast(cb, C.POINTER(C.c_void_p))
         d.gn_w, d.gn_b = C.cast(gw, C.POINTER(C.c_void_p)), C.cast(gb, C.POINTER(C.c_void_p))
         d.to_img_w, d.to_img_b = tiw.data_ptr(), L.dev_f32(self.to_img.bias.detach()).data_ptr()
-        if self.matmul == "bf16x3":
-            imgs = [self._conv3_image(i) for i in range(nb)]
-            keep.extend(imgs)
-            c3 = (C.c_void_p * nb)(*[t.data_ptr() for t in imgs])
-            keep.append(c3)
-            d.conv_w3 = C.cast(c3, C.POINTER(C.c_void_p))
-        elif self.matmul != "f32":
-            raise ValueError(f"matmul must be 'f32' or 'bf16x3', got {self.matmul!r}")
+        if self.matmul not in ("f32", "bf16x3", "f16x2"):
+            raise ValueError(f"matmul must be 'f32', 'bf16x3' or 'f16x2', got {self.matmul!r}")
+        if self.matmul != "f32":
+            self._split_conv_desc(d, keep, nb, 0, False, (self.cfg.dec_base // 8) * T * H * W)
         # chunk the batch so the NDHWC activations (2 x 0.85 GB per 48x256x256 sample) stay inside the budget
         d.B = 1
         per = L.lib().avd_vae_decode_workspace_bytes(C.byref(d))

@@ -535,3 +535,78 @@ def test_weight_bounds_kernel(dev):
     assert math.isnan(a) and math.isnan(n)
     with pytest.raises(L.AvdError):
         Fn.f16x2_scale(a)
+
+
+# ------------------------------------------------------------------------------------------------- VideoVAE convolutions on f16x2
+def test_vae_decode_f16x2(dev):
+    """Decoder convolutions with two scaled fp16 planes per operand (the first image's scale derived on the device from
+    max |from_lat(z)|, the later ones from the GroupNorm bound): golden fixture, ragged tiles, chunked batch, and the fp64 oracle at
+    128x128 next to the fp32-MFMA decoder; latents of magnitude 1e4 and 1e-4 (the scale follows the data); NaN stays loud."""
+    import multimodal_diffusion_amd as A
+    from conftest import load_golden, split_weights
+    from test_gpu_parity import G, _vae_from
+    g = load_golden("g11_vae_decode.npz")
+    vae = _vae_from(split_weights(g)["w"], dev)
+    vae.matmul = "f16x2"
+    x = vae.decode(G(g["z"], dev)).cpu()
+    assert rel_err(x, g["x"]) < TOL
+    assert rel_err(vae.decode(G(g["z"][:1], dev), out_size=(6, 24, 40)).cpu(), g["x_odd"]) < TOL
+    assert torch.equal(vae.decode(G(g["z"], dev), max_workspace_bytes=1).cpu(), x)
+    W = R.synth_vae_decoder(seed=3, n_blocks=3)
+    z = torch.randn(1, 8, 3, 16, 16, generator=torch.Generator().manual_seed(4))
+    errs = {}
+    for scale in (1.0, 1e4, 1e-4):
+        ref = R.vae_decode((z * scale).double(), {k: v.double() for k, v in W.items()}, n_blocks=3, out_act="tanh")
+        for mode in ("f32", "f16x2"):
+            v = A.VideoVAE(A.VideoVAEConfig(dec_blocks=3, out_activation="tanh")).eval()
+            v.load_state_dict(W, strict=False)
+            v.matmul = mode
+            out = v.to(dev).decode((z * scale).to(dev)).cpu()
+            assert torch.isfinite(out).all()
+            errs[(mode, scale)] = rel_err(out, ref)
+        print(f"vae decode |z| x {scale:g}: f16x2 {errs[('f16x2', scale)]:.3e}, fp32-MFMA {errs[('f32', scale)]:.3e}")
+        assert errs[("f16x2", scale)] < TOL and errs[("f16x2", scale)] < 3.0 * errs[("f32", scale)] + 1e-7, errs
+    zn = z.clone()
+    zn[0, 3, 1, 5, 5] = float("nan")
+    v.matmul = "f16x2"
+    assert torch.isnan(v.decode(zn.to(dev))).any()
+
+
+def test_vae_encode_f16x2(dev):
+    """Encoder with its 64 -> 64 convolution(s) on f16x2: golden fixture at the fp32 encoder's tolerance."""
+    import warnings
+    import multimodal_diffusion_amd as A
+    from conftest import load_golden, split_weights
+    from test_gpu_parity import G
+    g = load_golden("g12_vae_encode.npz")
+    vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval()
+    vae.load_state_dict(split_weights(g)["w"], strict=False)
+    vae = vae.to(dev)
+    z32 = vae.encode(G(g["x"], dev)).cpu()
+    vae.matmul = "f16x2"
+    z2 = vae.encode(G(g["x"], dev)).cpu()
+    assert rel_err(z2, g["z"]) < TOL and rel_err(z2, z32) < 2e-5
+    assert not torch.equal(z2, z32) or len(vae.enc_net) == 1, "f16x2 encoder path did not run"
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert rel_err(vae.encode(G(g["x_crop"], dev)).cpu(), g["z_crop"]) < TOL
+
+
+def test_vae_decode_f16x2_256(dev):
+    """256x256 (the bench's clip size), one sample: f16x2 against the fp32-MFMA decoder (which test_vae_decode_256_vs_oracle pins
+    to the oracle) — the GroupNorm bound at n = 25 M elements per group leaves typical values 12 binades below the fp16 top."""
+    import multimodal_diffusion_amd as A
+    torch.manual_seed(0)
+    vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval().to(dev)
+    with torch.no_grad():
+        for p in vae.parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn_like(p))
+    z = torch.randn(1, 8, 12, 32, 32, generator=torch.Generator().manual_seed(6)).to(dev)
+    x32 = vae.decode(z)
+    vae.matmul = "f16x2"
+    x2 = vae.decode(z)
+    assert torch.isfinite(x2).all() and not torch.equal(x2, x32)
+    e = rel_err(x2.cpu(), x32.cpu().double())
+    print(f"vae decode 256x256, f16x2 vs fp32-MFMA: {e:.3e}")
+    assert e < 2e-5

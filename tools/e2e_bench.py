@@ -31,7 +31,7 @@ sched = su.make_sampling_schedule(1000, S)
 z0 = torch.randn(B, 8, 12, size // 8, size // 8, generator=torch.Generator().manual_seed(1)).to(dev)
 za = torch.randn(B, 8, 150, generator=torch.Generator().manual_seed(2)).to(dev)
 for mode in ("f32", "bf16x3", "f16x2"):
-    vae.matmul = "f32" if mode == "f32" else "bf16x3"       # the decoder has the fp32-MFMA and the bf16x3 convolutions
+    vae.matmul = mode
     eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=tdim, target="video", latent_shape=tuple(z0.shape),
                           prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=mode)
     eng.set_prompt(za)

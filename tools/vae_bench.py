@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--iters", type=int, default=5)
-ap.add_argument("--matmul", default="f32", choices=["f32", "bf16x3"])
+ap.add_argument("--matmul", default="f32", choices=["f32", "bf16x3", "f16x2"])
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
