@@ -32,6 +32,7 @@ prof bf16x3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt --ma
 prof f32 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt --matmul f32
 prof vae $ROOT/tools/vae_bench.py --iters 5
 prof vae3 $ROOT/tools/vae_bench.py --iters 5 --matmul bf16x3
+prof vae2 $ROOT/tools/vae_bench.py --iters 5 --matmul f16x2
 
 step "PMC traffic (separate FETCH_SIZE / WRITE_SIZE passes; single-stream launches as in the roofline pass)"
 python3 tools/pmc_traffic.py --out gpurun_out/$TAG/traffic_f16x2.json > $OUT/traffic_f16x2.txt 2>&1 || exit 1
