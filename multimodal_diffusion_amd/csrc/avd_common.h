@@ -270,6 +270,8 @@ int attn_f32_split3(const float* qkv, void* out3, int B, int N, int H, int Dh, f
 // sk_ws / sk_floats: optional scratch for the stream-K launch (gemm_bf16x3_sk_floats() floats); null = plain tiling
 int64_t gemm_bf16x3_sk_floats();
 extern int g_s3_streamk;
+extern int g_s3_stagger;
+extern thread_local bool t_s3_two_streams;
 // terms == 3 (f16x2): ab_scale = (A image scale) x (W image scale), c_scale = scale of the image written (if one is written)
 int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* img, int64_t M, int tokens, int heads, int K, float qscale,
                      int terms, hipStream_t st, float* sk_ws = nullptr, int64_t sk_floats = 0, float ab_scale = 1.f, float c_scale = 1.f);

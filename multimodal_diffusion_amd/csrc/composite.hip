@@ -477,6 +477,7 @@ extern "C" const char* avd_last_error(void) { return g_err; }
 extern "C" int avd_tune_set(const char* key, int64_t value) {
     AVD_REQUIRE(key, AVD_EINVAL, "tune_set: null key");
     if (!strcmp(key, "s3_streamk")) { g_s3_streamk = (int)value; return AVD_OK; }
+    if (!strcmp(key, "s3_stagger")) { g_s3_stagger = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_tile")) { g_gemm_force_tile = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_persist")) { g_gemm_persist = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_stages")) { g_gemm_stages = (int)value; return AVD_OK; }
@@ -575,6 +576,7 @@ extern "C" int avd_denoise_step_f32(const avd_step_desc* s, const float* z, cons
         const int64_t hc = p.core / 2, hh = p.head / 2;
         AVD_HIP(hipEventRecord(g_fork, st));
         AVD_HIP(hipStreamWaitEvent(g_aux, g_fork, 0));
+        struct TwoStreams { TwoStreams() { t_s3_two_streams = true; } ~TwoStreams() { t_s3_two_streams = false; } } two_streams_scope;
         for (int half = 0; half < 2; ++half) {
             hipStream_t hs = half ? g_aux : st;
             float* xh = X2 + half * half_rows;
