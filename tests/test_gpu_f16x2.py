@@ -610,3 +610,21 @@ def test_vae_decode_f16x2_256(dev):
     e = rel_err(x2.cpu(), x32.cpu().double())
     print(f"vae decode 256x256, f16x2 vs fp32-MFMA: {e:.3e}")
     assert e < 2e-5
+
+
+def test_block_stagger_changes_timing_only(dev, full):
+    """The start-up stagger of the co-resident blocks of the 256x128 split GEMM (automatic on single-stream launches; `s3_stagger`
+    forces it) is a scheduling device: results are bit-identical with it off, automatic and forced large."""
+    from multimodal_diffusion_amd import _lib as L
+    ws, _ = full
+    core, _, _, _ = _full_modules(dev, ws)
+    core.matmul = "f16x2"
+    x = torch.randn(64, 421, 512, generator=torch.Generator().manual_seed(21)).to(dev)      # 26,944 rows: two generations of blocks
+    outs = []
+    for v in (0, -1, 40):
+        L.check(L.lib().avd_tune_set(b"s3_stagger", v))
+        try:
+            outs.append(core(x))
+        finally:
+            L.check(L.lib().avd_tune_set(b"s3_stagger", -1))
+    assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
