@@ -157,7 +157,7 @@ def parse_args(argv=None):
                          "(exact operand split); f32: fp32 MFMA everywhere; bf16x3_strict: all nine product terms; "
                          "bf16: plain bf16 operands (reduced precision, reported error)")
     ap.add_argument("--attn", default="default", choices=["default", "fp8"],
-                    help="fp8: e4m3 QK^T / PV in the attention (reduced precision, BASELINE C5; needs a split matmul mode; never the default)")
+                    help="fp8: e4m3 QK^T / PV in the attention (reduced precision, BASELINE C5; needs a split matmul mode — f16x2, bf16x3 or bf16; never the default)")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra (untimed-region) measurements of the other matmul modes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -255,7 +255,7 @@ def main():
         e = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=tdim, target="video",
                             latent_shape=lat, prompt_tokens=na, alpha_bar=abar, guidance=args.guidance,
                             split_streams=split, matmul=mode,
-                            attn=args.attn if mode not in ("f32", "f16x2") else "default")
+                            attn=args.attn if mode != "f32" else "default")
         e.set_prompt(z_a0)
         e.begin(sched)
         return e

@@ -275,6 +275,9 @@ int avd_attn_fwd_qkv3_f32(const void* qkv3, float* out, void* out3, int B, int N
 int64_t avd_attn_fp8_workspace_bytes(int B, int N, int H);
 int avd_attn_fwd_fp8_f32(const void* qkv3, void* workspace, int64_t workspace_bytes, float* out, void* out3, int B, int N, int H,
                          int n_query, avd_stream_t stream);
+/* the same with an f16x2 q|k|v image at scale qkv_scale (avd_gemm_f16x2_qkv_f32); out2 != NULL: the result as an f16x2 image at out_scale */
+int avd_attn_fwd_fp8_f16x2_f32(const void* qkv, void* workspace, int64_t workspace_bytes, float* out, void* out2, int B, int N,
+                               int H, int n_query, float qkv_scale, float out_scale, avd_stream_t stream);
 /* C = act(A W^T + bias) (+ residual), A3/W3 split3 images of A [M,K] and W [N,K]; N % 256 == 0, K % 16 == 0.
  * C3 == NULL: fp32 row-major C [M,N], act AVD_ACT_NONE, residual optional (may alias C).
  * C3 != NULL: the result is written as the split3 image of [M,N] instead (bias required, act AVD_ACT_NONE or AVD_ACT_GELU,

@@ -127,6 +127,7 @@ SIGNATURES = {
     "avd_attn_fwd_qkv3_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "avd_attn_fp8_workspace_bytes": (_L, [_I, _I, _I]),
     "avd_attn_fwd_fp8_f32": (_I, [_P, _P, _L, _P, _P, _I, _I, _I, _I, _P]),
+    "avd_attn_fwd_fp8_f16x2_f32": (_I, [_P, _P, _L, _P, _P, _I, _I, _I, _I, _F, _F, _P]),
     "avd_gemm_bf16x3_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     "avd_weight_bounds_f32": (_I, [_P, _L, _I, _P, _P]),
     "avd_split_f16x2_f32": (_I, [_P, _P, _L, _I, _F, _P]),

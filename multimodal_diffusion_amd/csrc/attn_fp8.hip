@@ -45,10 +45,11 @@ __device__ __forceinline__ i64 pack_fp8x8(const float* v) {
 // multiplies in one MFMA (4 hi + (j & 3) + 8 (j >> 2), j = 0..7) are the 8 contiguous bytes at 8 hi
 __device__ __forceinline__ int f8_vpos(int k) { return (k & 3) | ((k & 4) << 1) | ((k & 8) >> 1); }
 
-// one block per (part, sample, head, 64-row tile) of the qkv3 image
+// one block per (part, sample, head, 64-row tile) of the qkv3 image.  F16: the image holds two fp16 planes at scale 1 / inv_s (f16x2)
+template <bool F16>
 __global__ __launch_bounds__(256) void quant_fp8_kernel(const unsigned char* __restrict__ img, unsigned char* __restrict__ q8,
                                                         unsigned char* __restrict__ k8, unsigned char* __restrict__ v8, int Bt, int N,
-                                                        int Npad, int H) {
+                                                        int Npad, int H, float inv_s) {
     __shared__ __attribute__((aligned(16))) unsigned char vt[64 * 64];
     const int ntile = Npad / 64;
     int w = blockIdx.x;
@@ -66,12 +67,21 @@ __global__ __launch_bounds__(256) void quant_fp8_kernel(const unsigned char* __r
         const int c = c0 + cc;
         const int slot = (c ^ qkv3_swizzle(part, n < N ? n : N - 1)) << 4;
         float v[8];
-        const u32x4 ph = *reinterpret_cast<const u32x4*>(src + slot), pm = *reinterpret_cast<const u32x4*>(src + 128 + slot),
-                    pl = *reinterpret_cast<const u32x4*>(src + 256 + slot);
+        const u32x4 ph = *reinterpret_cast<const u32x4*>(src + slot), pm = *reinterpret_cast<const u32x4*>(src + 128 + slot);
+        if constexpr (F16) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[2 * e] = (bf16_lo(ph[e]) + bf16_lo(pm[e])) + bf16_lo(pl[e]);
-            v[2 * e + 1] = (bf16_hi(ph[e]) + bf16_hi(pm[e])) + bf16_hi(pl[e]);
+            for (int e = 0; e < 4; ++e) {
+                const f32x2 a = unpk_f16(ph[e]), c = unpk_f16(pm[e]);
+                v[2 * e] = (a[0] + c[0]) * inv_s;
+                v[2 * e + 1] = (a[1] + c[1]) * inv_s;
+            }
+        } else {
+            const u32x4 pl = *reinterpret_cast<const u32x4*>(src + 256 + slot);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                v[2 * e] = (bf16_lo(ph[e]) + bf16_lo(pm[e])) + bf16_lo(pl[e]);
+                v[2 * e + 1] = (bf16_hi(ph[e]) + bf16_hi(pm[e])) + bf16_hi(pl[e]);
+            }
         }
         if (n >= N) {
 #pragma unroll
@@ -109,10 +119,10 @@ __global__ __launch_bounds__(256) void quant_fp8_kernel(const unsigned char* __r
     }
 }
 
-template <bool SPLIT_OUT>
+template <int SPLIT_OUT>      // 0: fp32 out; 1: bf16x3 (split3) image; 2: f16x2 image at scale o_scale
 __global__ __launch_bounds__(F8_NW * 64, 2) void attn_fp8_kernel(const unsigned char* __restrict__ q8, const unsigned char* __restrict__ k8,
                                                                  const unsigned char* __restrict__ v8, float* __restrict__ out, int N,
-                                                                 int Npad, int H, int n_query, int nqb) {
+                                                                 int Npad, int H, int n_query, int nqb, float o_scale) {
     constexpr int NW = F8_NW;
     __shared__ __attribute__((aligned(16))) unsigned char Ks[4096];
     __shared__ __attribute__((aligned(16))) unsigned char Vs[4096];
@@ -242,7 +252,7 @@ __global__ __launch_bounds__(F8_NW * 64, 2) void attn_fp8_kernel(const unsigned 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / (l_tot * F8_PSCALE);
     const int d = H * F8_DH;
-    if constexpr (SPLIT_OUT) {
+    if constexpr (SPLIT_OUT != 0) {
         float ch[8][4];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4)
@@ -262,7 +272,10 @@ __global__ __launch_bounds__(F8_NW * 64, 2) void attn_fp8_kernel(const unsigned 
                 v[e] = hi ? recv : ch[c][e];
                 v[4 + e] = hi ? ch[c + 1][e] : recv;
             }
-            if (q_row < n_query) store_split8(o3, (int64_t)b * N + q_row, h * F8_DH + 8 * (c + hi), d, v);
+            if (q_row < n_query) {
+                if constexpr (SPLIT_OUT == 2) store_split8_h2(o3, (int64_t)b * N + q_row, h * F8_DH + 8 * (c + hi), d, v, o_scale);
+                else store_split8(o3, (int64_t)b * N + q_row, h * F8_DH + 8 * (c + hi), d, v);
+            }
         }
     } else if (q_row < n_query) {
         float* dst = out + ((int64_t)b * N + q_row) * d + h * F8_DH + 4 * hi;
@@ -278,9 +291,14 @@ __global__ __launch_bounds__(F8_NW * 64, 2) void attn_fp8_kernel(const unsigned 
 
 int64_t attn_fp8_ws_bytes(int B, int N, int H) { return (int64_t)3 * B * H * qkv3_npad(N) * 64; }
 
-// qkv3: the image avd_gemm_bf16x3_qkv3_f32 wrote; ws: attn_fp8_ws_bytes scratch; out3 != null: split3 image of the result
-int attn_fp8(const void* qkv3, void* ws, int64_t ws_bytes, float* out, void* out3, int B, int N, int H, int n_query, hipStream_t st) {
+// qkv3: the image avd_gemm_bf16x3_qkv3_f32 (img_terms != 3) or avd_gemm_f16x2_qkv_f32 (img_terms 3, at scale img_scale) wrote;
+// ws: attn_fp8_ws_bytes scratch; out3 != null: the result as an operand image of the same kind (f16x2: at scale out_scale)
+int attn_fp8(const void* qkv3, void* ws, int64_t ws_bytes, float* out, void* out3, int B, int N, int H, int n_query, hipStream_t st,
+             int img_terms, float img_scale, float out_scale) {
     AVD_REQUIRE(qkv3 && ws && (out || out3), AVD_EINVAL, "attn_fp8: null pointer");
+    AVD_REQUIRE(img_scale > 0.f && img_scale < __builtin_inff() && out_scale > 0.f && out_scale < __builtin_inff(), AVD_EINVAL,
+                "attn_fp8: image scales must be positive and finite");
+    const bool h2 = img_terms == 3;
     AVD_REQUIRE(B > 0 && N > 0 && H > 0, AVD_EINVAL, "attn_fp8: bad dims B=%d N=%d H=%d", B, N, H);
     AVD_REQUIRE(n_query >= 0 && n_query <= N, AVD_EINVAL, "attn_fp8: n_query=%d outside [0,%d]", n_query, N);
     AVD_REQUIRE(ws_bytes >= attn_fp8_ws_bytes(B, N, H), AVD_EWORKSPACE, "attn_fp8: workspace %lld < %lld bytes", (long long)ws_bytes,
@@ -296,18 +314,25 @@ int attn_fp8(const void* qkv3, void* ws, int64_t ws_bytes, float* out, void* out
     {
         static const int tag = prof_tag_id("quant_fp8_kernel");
         ProfScope prof(tag, (double)per * 3 * 7.0, st);
-        hipLaunchKernelGGL(quant_fp8_kernel, dim3((unsigned)(3 * B * H * ntile)), dim3(256), 0, st, static_cast<const unsigned char*>(qkv3), q8, k8,
-                           v8, B, N, Npad, H);
+        if (h2)
+            hipLaunchKernelGGL(quant_fp8_kernel<true>, dim3((unsigned)(3 * B * H * ntile)), dim3(256), 0, st, static_cast<const unsigned char*>(qkv3),
+                               q8, k8, v8, B, N, Npad, H, 1.0f / img_scale);
+        else
+            hipLaunchKernelGGL(quant_fp8_kernel<false>, dim3((unsigned)(3 * B * H * ntile)), dim3(256), 0, st, static_cast<const unsigned char*>(qkv3),
+                               q8, k8, v8, B, N, Npad, H, 1.0f);
         AVD_CHECK_LAUNCH("quant_fp8");
     }
     const int nqb = (n_query + 32 * F8_NW - 1) / (32 * F8_NW);
     static const int tag = prof_tag_id("attn_fp8_kernel");
     ProfScope prof(tag, 4.0 * (double)B * H * (double)n_query * N * F8_DH, st);
-    if (out3)
-        hipLaunchKernelGGL(attn_fp8_kernel<true>, dim3(nqb * H * B), dim3(F8_NW * 64), 0, st, q8, k8, v8, static_cast<float*>(out3), N, Npad, H,
-                           n_query, nqb);
+    if (out3 && h2)
+        hipLaunchKernelGGL(attn_fp8_kernel<2>, dim3(nqb * H * B), dim3(F8_NW * 64), 0, st, q8, k8, v8, static_cast<float*>(out3), N, Npad, H,
+                           n_query, nqb, out_scale);
+    else if (out3)
+        hipLaunchKernelGGL(attn_fp8_kernel<1>, dim3(nqb * H * B), dim3(F8_NW * 64), 0, st, q8, k8, v8, static_cast<float*>(out3), N, Npad, H,
+                           n_query, nqb, 1.f);
     else
-        hipLaunchKernelGGL(attn_fp8_kernel<false>, dim3(nqb * H * B), dim3(F8_NW * 64), 0, st, q8, k8, v8, out, N, Npad, H, n_query, nqb);
+        hipLaunchKernelGGL(attn_fp8_kernel<0>, dim3(nqb * H * B), dim3(F8_NW * 64), 0, st, q8, k8, v8, out, N, Npad, H, n_query, nqb, 1.f);
     AVD_CHECK_LAUNCH("attn_fp8");
     return AVD_OK;
 }
@@ -320,5 +345,9 @@ extern "C" int64_t avd_attn_fp8_workspace_bytes(int B, int N, int H) {
 }
 extern "C" int avd_attn_fwd_fp8_f32(const void* qkv3, void* workspace, int64_t workspace_bytes, float* out, void* out3, int B, int N, int H,
                                     int n_query, avd_stream_t stream) {
-    return avd::attn_fp8(qkv3, workspace, workspace_bytes, out, out3, B, N, H, n_query, static_cast<hipStream_t>(stream));
+    return avd::attn_fp8(qkv3, workspace, workspace_bytes, out, out3, B, N, H, n_query, static_cast<hipStream_t>(stream), 6, 1.f, 1.f);
+}
+extern "C" int avd_attn_fwd_fp8_f16x2_f32(const void* qkv, void* workspace, int64_t workspace_bytes, float* out, void* out2, int B, int N, int H,
+                                          int n_query, float qkv_scale, float out_scale, avd_stream_t stream) {
+    return avd::attn_fp8(qkv, workspace, workspace_bytes, out, out2, B, N, H, n_query, static_cast<hipStream_t>(stream), 3, qkv_scale, out_scale);
 }

@@ -278,7 +278,8 @@ int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* im
 int64_t qkv3_bytes(int B, int N, int H);
 // fp8 attention (attn_fp8.hip): reads the same qkv3 image, needs attn_fp8_ws_bytes(B, N, H) of scratch
 int64_t attn_fp8_ws_bytes(int B, int N, int H);
-int attn_fp8(const void* qkv3, void* ws, int64_t ws_bytes, float* out, void* out3, int B, int N, int H, int n_query, hipStream_t st);
+int attn_fp8(const void* qkv3, void* ws, int64_t ws_bytes, float* out, void* out3, int B, int N, int H, int n_query, hipStream_t st,
+             int img_terms = 6, float img_scale = 1.f, float out_scale = 1.f);
 // terms == 3: img_scale = scale of the qkv image, out_scale = scale of the image written to out3
 int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms, hipStream_t st,
                 float img_scale = 1.f, float out_scale = 1.f);

@@ -156,7 +156,6 @@ static int check_core(const avd_core_weights* w) {
     AVD_REQUIRE(w->split_terms == 0 || w->split_terms == 6 || w->split_terms == 9 || w->split_terms == 1 || w->split_terms == 3, AVD_EINVAL,
                 "core: split_terms must be 0/6 (default), 9 (strict), 1 (plain bf16) or 3 (f16x2), got %d", w->split_terms);
     if (w->split_terms == 3) {
-        AVD_REQUIRE(w->attn_mode == 0, AVD_EUNSUPPORTED, "core: the fp8 attention reads bf16 planes; it cannot follow split_terms 3 (f16x2)");
         for (int l = 0; l < w->n_layers; ++l)
             for (int i = 0; i < 8; ++i) {
                 const float s = w->blocks[l].f16x2_scale[i];
@@ -215,7 +214,7 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
             if (int rc = gemm_bf16x3_qkv3(hs, b.in_proj_weight3, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, terms, st, skw, skf,
                                           h2 ? s_n1 * w_in : 1.f, s_qkv)) return rc;
             if (w->attn_mode == 1) {
-                if (int rc = attn_fp8(qkv, skw, skf * 4, nullptr, hs, B, N, H, nq, st)) return rc;
+                if (int rc = attn_fp8(qkv, skw, skf * 4, nullptr, hs, B, N, H, nq, st, terms, s_qkv, s_qkv)) return rc;
             } else {
                 if (int rc = attn_bf16x3(qkv, nullptr, hs, B, N, H, nq, terms, st, s_qkv, s_qkv)) return rc;
             }

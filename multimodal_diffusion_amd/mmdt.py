@@ -220,9 +220,7 @@ class MMDiT(nn.Module):
         if self.attn not in ("default", "fp8"):
             raise ValueError(f"attn must be 'default' or 'fp8', got {self.attn!r}")
         if self.attn == "fp8" and self.matmul == "f32":
-            raise ValueError("attn='fp8' reads the qkv3 image of the split matmul modes: use matmul='bf16x3' (or 'bf16')")
-        if self.attn == "fp8" and self.matmul == "f16x2":
-            raise ValueError("attn='fp8' reads bf16 planes: it cannot be combined with matmul='f16x2'")
+            raise ValueError("attn='fp8' reads the qkv3 image of the split matmul modes: use matmul='f16x2', 'bf16x3' or 'bf16'")
         return 1 if self.attn == "fp8" else 0
 
     # ---- pointer table for the composite (rebuilt per call: parameters may have moved) ----

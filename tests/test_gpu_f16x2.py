@@ -628,3 +628,33 @@ def test_block_stagger_changes_timing_only(dev, full):
         finally:
             L.check(L.lib().avd_tune_set(b"s3_stagger", -1))
     assert torch.isfinite(outs[0]).all() and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+def test_fp8_attention_on_f16x2_images(dev, full):
+    """BASELINE C5 as named (512x512, "fp8 MFMA attention"), with f16x2 projections: the e4m3 attention reads the f16x2 q|k|v image
+    and writes its result as an f16x2 image.  Reduced precision — the error against the fp32 oracle is reported and bounded loosely
+    (5e-2 of max|z|), and must be of the size the bf16x3 + fp8 combination has."""
+    import multimodal_diffusion_amd as A
+    ws, mods = full
+    core, head, av, aa = mods
+    g = torch.Generator().manual_seed(512)
+    B = 8
+    z_v = torch.randn(B, 8, 12, 64, 64, generator=g)
+    z_a = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn = torch.tensor([982, 500, 16, 999] * 2)
+    tp = torch.tensor([966, 480, -1, 979] * 2)
+    ref = R.denoise_step_a2v(z_v[:1], z_a[:1], tn[:1], tp[:1], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"], core=ws["core"],
+                             head=ws["head"], n_layers=8, n_heads=8, guidance=3.5)
+    errs = {}
+    for matmul, attn in (("f16x2", "default"), ("f16x2", "fp8"), ("bf16x3", "fp8")):
+        eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z_v.shape),
+                              prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=matmul, attn=attn)
+        eng.set_prompt(z_a.to(dev))
+        out = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)).cpu()
+        assert torch.isfinite(out).all()
+        errs[(matmul, attn)] = rel_err(out[:1], ref)
+    print(f"C5 step: {errs}")
+    assert errs[("f16x2", "default")] < TOL
+    assert 1e-5 < errs[("f16x2", "fp8")] < 5e-2
+    assert errs[("f16x2", "fp8")] < 2.0 * errs[("bf16x3", "fp8")]

@@ -19,7 +19,8 @@ $B --matmul bf16 --no-alt --cpu-steps 1 > $OUT/bench_bf16.json 2>> $OUT/bench.er
 $B --size 64 --batch 32 --sampler-steps 100 --steps 100 --warmup 10 --matmul bf16 --no-alt > $OUT/bench_c2_bf16.json 2>> $OUT/bench.err || exit 1
 $B --size 64 --batch 32 --sampler-steps 100 --steps 100 --warmup 10 --matmul f32 --no-alt > $OUT/bench_c2_f32.json 2>> $OUT/bench.err || exit 1
 $B --size 512 --batch 8 --steps 20 --warmup 3 --no-alt --cpu-steps 1 > $OUT/bench_c5.json 2>> $OUT/bench.err || exit 1
-$B --size 512 --batch 8 --steps 20 --warmup 3 --matmul bf16x3 --attn fp8 --no-alt --cpu-steps 1 > $OUT/bench_c5_fp8attn.json 2>> $OUT/bench.err || exit 1
+$B --size 512 --batch 8 --steps 20 --warmup 3 --attn fp8 --no-alt --cpu-steps 1 > $OUT/bench_c5_fp8attn.json 2>> $OUT/bench.err || exit 1
+$B --size 512 --batch 8 --steps 20 --warmup 3 --matmul bf16x3 --attn fp8 --no-alt --cpu-steps 1 > $OUT/bench_c5_bf16x3_fp8attn.json 2>> $OUT/bench.err || exit 1
 $B --size 512 --batch 8 --steps 20 --warmup 3 --matmul bf16x3 --no-alt --no-cpu-baseline > $OUT/bench_c5_bf16x3.json 2>> $OUT/bench.err || exit 1
 $B --size 128 --batch 32 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_128.json 2>> $OUT/bench.err || exit 1
 $B --size 32 --batch 4 --steps 200 --warmup 20 --no-alt --cpu-steps 3 --matmul f32 > $OUT/bench_c1_gpu.json 2>> $OUT/bench.err || exit 1
