@@ -658,3 +658,31 @@ def test_fp8_attention_on_f16x2_images(dev, full):
     assert errs[("f16x2", "default")] < TOL
     assert 1e-5 < errs[("f16x2", "fp8")] < 5e-2
     assert errs[("f16x2", "fp8")] < 2.0 * errs[("bf16x3", "fp8")]
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_f16x2_fuzz_weight_and_input_scales(dev, seed):
+    """Seeded fuzz of the scale derivation: a 2-layer core whose every parameter tensor is multiplied by an independent log-uniform
+    factor in [1e-2, 1e2] (gains, weights, biases), inputs of magnitude 10^U(-3, 4) — the f16x2 forward must stay finite and no
+    further from the fp64 oracle than 3x the fp32-MFMA path's own error (or the parity tolerance, whichever is larger)."""
+    import multimodal_diffusion_amd as A
+    g = torch.Generator().manual_seed(1000 + seed)
+    ws = R.synth_weights(seed=seed, n_layers=2)["core"]
+    for k in ws:
+        if k.endswith("in_proj_weight"):
+            f = 10.0 ** float(torch.empty(1).uniform_(-1.0, 0.5, generator=g))     # keeps the attention logits conditioned
+        else:
+            f = 10.0 ** float(torch.empty(1).uniform_(-2.0, 2.0, generator=g))
+        ws[k] = ws[k] * f
+    x = torch.randn(16, 421, 512, generator=g) * 10.0 ** float(torch.empty(1).uniform_(-3.0, 4.0, generator=g))
+    ref = R.mmdit_forward(x[:1].double(), {k: v.double() for k, v in ws.items()}, 2, 8)
+    errs = {}
+    for mode in ("f32", "f16x2"):
+        core = A.MMDiT(d_model=512, n_layers=2, n_heads=8, mlp_ratio=4.0).eval()
+        core.load_state_dict(ws, strict=True)
+        core = core.to(dev)
+        core.matmul = mode
+        y = core(x.to(dev)).cpu()
+        assert torch.isfinite(y).all(), mode
+        errs[mode] = rel_err(y[:1], ref)
+    assert errs["f16x2"] < max(TOL, 3.0 * errs["f32"]), errs
