@@ -168,6 +168,7 @@ struct S3Args {
     int tokN, tokNpad, heads;   // EPI_QKV3: tokens per sample, padded tokens per sample, heads (N == 3 * heads * 64)
     float qscale;               // EPI_QKV3: factor folded into q before it is split (softmax scale * log2 e)
     int stagger;                // 256x128 kernel: the block in the odd wave slots of its SIMDs starts stagger x 1024 cycles late
+    int first_gen;              // ... if it belongs to the first generation of blocks (blockIdx < 2 x CUs of the device)
     int terms;                  // 6 (default), 9 (strict), 1 (plain bf16 operands) or 3 (f16x2 images)
     float ab_inv, c_scale;      // terms 3: 1 / (A image scale x W image scale) applied to the sums; scale of the image written
     // stream-K (sk_partial != null): the grid is one resident block per slot; XCD x owns a contiguous range of tiles and its
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_b_kernel(S3Args g) {
         // block's epilogue runs beside the other's loop.
         unsigned hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-        if ((hwid & 1u) && blockIdx.x < 512)          // first generation only (2 slots x 256 CUs); later blocks inherit the phase
+        if ((hwid & 1u) && (int)blockIdx.x < g.first_gen)      // first generation only (2 slots per CU); later blocks inherit the phase
             for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(16);
     }
     const int ng = g.K >> 4;
@@ -1091,7 +1092,8 @@ static int launch_s3t(const S3Args& a, hipStream_t st) {
     const int64_t nwg = (nbm + g.sm - 1) / g.sm * g.sm * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
     g.stagger = 0;
-    if (tile && nbm * g.nbn >= 2 * 512)
+    g.first_gen = 2 * sk_cu_count();
+    if (tile && g.first_gen > 0 && nbm * g.nbn >= 2 * g.first_gen)
         g.stagger = g_s3_stagger >= 0 ? g_s3_stagger : t_s3_two_streams ? 0 : (TERMS == 3 ? 24 : TERMS == 1 ? 12 : 48) * (a.K >= 1024 ? 2 : 1);
     // tags = the kernel names as rocprofv3 prints their template arguments (EPI, TERMS, stream-K)
     static const int tag0 = prof_tag_id("gemm_bf16x3_kernel<%d, %d, false>", EPI, TERMS), tag1 = prof_tag_id("gemm_bf16x3_b_kernel<%d, %d, false>", EPI, TERMS);
@@ -1127,7 +1129,7 @@ int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* 
     AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(C) && aligned16(C3) && aligned16(bias) && aligned16(R), AVD_EUNSUPPORTED,
                 "gemm_bf16x3: pointers must be 16-byte aligned");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, R, C,
-             static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0, 0, 0, 0, 0.f, 0, terms, 1.0f / ab_scale, c_scale, sk_ws, nullptr, 0, sk_floats};
+             static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0, 0, 0, 0, 0.f, 0, 0, terms, 1.0f / ab_scale, c_scale, sk_ws, nullptr, 0, sk_floats};
     if (C3) {
         AVD_REQUIRE((act == AVD_ACT_GELU || act == AVD_ACT_NONE) && !R && bias, AVD_EUNSUPPORTED,
                     "gemm_bf16x3: image output implies bias, act NONE or GELU, no residual");
@@ -1150,7 +1152,7 @@ int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* im
     AVD_REQUIRE(gemm_bf16x3_supported(M, N, K), AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: need 3*heads*64 %% 256 == 0 and K %% 16 == 0");
     AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(bias) && aligned16(img), AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: alignment");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, nullptr, nullptr,
-             static_cast<unsigned char*>(img), M, N, K, 0, 0, 0, tokens, qkv3_npad(tokens), heads, qscale, 0, terms, 1.0f / ab_scale, c_scale,
+             static_cast<unsigned char*>(img), M, N, K, 0, 0, 0, tokens, qkv3_npad(tokens), heads, qscale, 0, 0, terms, 1.0f / ab_scale, c_scale,
              sk_ws, nullptr, 0, sk_floats};
     return launch_s3<S3_EPI_QKV3>(a, st);
 }
