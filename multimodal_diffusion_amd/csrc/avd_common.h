@@ -239,9 +239,7 @@ int gemm_f32(const float* A, RowMap am, const float* W, const float* bias, const
 int gemm_f32_tube(const float* z, const TubeGather& tg, const float* W, const float* bias, float* C, RowMap cm, int64_t M, int N, int K,
                   hipStream_t st);
 
-extern int g_gemm_persist;       // 1 = persistent tile-queue launch for big GEMM grids (avd_tune_set "gemm_persist")
 extern int g_gemm_stages;        // 2 or 3 LDS stages for the 128x64 / 64x64 tiles (avd_tune_set "gemm_stages")
-extern int g_gemm_stagger_pct;   // first-generation stagger of co-resident GEMM blocks, percent of a block's MFMA time (avd_tune_set "gemm_stagger")
 extern int g_gemm_force_tile;     // -1 = automatic tile choice; 0 / 1 / 2 = 128x128 / 128x64 / 64x64 (avd_tune_set "gemm_tile")
 bool gemm_f32_fold_supported(int N, int K);
 int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm, float* C, RowMap cm,
@@ -267,14 +265,12 @@ int layernorm_act_split3_f32(const float* x, const float* gamma, const float* be
                              hipStream_t st, float h2_scale = 0.f);
 bool gemm_bf16x3_supported(int64_t M, int N, int K);
 int attn_f32_split3(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st);
-// sk_ws / sk_floats: optional scratch for the stream-K launch (gemm_bf16x3_sk_floats() floats); null = plain tiling
-int64_t gemm_bf16x3_sk_floats();
-extern int g_s3_streamk;
 extern int g_s3_stagger;
+extern int g_s3_tile;            // -1 = per epilogue; 0 / 1 = 8-wave 256x256 / 4-wave 256x128 blocks (avd_tune_set "s3_tile")
 extern thread_local bool t_s3_two_streams;
 // terms == 3 (f16x2): ab_scale = (A image scale) x (W image scale), c_scale = scale of the image written (if one is written)
 int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* img, int64_t M, int tokens, int heads, int K, float qscale,
-                     int terms, hipStream_t st, float* sk_ws = nullptr, int64_t sk_floats = 0, float ab_scale = 1.f, float c_scale = 1.f);
+                     int terms, hipStream_t st, float ab_scale = 1.f, float c_scale = 1.f);
 int64_t qkv3_bytes(int B, int N, int H);
 // fp8 attention (attn_fp8.hip): reads the same qkv3 image, needs attn_fp8_ws_bytes(B, N, H) of scratch
 int64_t attn_fp8_ws_bytes(int B, int N, int H);
@@ -284,6 +280,6 @@ int attn_fp8(const void* qkv3, void* ws, int64_t ws_bytes, float* out, void* out
 int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms, hipStream_t st,
                 float img_scale = 1.f, float out_scale = 1.f);
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
-                int act, int terms, hipStream_t st, float* sk_ws = nullptr, int64_t sk_floats = 0, float ab_scale = 1.f, float c_scale = 1.f);
+                int act, int terms, hipStream_t st, float ab_scale = 1.f, float c_scale = 1.f);
 
 }  // namespace avd

@@ -139,9 +139,9 @@ static int64_t core_ws_bytes(const avd_core_weights* w, int B, int N) {
     if (!core_use_split(w, M)) return fp32_path;
     // + split3 image of the norm / attention output, and the wide buffer must also hold the split3 image of the MLP hidden
     const int64_t wide_b = core_split_wide_bytes(w, B, N);
-    // third region: parked stream-K tiles, or (attn_mode 1) the fp8 attention's operand images — never both at once
-    const int64_t sk_b = gemm_bf16x3_sk_floats() * 4, f8_b = w->attn_mode == 1 ? attn_fp8_ws_bytes(B, N, w->n_heads) : 0;
-    const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d)) + align_up(sk_b > f8_b ? sk_b : f8_b);
+    // third region: (attn_mode 1) the fp8 attention's operand images
+    const int64_t f8_b = w->attn_mode == 1 ? attn_fp8_ws_bytes(B, N, w->n_heads) : 0;
+    const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d)) + align_up(f8_b);
     return split_path > fp32_path ? split_path : fp32_path;
 }
 
@@ -198,9 +198,7 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
         void* wide3 = qkv;
         void* hs = cs.take((split3_bytes(M, d) + 3) / 4);
         const int64_t f8_b = w->attn_mode == 1 ? attn_fp8_ws_bytes(B, N, H) : 0;
-        int64_t skf = gemm_bf16x3_sk_floats();
-        if (f8_b > skf * 4) skf = (f8_b + 3) / 4;
-        float* skw = cs.take(skf);            // parked partial tiles of the stream-K launches / fp8 attention operands
+        float* f8w = cs.take((f8_b + 3) / 4);         // fp8 attention operands (attn_mode 1 only)
         for (int l = 0; l < w->n_layers; ++l) {
             const avd_block_weights& b = w->blocks[l];
             const bool last = l == w->n_layers - 1;
@@ -211,20 +209,20 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
             const float s_n1 = h2 ? fs[4] : 0.f, s_qkv = h2 ? fs[5] : 1.f, s_n2 = h2 ? fs[6] : 0.f, s_fc1 = h2 ? fs[7] : 1.f;
             const float w_in = h2 ? fs[0] : 1.f, w_out = h2 ? fs[1] : 1.f, w_fc1 = h2 ? fs[2] : 1.f, w_fc2 = h2 ? fs[3] : 1.f;
             if (int rc = rmsnorm_split3_f32(cur, b.norm1_scale, hs, M, d, w->norm_eps, st, s_n1)) return rc;
-            if (int rc = gemm_bf16x3_qkv3(hs, b.in_proj_weight3, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, terms, st, skw, skf,
+            if (int rc = gemm_bf16x3_qkv3(hs, b.in_proj_weight3, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, terms, st,
                                           h2 ? s_n1 * w_in : 1.f, s_qkv)) return rc;
             if (w->attn_mode == 1) {
-                if (int rc = attn_fp8(qkv, skw, skf * 4, nullptr, hs, B, N, H, nq, st, terms, s_qkv, s_qkv)) return rc;
+                if (int rc = attn_fp8(qkv, f8w, f8_b, nullptr, hs, B, N, H, nq, st, terms, s_qkv, s_qkv)) return rc;
             } else {
                 if (int rc = attn_bf16x3(qkv, nullptr, hs, B, N, H, nq, terms, st, s_qkv, s_qkv)) return rc;
             }
-            if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, nullptr, M, d, d, AVD_ACT_NONE, terms, st, skw, skf,
+            if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, nullptr, M, d, d, AVD_ACT_NONE, terms, st,
                                      h2 ? s_qkv * w_out : 1.f, 1.f)) return rc;
             cur = y;
             if (int rc = rmsnorm_split3_f32(y, b.norm2_scale, hs, M, d, w->norm_eps, st, s_n2)) return rc;
-            if (int rc = gemm_bf16x3(hs, b.fc1_weight3, b.fc1_bias, nullptr, nullptr, wide3, M, hid, d, AVD_ACT_GELU, terms, st, skw, skf,
+            if (int rc = gemm_bf16x3(hs, b.fc1_weight3, b.fc1_bias, nullptr, nullptr, wide3, M, hid, d, AVD_ACT_GELU, terms, st,
                                      h2 ? s_n2 * w_fc1 : 1.f, s_fc1)) return rc;
-            if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, nullptr, M, d, hid, AVD_ACT_NONE, terms, st, skw, skf,
+            if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, nullptr, M, d, hid, AVD_ACT_NONE, terms, st,
                                      h2 ? s_fc1 * w_fc2 : 1.f, 1.f)) return rc;
         }
         return rmsnorm_f32(y, rd, w->final_norm_scale, y, rd, M, d, w->norm_eps, st);
@@ -324,18 +322,18 @@ static int head_forward(const avd_head_weights* w, const float* h, RowMap hm, in
         float* t2 = cv.take(rows * w->hidden);
         if (int rc = split3_rows_f32(h, hm, imgA, rows, w->d_in, st, asc(0))) return rc;
         if (int rc = gemm_bf16x3(imgA, w->input_proj_weight3, w->input_proj_bias, nullptr, nullptr, imgB, rows, w->hidden, w->d_in, AVD_ACT_NONE,
-                                 terms, st, nullptr, 0, h2 ? asc(0) * wsc(0) : 1.f, h2 ? asc(1) : 1.f)) return rc;
+                                 terms, st, h2 ? asc(0) * wsc(0) : 1.f, h2 ? asc(1) : 1.f)) return rc;
         void* cur = imgB;
         void* nxt = imgA;
         for (int j = 0; j < n; ++j) {
             if (int rc = gemm_bf16x3(cur, w->shared_lin_weight3[j], w->shared_lin_bias[j], nullptr, t2, nullptr, rows, w->hidden, w->hidden,
-                                     AVD_ACT_NONE, terms, st, nullptr, 0, h2 ? asc(1 + j) * wsc(1 + j) : 1.f, 1.f)) return rc;
+                                     AVD_ACT_NONE, terms, st, h2 ? asc(1 + j) * wsc(1 + j) : 1.f, 1.f)) return rc;
             if (int rc = layernorm_act_split3_f32(t2, w->shared_ln_weight[j], w->shared_ln_bias[j], nxt, rows, w->hidden, w->ln_eps, w->act, st,
                                                   asc(2 + j))) return rc;
             void* t = cur; cur = nxt; nxt = t;
         }
         return gemm_bf16x3(cur, w->out_proj_weight3, w->out_proj_bias, nullptr, out, nullptr, rows, w->d_out, w->hidden, AVD_ACT_NONE, terms, st,
-                           nullptr, 0, h2 ? asc(1 + n) * wsc(1 + n) : 1.f, 1.f);
+                           h2 ? asc(1 + n) * wsc(1 + n) : 1.f, 1.f);
     }
     float* t1 = cv.take(rows * w->hidden);
     float* t2 = cv.take(rows * w->hidden);
@@ -475,12 +473,10 @@ extern "C" const char* avd_last_error(void) { return g_err; }
 
 extern "C" int avd_tune_set(const char* key, int64_t value) {
     AVD_REQUIRE(key, AVD_EINVAL, "tune_set: null key");
-    if (!strcmp(key, "s3_streamk")) { g_s3_streamk = (int)value; return AVD_OK; }
+    if (!strcmp(key, "s3_tile")) { g_s3_tile = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_stagger")) { g_s3_stagger = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_tile")) { g_gemm_force_tile = (int)value; return AVD_OK; }
-    if (!strcmp(key, "gemm_persist")) { g_gemm_persist = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_stages")) { g_gemm_stages = (int)value; return AVD_OK; }
-    if (!strcmp(key, "gemm_stagger")) { g_gemm_stagger_pct = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_min_rows")) { g_s3_min_rows = value; return AVD_OK; }
     if (!strcmp(key, "no_fold")) { g_no_fold = value != 0; return AVD_OK; }
     return set_error(AVD_EINVAL, "tune_set: unknown key '%s'", key);

@@ -55,14 +55,6 @@ struct GemmArgs {
     int ss_in_cols;
     float ss_sqrt_d, ss_eps;
     float* ss_out;
-    // first-generation stagger (cycles per resident slot, 0 = off): blocks blockIdx >= 256 are the 2nd, 3rd ... block of their CU
-    // and start that many shader cycles late, so co-resident blocks do not run their prologues / epilogues in lockstep
-    int stagger;
-    // persistent mode (queue != null): the grid is 2 blocks per CU, each pulls tiles from its XCD's counter until the XCD's
-    // contiguous tile range is exhausted.  queue[0..7] next tile per XCD label, queue[8] blocks that have finished (the last
-    // one re-zeroes the slot for its next use).  ntiles = row blocks x column blocks.
-    unsigned int* queue;
-    int ntiles;
     TubeGather tg;          // gemm_f32_reg_kernel<..., GATHER = true> only: A rows are tube tokens of the latent at A
 #ifdef AVD_GEMM_STAMPS      // diagnostic build only (tools/micro/gemm_stamps.py): per-block phase stamps, never in the product library
     unsigned long long* dbg;
@@ -80,11 +72,6 @@ struct GemmArgs {
 #else
 #define AVD_STAMP(i) do { } while (0)
 #endif
-
-// tile-queue slots of the persistent launches: zero at module load, every launch leaves its slot zeroed again.  A slot is 16
-// words; consecutive launches take consecutive slots, so kernels that overlap on two streams never share one.
-constexpr int GEMM_QUEUE_SLOTS = 64;
-__device__ unsigned int g_gemm_queue[GEMM_QUEUE_SLOTS * 16];
 
 __device__ __forceinline__ int xcd_remap(int b, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, x = b & 7;
@@ -109,16 +96,8 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int A_PIECES = BM / 32, B_PIECES = BN / 32;   // 1-KiB pieces (8 rows x 128 B) per wave
     constexpr int STAGE = (BM + BN) * BK;                   // floats per stage
-    constexpr int TILE_BOX = (NST * STAGE > 4 * WM * (WN + 4) ? NST * STAGE : 4 * WM * (WN + 4));   // word index behind stages / slabs
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
-    if (g.stagger > 0) {
-        const int slot = blockIdx.x >> 8;
-        if (slot > 0 && slot < WPS) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime(), want = (unsigned long long)slot * g.stagger;
-            while (__builtin_amdgcn_s_memtime() - t0 < want) __builtin_amdgcn_s_sleep(64);
-        }
-    }
     AVD_STAMP(0);
 #ifdef AVD_GEMM_STAMPS
     if (threadIdx.x == 0) {
@@ -133,35 +112,9 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-    // Tile supply.  Classic: one tile per block, block ids remapped so an XCD gets a contiguous tile range.  Persistent: two
-    // blocks per CU with FIXED matrix-pipe priority (the first 256 block ids high, the rest low) pull tiles of their XCD's
-    // range from an atomic counter.  Equal co-resident blocks drift into lockstep — a block that is alone on the pipe runs
-    // twice as fast and catches up — and then run prologue and epilogue together with the pipe idle (measured: 17-21 % of
-    // the kernel).  With fixed priorities the high block runs its main loop at full speed and the low block takes exactly
-    // the slots the high one leaves: its prologue (first-stage DMA latency), its epilogue and its barrier waits.
-    const bool persist = g.queue != nullptr;
-    int* tile_box = reinterpret_cast<int*>(smem) + TILE_BOX;      // one word past stages / slabs: next tile id, block-wide
-    int xq = 0, xr = 0, xstart = 0, xcount = 0;
-    if (persist) {
-        const int x = blockIdx.x & 7;
-        xq = g.ntiles >> 3;
-        xr = g.ntiles & 7;
-        xstart = x < xr ? x * (xq + 1) : xr * (xq + 1) + (x - xr) * xq;
-        xcount = xq + (x < xr ? 1 : 0);
-        if (blockIdx.x < 256) __builtin_amdgcn_s_setprio(3);
-        if (tid == 0) *tile_box = (int)atomicAdd(g.queue + x, 1u);
-        __syncthreads();
-    }
-    for (int round = 0;; ++round) {
-    int wg;
-    if (persist) {
-        const int ticket = *tile_box;
-        if (ticket >= xcount) break;
-        wg = xstart + ticket;
-    } else {
-        if (round) break;
-        wg = xcd_remap(blockIdx.x, gridDim.x);
-    }
+    // one tile per block, block ids remapped so an XCD gets a contiguous tile range (a persistent tile queue and a
+    // first-generation stagger were measured in round 2, within +-1 % — DESIGN 4.2 — and removed from the product in round 3)
+    const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int bm = wg / g.nbn, bn = wg % g.nbn;
 
     // ---- DMA source addresses: piece p = tile rows 8p..8p+7; lane -> row 8p + lane/8, PHYSICAL chunk lane%8 ----
@@ -213,9 +166,6 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
         __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
     }
     __builtin_amdgcn_s_barrier();
-    // everyone has read this tile's id: fetch the next one now, its latency hides under the main loop
-    unsigned int next_ticket = 0;
-    if (persist && tid == 0) next_ticket = atomicAdd(g.queue + (blockIdx.x & 7), 1u);
 
     // fragment read offsets (floats): row*32 + ((2kk+hi) ^ ((row>>1)&7))*4 — conflict-free ds_read_b128
     int a_row[TM], a_sw[TM], b_row[TN], b_sw[TN];
@@ -399,18 +349,6 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
         }
     }
     }   // n < N
-    if (!persist) break;
-    if (tid == 0) *tile_box = (int)next_ticket;
-    __syncthreads();                // slabs drained before the next tile's DMA lands on them; next tile id visible
-    }   // tiles
-    if (persist && tid == 0) {
-        // the last block to leave re-zeroes the slot (every block has drawn its final ticket before it counts itself done)
-        const unsigned int done = atomicAdd(g.queue + 8, 1u);
-        if (done == gridDim.x - 1) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) __hip_atomic_store(g.queue + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     AVD_STAMP(3);
 }
 
@@ -556,26 +494,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_reg_kernel(GemmArgs g) {
 // host side
 // =====================================================================================================
 
-// device address of g_gemm_queue on the current device (looked up once per device)
-static int gemm_queue_base(unsigned int** out) {
-    static std::atomic<unsigned int*> cache[64];
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return set_error(AVD_ELAUNCH, "gemm queue: hipGetDevice: %s", hipGetErrorString(e));
-    unsigned int* p = dev < 64 ? cache[dev].load(std::memory_order_acquire) : nullptr;
-    if (!p) {
-        e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_gemm_queue));
-        if (e != hipSuccess) return set_error(AVD_ELAUNCH, "gemm queue: %s", hipGetErrorString(e));
-        if (dev < 64) cache[dev].store(p, std::memory_order_release);
-    }
-    *out = p;
-    return AVD_OK;
-}
-
 template <int BM, int BN, int WM, int WN, int EPI, int WPS, int NST>
 static int launch_dma(const GemmArgs& a, hipStream_t st) {
     constexpr int stage_lds = NST * (BM + BN) * GEMM_BK * 4, epi_lds = 4 * WM * (WN + 4) * 4;
-    constexpr int lds = (stage_lds > epi_lds ? stage_lds : epi_lds) + 16;       // + the tile box
+    constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
     static LdsAttr attr;
     auto kern = gemm_f32_dma_kernel<BM, BN, WM, WN, EPI, WPS, NST>;
     if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), lds, "gemm_f32_dma")) return rc;
@@ -583,24 +505,10 @@ static int launch_dma(const GemmArgs& a, hipStream_t st) {
     g.nbn = (a.N + BN - 1) / BN;
     const int64_t nwg = ((a.M + BM - 1) / BM) * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm grid too large");
-    // one slot's delay = the block's own MFMA issue time (K/32 tiles x TM*TN*16 MFMAs x 64 cycles), scaled by the knob
-    g.stagger = nwg > 256 ? (int)((int64_t)(a.K / GEMM_BK) * (WM / 32) * (WN / 32) * 16 * 64 * g_gemm_stagger_pct / 100) : 0;
-    // persistent launch: worth it once there are a few tiles per resident block
-    int64_t grid = nwg;
-    g.queue = nullptr;
-    g.ntiles = (int)nwg;
-    if (g_gemm_persist && nwg >= 2 * 512) {
-        static std::atomic<unsigned> seq{0};
-        unsigned int* base = nullptr;
-        if (int rc = gemm_queue_base(&base)) return rc;
-        g.queue = base + (seq.fetch_add(1) % GEMM_QUEUE_SLOTS) * 16;
-        g.stagger = 0;
-        grid = 512;
-    }
     // tag = the kernel name exactly as rocprofv3 prints its template arguments (EPI: 0 bias, 1 gelu, 2 residual)
     static const int tag = prof_tag_id("gemm_f32_dma_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, EPI, WPS, NST);
     ProfScope prof(tag, 2.0 * (double)a.M * a.N * a.K, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, st, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, g);
     AVD_CHECK_LAUNCH("gemm_f32_dma");
     return AVD_OK;
 }
@@ -640,16 +548,12 @@ unsigned long long* g_gemm_dbg = nullptr;
 extern "C" void lab_set_dbg(unsigned long long* p) { g_gemm_dbg = p; }
 extern "C" void lab_set_tile(int t);
 #endif
-int g_gemm_persist = getenv("AVD_GEMM_PERSIST") ? atoi(getenv("AVD_GEMM_PERSIST")) : 0;   // persistent tile queue for big grids
 int g_gemm_stages = getenv("AVD_GEMM_STAGES") ? atoi(getenv("AVD_GEMM_STAGES")) : 0;      // LDS ring depth of the 128x64 / 64x64 tiles: 0 = by size
-int g_gemm_stagger_pct = getenv("AVD_GEMM_STAGGER") ? atoi(getenv("AVD_GEMM_STAGGER")) : 0;
 int g_gemm_force_tile = getenv("AVD_GEMM_TILE") ? atoi(getenv("AVD_GEMM_TILE")) : -1;
 
 #ifdef AVD_GEMM_STAMPS
 extern "C" void lab_set_tile(int t) { g_gemm_force_tile = t; }
-extern "C" void lab_set_stagger(int pct) { g_gemm_stagger_pct = pct; }
 extern "C" void lab_set_stages(int n) { g_gemm_stages = n; }
-extern "C" void lab_set_persist(int n) { g_gemm_persist = n; }
 #endif
 bool gemm_f32_fold_supported(int N, int K) { return K % GEMM_BK == 0 && N % 128 == 0; }
 
@@ -670,7 +574,7 @@ int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, 
     AVD_REQUIRE(aligned16(A) && aligned16(W), AVD_EUNSUPPORTED, "gemm: A/W must be 16-byte aligned");
     AVD_REQUIRE(act == AVD_ACT_NONE || act == AVD_ACT_GELU || act == AVD_ACT_SILU, AVD_EINVAL, "gemm: bad act %d", act);
     if (M == 0) return AVD_OK;
-    GemmArgs g{A, am, W, bias, R, rm, C, cm, M, N, K, act, 0, ss_in, ss_in_cols, sqrt_d, eps, ss_out, 0, nullptr, 0};
+    GemmArgs g{A, am, W, bias, R, rm, C, cm, M, N, K, act, 0, ss_in, ss_in_cols, sqrt_d, eps, ss_out, TubeGather{}};
 #ifdef AVD_GEMM_STAMPS
     g.dbg = g_gemm_dbg;
 #endif
@@ -707,7 +611,7 @@ int gemm_f32_tube(const float* z, const TubeGather& tg, const float* W, const fl
     AVD_REQUIRE(z && W && C && M > 0 && N > 0 && K > 0, AVD_EINVAL, "gemm_tube: bad arguments");
     AVD_REQUIRE(tg.w % 4 == 0 && tg.W % 4 == 0 && K % 4 == 0 && aligned16(z) && aligned16(W), AVD_EUNSUPPORTED,
                 "gemm_tube: the gathered A load needs w %% 4 == 0, W %% 4 == 0, K %% 4 == 0 and 16-byte aligned operands");
-    GemmArgs g{z, RowMap{K, 0, 0}, W, bias, nullptr, cm, C, cm, M, N, K, AVD_ACT_NONE, 0, nullptr, 0, 1.f, 0.f, nullptr, 0, nullptr, 0, tg};
+    GemmArgs g{z, RowMap{K, 0, 0}, W, bias, nullptr, cm, C, cm, M, N, K, AVD_ACT_NONE, 0, nullptr, 0, 1.f, 0.f, nullptr, tg};
 #ifdef AVD_GEMM_STAMPS
     g.dbg = g_gemm_dbg;
 #endif

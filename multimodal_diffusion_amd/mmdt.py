@@ -4,7 +4,8 @@ Same class names, constructor kwargs, ``forward`` signatures and ``state_dict`` 
 (``blocks.{i}.norm1.scale``, ``blocks.{i}.attn.mha.in_proj_weight`` … ``final_norm.scale``), so a reference
 ``core`` state dict loads with ``strict=True``.  The modules own parameters only; every FLOP runs in
 ``libavdiff_hip.so``.  Inference only (the benchmarked path is ``@torch.no_grad`` + ``.eval()``,
-sample_clip.py:84-107,220): dropout / token-dropout in training mode, masks and RoPE raise.
+sample_clip.py:84-107,220): dropout / token-dropout in training mode and float masks raise; ``rope`` is accepted and
+ignored as the reference does (mmdt.py:125-127 never reads it).
 """
 from __future__ import annotations
 
@@ -146,8 +147,8 @@ class MMDiT(nn.Module):
     def __init__(self, d_model=1024, n_layers=16, n_heads=16, mlp_ratio=4.0,
                  dropout=0.1, attn_dropout=0.0, norm="rmsnorm", rope=False, token_dropout=0.0):
         super().__init__()
-        if rope:
-            raise NotImplementedError("rope=True is a no-op flag in the reference (never read); refusing silently-ignored options")
+        # `rope` is stored and never read, exactly as in the reference (mmdt.py:125-127 keeps it in cfg only): a config that sets
+        # it builds the same model there and here
         self.cfg = MMDiTCfg(d_model, n_layers, n_heads, mlp_ratio, dropout, attn_dropout, norm, rope, token_dropout)
         self.blocks = nn.ModuleList([Block(d_model, n_heads, mlp_ratio, dropout, attn_dropout, norm)
                                      for _ in range(n_layers)])

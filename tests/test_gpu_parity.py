@@ -1285,35 +1285,44 @@ def test_attention_key_padding_mask(dev):
                        Fn.attention(qkv.to(dev), H))
 
 
-def test_optional_launch_modes_agree(dev, full):
-    """The two launch modes that are kept as measured experiments (off by default) compute the same results: the persistent
-    tile-queue fp32 GEMM (bit-identical: same tiles, same k order) and the stream-K bf16x3 GEMMs (fixed part order: deterministic,
-    equal to plain tiling within rounding of the re-associated K split)."""
-    from multimodal_diffusion_amd import functional as Fn
+def test_split_gemm_tile_configurations_agree(dev):
+    """The two block configurations of the split-operand GEMM (8 waves 256x256 / 4 waves 256x128, avd_tune_set "s3_tile") sum
+    every output element over k in the same order with the same product terms: bit-identical results, in every mode, for the
+    fp32 and the image epilogues, on a ragged row count and on K = 16 .. 2048 (ring prologue / tail with fewer tiles than stages,
+    odd and even step counts)."""
+    from multimodal_diffusion_amd import functional as Fn, _lib as L
     g = torch.Generator().manual_seed(41)
-    x = torch.randn(26944, 512, generator=g).to(dev)
-    w = (torch.randn(1536, 512, generator=g) / 22.6).to(dev)
-    b = torch.randn(1536, generator=g).to(dev)
-    y0 = Fn.linear(x, w, b)
-    _tune("gemm_persist", 1)
-    try:
-        y1 = Fn.linear(x, w, b)
-        y2 = Fn.linear(x, w, b)
-    finally:
-        _tune("gemm_persist", 0)
-    assert torch.equal(y0, y1) and torch.equal(y1, y2)
-    ws, _ = full
-    outs = []
-    for sk in (0, 1, 1):
-        mods = _full_modules(dev, ws)
-        _tune("s3_streamk", sk)
-        try:
-            out, ref = _one_step(dev, mods, ws, 256, 20, 2, matmul="bf16x3", seed=5)
-        finally:
-            _tune("s3_streamk", 0)
-        assert rel_err(out[:2], ref) < TOL
-        outs.append(out)
-    assert torch.equal(outs[1], outs[2]) and rel_err(outs[1], outs[0]) < 1e-5
+    for M, N, K in ((2701, 512, 512), (768, 256, 16), (515, 256, 48), (300, 512, 2048), (1024, 768, 80), (256, 256, 112)):
+        x = torch.randn(M, K, generator=g).to(dev)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+        b = torch.randn(N, generator=g).to(dev)
+        r = torch.randn(M, N, generator=g).to(dev)
+        ref = (x.double() @ w.double().T + b.double() + r.double()).cpu()
+        for mode in ("bf16x3", "bf16x3_strict", "bf16", "f16x2"):
+            outs = []
+            for tile in (0, 1):
+                _tune("s3_tile", tile)
+                try:
+                    if mode == "f16x2":
+                        x2, sx = Fn.split_f16x2(x)
+                        w2, sw = Fn.split_f16x2(w)
+                        y = Fn.linear_f16x2(x2, M, w2, N, K, sx * sw, bias=b, residual=r)
+                        img = Fn.linear_f16x2(x2, M, w2, N, K, sx * sw, bias=b, act=L.ACT_GELU, out_scale=64.0)
+                    else:
+                        terms = {"bf16x3": 6, "bf16x3_strict": 9, "bf16": 1}[mode]
+                        x3, w3 = Fn.split3(x), Fn.split3(w)
+                        y = Fn.linear_bf16x3(x3, M, w3, N, K, bias=b, residual=r, terms=terms)
+                        img = Fn.linear_bf16x3(x3, M, w3, N, K, bias=b, act=L.ACT_GELU, out_split3=True, terms=terms)
+                finally:
+                    _tune("s3_tile", -1)
+                outs.append((y, img))
+            assert torch.equal(outs[0][0], outs[1][0]), (mode, M, N, K)
+            if M % 256 == 0:          # whole image defined (rows past M inside the last 256-row tile are never written)
+                live = 2 if mode == "f16x2" else 3          # an f16x2 image never writes its third plane
+                i0, i1 = (o[1].view(-1, 3, 4096)[:, :live] for o in outs)
+                assert torch.equal(i0, i1), (mode, M, N, K)
+            tol = 2e-2 if mode == "bf16" else 3e-6
+            assert rel_err(outs[0][0].cpu(), ref) < tol, (mode, M, N, K)
 
 
 # ------------------------------------------------------------------------------------------------- reduced-precision variants

@@ -123,8 +123,9 @@ def test_no_cpu_fallback():
     assert {"blocks.0.norm1.weight", "blocks.0.norm1.bias", "final_norm.weight", "final_norm.bias"} <= set(ln.state_dict())
     with pytest.raises(L.AvdError):
         ln.eval()(torch.zeros(1, 4, 128))
-    with pytest.raises(NotImplementedError):
-        A.MMDiT(d_model=128, n_layers=1, n_heads=2, rope=True)
+    # rope=True is accepted and ignored, as in the reference (mmdt.py:125-127 stores the flag and never reads it)
+    rp = A.MMDiT(d_model=128, n_layers=1, n_heads=2, rope=True)
+    assert rp.cfg.rope is True and set(rp.state_dict()) == set(A.MMDiT(d_model=128, n_layers=1, n_heads=2).state_dict())
 
 
 def test_product_does_not_import_oracle():

@@ -245,3 +245,30 @@ def test_g16_dropin_corners(small_model):
     flat = wnd.reshape(6, 5, 8)
     y = R.audio_untokens(flat, 1, 8, 24, 4, hann=True).view(2, 3, 24)
     assert rel_err(y, g["hann/y"]) < 1e-6
+
+
+def test_fast_port_matches_oracle(small_model):
+    """bench.py's timed cpu_baseline (oracle/ref_cpu_fast.py: the same functions on the fused ATen kernels the reference's modules
+    dispatch to) against the pinned oracle: every function to 1e-5, and the full-width CFG step against the REFERENCE's own output
+    (fixture g17).  tools/cpu_port_speed.py holds its speed to the reference's (profiles/r03_cpu_port_speed.json)."""
+    from oracle import ref_cpu_fast as RF
+    g, W, meta = small_model
+    L_, H_ = meta["n_layers"], meta["n_heads"]
+    x = T(g["x"])
+    assert rel_err(RF.mmdit_forward(x, W["core"], L_, H_), R.mmdit_forward(x, W["core"], L_, H_)) < 1e-5
+    ws = R.synth_weights(seed=0, n_layers=2)
+    gen = torch.Generator().manual_seed(5)
+    xx = torch.randn(3, 61, 512, generator=gen)
+    assert rel_err(RF.mmdit_forward(xx, ws["core"], 2, 8), R.mmdit_forward(xx, ws["core"], 2, 8)) < 1e-5
+    assert rel_err(RF.rmsnorm(xx, ws["core"]["final_norm.scale"]), R.rmsnorm(xx, ws["core"]["final_norm.scale"])) < 1e-6
+    assert rel_err(RF.noise_head(xx, ws["head"], "video"), R.noise_head(xx, ws["head"], "video")) < 1e-5
+    # one full-width CFG step on g17's first two samples: port vs oracle and vs the reference's stored result
+    g17 = load_golden("g17_full_step_c3.npz")
+    wf = R.synth_weights(seed=0)
+    z_v, z_a = g17_inputs()
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    kw = dict(adapt_v=wf["adapt_v"], adapt_a=wf["adapt_a"], core=wf["core"], head=wf["head"], n_layers=8, n_heads=8, guidance=3.5)
+    zf = RF.denoise_step_a2v(z_v[:2], z_a[:2], T(g17["t_now"])[:2], T(g17["t_prev"])[:2], abar, **kw)
+    zo = R.denoise_step_a2v(z_v[:2], z_a[:2], T(g17["t_now"])[:2], T(g17["t_prev"])[:2], abar, **kw)
+    assert rel_err(zf, zo) < 1e-5
+    assert rel_err(zf, g17["z_next01"]) < TOL

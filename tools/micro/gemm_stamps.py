@@ -20,10 +20,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--build", action="store_true")
 ap.add_argument("--rows", type=int, default=64 * 421)
 ap.add_argument("--tile", type=int, default=-1)
-ap.add_argument("--stagger", type=int, default=0)
 ap.add_argument("--dump-map", action="store_true")
 ap.add_argument("--stages", type=int, default=2)
-ap.add_argument("--persist", type=int, default=1)
 ap.add_argument("--variant", default="", help="extra -D flags for the diagnostic build, e.g. AVD_LAB_NODMA or AVD_LAB_NODMA,AVD_LAB_NOLDS")
 args = ap.parse_args()
 so = HERE / ("libgemm_stamps" + ("_" + args.variant.replace(",", "_") if args.variant else "") + ".so")
@@ -41,12 +39,8 @@ lib.lab_set_tile.argtypes = [I]
 dev = torch.device("cuda:0")
 M = args.rows
 lib.lab_set_tile(args.tile)
-lib.lab_set_stagger.argtypes = [I]
-lib.lab_set_stagger(args.stagger)
 lib.lab_set_stages.argtypes = [I]
 lib.lab_set_stages(args.stages)
-lib.lab_set_persist.argtypes = [I]
-lib.lab_set_persist(args.persist)
 g = torch.Generator().manual_seed(0)
 shapes = [("in_proj", 1536, 512, 0, False, False), ("out_proj", 512, 512, 0, True, True), ("fc1+gelu", 2048, 512, 1, False, False),
           ("fc2+res", 512, 2048, 0, True, True)]

@@ -13,6 +13,7 @@ from multimodal_diffusion_amd import functional as Fn, _lib as L  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=26944)
 ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--only", default="", help="run only the epilogue kinds whose name contains this")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 M = args.rows
@@ -34,6 +35,8 @@ def timed(fn):
 
 for mode in ("f16x2", "bf16x3", "bf16"):
     for epi, N in (("res", 512), ("gelu_split", 2048), ("qkv-like plain", 1536)):
+        if args.only and args.only not in epi:
+            continue
         res = []
         for K in (256, 512, 1024, 2048, 4096):
             x = torch.randn(M, K, generator=g).to(dev)

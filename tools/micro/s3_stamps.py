@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Diagnostic: where does a block of the split-operand GEMMs (gemm_bf16x3.hip) spend its K loop?  (GPU box only; not a product path)
 
-tools/micro/libs3_stamps.so = gemm_bf16x3.hip built with -DAVD_S3_STAMPS (+ lab_stub.hip).  Wave 0 of every block sums the core-clock
-cycles of each K step's phases (DMA wait | barrier | DMA issue | fragment reads + MFMAs) and stamps block entry / loop start /
-loop end / block end.  Printed per shape and mode: kernel time, effective clock, share of block lifetime in prologue / loop /
-epilogue, cycles per K step by phase against the MFMA-issue floor."""
+tools/micro/libs3_stamps.so = gemm_bf16x3.hip built with -DAVD_S3_STAMPS (+ lab_stub.hip).  Every block stamps (core clock + 100 MHz
+real time) its entry / loop start / loop end / exit — no stamp inside the K loop.  Printed per shape and mode: kernel time, in-kernel
+clock, share of block lifetime in prologue / loop / epilogue, cycles per K step against the MFMA-issue floor.
+--variant AVD_LAB_NODMA / AVD_LAB_NOLDS: diagnostic builds without the in-loop DMA / without the fragment reads (wrong results by design)."""
 import argparse
 import ctypes as C
 import subprocess
@@ -18,6 +18,8 @@ ROOT = HERE.parent.parent
 ap = argparse.ArgumentParser()
 ap.add_argument("--build", action="store_true")
 ap.add_argument("--rows", type=int, default=64 * 421)
+ap.add_argument("--warm-s", type=float, default=1.0)
+ap.add_argument("--modes", default="f16x2,bf16x3,bf16")
 ap.add_argument("--variant", default="", help="extra -D flags for the diagnostic build, e.g. AVD_LAB_HALFLDS")
 args = ap.parse_args()
 so = HERE / ("libs3_stamps" + ("_" + args.variant.replace(",", "_") if args.variant else "") + ".so")
@@ -40,6 +42,8 @@ g = torch.Generator().manual_seed(0)
 shapes = [("out_proj (256x256 tiles, +res)", 512, 512, "res"), ("fc2 (256x256 tiles, +res)", 512, 2048, "res"),
           ("fc1 (256x128 tiles, GELU->image)", 2048, 512, "gelu")]
 for mode, terms in (("f16x2", 3), ("bf16x3", 6), ("bf16", 1)):
+    if mode not in args.modes.split(","):
+        continue
     mfma_per_step = {3: 24, 6: 48, 1: 8}[terms] * 32        # cycles of matrix-pipe issue per wave per 16-k step (128 x 64 wave tile)
     for name, N, K, epi in shapes:
         x = torch.randn(M, K, generator=g).to(dev)
@@ -69,9 +73,13 @@ for mode, terms in (("f16x2", 3), ("bf16x3", 6), ("bf16", 1)):
                 return lib.avd_gemm_bf16x3_f32(x3.data_ptr(), w3.data_ptr(), b.data_ptr(), None, None, y3.data_ptr(), M, N, K, 1, terms, None)
             return lib.avd_gemm_bf16x3_f32(x3.data_ptr(), w3.data_ptr(), b.data_ptr(), r.data_ptr(), y.data_ptr(), None, M, N, K, 0, terms, None)
 
-        for _ in range(3):
-            assert run() == 0
-        torch.cuda.synchronize()
+        # back-to-back launches for ~1 s first: the clock a kernel holds under sustained load is what is being measured
+        import time
+        t_w = time.time()
+        while time.time() - t_w < args.warm_s:
+            for _ in range(50):
+                assert run() == 0
+            torch.cuda.synchronize()
         dbg.zero_()
         a, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
@@ -86,8 +94,6 @@ for mode, terms in (("f16x2", 3), ("bf16x3", 6), ("bf16", 1)):
         steps = d[:, 8].astype(np.float64)
         rt = (d[:, 9] - d[:, 10]).astype(np.float64) / 100e6      # s_memrealtime: 100 MHz, block entry -> exit
         ghz = float(np.median(life / 1e9 / np.maximum(rt, 1e-9)))
-        per = lambda c: float((d[:, c] / steps).mean())
-        tot = per(4) + per(5) + per(6) + per(7)
+        per_step = float(((d[:, 2] - d[:, 1]) / steps).mean())
         print(f"{mode:6s} {name:34s} {us:7.1f} us  blocks {len(d):4d}  clock ~{ghz:.2f} GHz | block life: prologue {pro.mean():.2f} loop {loop.mean():.2f} "
-              f"epilogue {epil.mean():.2f} ({life.mean():.0f} cyc) | per K step: wait {per(4):6.0f}  barrier {per(5):6.0f}  issue {per(6):5.0f}  "
-              f"reads+MFMA {per(7):6.0f}  = {tot:6.0f} cyc  (MFMA issue floor {mfma_per_step} per wave, x2 waves per SIMD = {2 * mfma_per_step})")
+              f"epilogue {epil.mean():.2f} ({life.mean():.0f} cyc) | {per_step:6.0f} cyc per K step (MFMA issue floor {mfma_per_step} per wave, x2 waves per SIMD = {2 * mfma_per_step})")
