@@ -170,6 +170,9 @@ def parse_args(argv=None):
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse N > 1 on a 1-GPU box)")
     ap.add_argument("--share-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--verify-ranks", action="store_true",
+                    help="N > 1: also report, per rank, a checksum of the broadcast conditioning and of the final latents "
+                         "(two tiny all-gathers outside the timed region; tests/test_gpu_parity.py::test_bench_two_ranks_share_device)")
     return ap.parse_args(argv)
 
 
@@ -205,7 +208,8 @@ def setup_run(args, need_gpu: bool = True):
     z_a0 = D.local_conditioning(cond_all, rank, world)
     z0 = torch.randn(lat, generator=torch.Generator().manual_seed(1 + rank)).to(dev)
     return dict(rank=rank, world=world, local=local, dev=dev, comm_dev=comm_dev, B=B, size=size, S=S, lat=lat, nv=nv, na=na,
-                abar=abar, sched=sched, z_a0=z_a0, z0=z0, global_batch=B * world)
+                abar=abar, sched=sched, z_a0=z_a0, z0=z0, global_batch=B * world,
+                cond_checksum=float(cond_all.double().sum().item()))
 
 
 def roofline_of(rep, matmul: str, n_steps: int):
@@ -308,6 +312,10 @@ def main():
     D.barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0, ctx["comm_dev"])
     assert torch.isfinite(za).all(), "non-finite latent after the timed region"
+    verify = None
+    if args.verify_ranks:
+        verify = {"conditioning_checksum_per_rank": D.gather_scalars(ctx["cond_checksum"], ctx["comm_dev"]),
+                  "latent_abs_sum_per_rank": D.gather_scalars(float(za.double().abs().sum().item()), ctx["comm_dev"])}
 
     out = None
     if rank == 0:
@@ -336,6 +344,8 @@ def main():
             "algorithmic_tflops_per_gpu": fl * per_gpu / 1e12,
             "algorithmic_tflops_total": fl * world * per_gpu / 1e12,
         }
+        if verify is not None:
+            out["verify"] = verify
 
     def instrumented(mode, base_engine):
         """(roofline, kernels, single_stream_steps_per_s | None) of `mode`: HIP events around every launch, on its stream, over 5

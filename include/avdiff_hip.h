@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AVD_ABI_VERSION 4
+#define AVD_ABI_VERSION 5
 
 #define AVD_OK            0
 #define AVD_EINVAL       -1   /* bad shape / argument (reference: AssertionError / ValueError) */
@@ -197,6 +197,13 @@ typedef struct {                       /* avdiff/models/mmdt.py:88-99 (Block) st
      * [4..7] the activation images: norm1 output, q|k|v (and the attention output), norm2 output, GELU(fc1) output.  Each
      * activation scale must satisfy scale * bound <= 2^15 for a bound on the magnitudes the image can hold. */
     float f16x2_scale[8];
+    /* optional (bf16 plane modes, i.e. split_terms 6 / 9 / 1): split3 images of in_proj_weight_n and fc1_weight_n above.  Both non-NULL
+     * in every block folds each RMSNorm of the split path into its neighbours: the residual epilogues of out_proj / fc2 also write the
+     * stream's operand image and its rows' sums of squares, in_proj / fc1 run on that un-normalised image with these weights and scale
+     * their rows by 1 / (rms + eps) before the bias — no RMSNorm kernel between the first block's input and the final norm
+     * (mmdt.py:39-42, 95-99; same arithmetic up to rounding). */
+    const void* in_proj_weight3n;
+    const void* fc1_weight3n;
 } avd_block_weights;
 
 typedef struct {                       /* avdiff/models/mmdt.py:116-149 (MMDiT) */

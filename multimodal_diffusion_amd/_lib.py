@@ -37,7 +37,7 @@ class BlockWeights(C.Structure):
         "norm2_scale", "fc1_weight", "fc1_bias", "fc2_weight", "fc2_bias",
         "in_proj_weight_n", "fc1_weight_n",
         "in_proj_weight3", "out_proj_weight3", "fc1_weight3", "fc2_weight3",
-        "norm1_bias", "norm2_bias")] + [("f16x2_scale", C.c_float * 8)]
+        "norm1_bias", "norm2_bias")] + [("f16x2_scale", C.c_float * 8), ("in_proj_weight3n", C.c_void_p), ("fc1_weight3n", C.c_void_p)]
 
 
 class CoreWeights(C.Structure):
@@ -87,7 +87,7 @@ class VaeEncodeDesc(C.Structure):
                 ("conv_w_scale", C.POINTER(C.c_float)), ("conv_a_scale", C.POINTER(C.c_float))]
 
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); must list every symbol include/avdiff_hip.h declares

@@ -156,9 +156,10 @@ __device__ __forceinline__ void split8(const float* v, u32x4& H, u32x4& Mi, u32x
 }
 
 // where the 8 values (row r, columns k..k+7, k % 8 == 0) of a [rows][K] matrix go in its split3 image
+template <bool RANGE_CHECK = true>
 __device__ __forceinline__ void store_split8(unsigned char* img, int64_t r, int k, int K, const float* v) {
     u32x4 H, Mi, Lo;
-    split8(v, H, Mi, Lo);
+    split8<RANGE_CHECK>(v, H, Mi, Lo);
     const int rr = (int)(r & 127), half = (k >> 3) & 1;
     unsigned char* dst = img + ((r >> 7) * (K >> 4) + (k >> 4)) * (int64_t)S3_CHUNK + rr * 32 + ((half ^ ((rr >> 3) & 1)) << 4);
     *reinterpret_cast<u32x4*>(dst) = H;
@@ -259,7 +260,8 @@ int weight_bounds_f32(const float* x, int64_t rows, int d, float* out2, hipStrea
 int64_t split3_bytes(int64_t rows, int K);
 // h2_scale > 0: write the f16x2 image with that scale instead of the three bf16 planes
 int split3_f32(const float* x, int64_t ld, void* out, int64_t rows, int K, hipStream_t st, float h2_scale = 0.f);
-int split3_rows_f32(const float* x, RowMap xm, void* out, int64_t rows, int K, hipStream_t st, float h2_scale = 0.f);
+// ss != null: also the rows' sums of squares per 64-column chunk, ss[row][K / 64] (a folded RMSNorm reads them)
+int split3_rows_f32(const float* x, RowMap xm, void* out, int64_t rows, int K, hipStream_t st, float h2_scale = 0.f, float* ss = nullptr);
 int rmsnorm_split3_f32(const float* x, const float* scale, void* out, int64_t rows, int d, float eps, hipStream_t st, float h2_scale = 0.f);
 int layernorm_act_split3_f32(const float* x, const float* gamma, const float* beta, void* out, int64_t rows, int d, float eps, int act,
                              hipStream_t st, float h2_scale = 0.f);
@@ -270,7 +272,7 @@ extern int g_s3_tile;            // -1 = per epilogue; 0 / 1 = 8-wave 256x256 / 
 extern thread_local bool t_s3_two_streams;
 // terms == 3 (f16x2): ab_scale = (A image scale) x (W image scale), c_scale = scale of the image written (if one is written)
 int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* img, int64_t M, int tokens, int heads, int K, float qscale,
-                     int terms, hipStream_t st, float ab_scale = 1.f, float c_scale = 1.f);
+                     int terms, hipStream_t st, float ab_scale = 1.f, float c_scale = 1.f, const float* ss_in = nullptr, float eps = 0.f);
 int64_t qkv3_bytes(int B, int N, int H);
 // fp8 attention (attn_fp8.hip): reads the same qkv3 image, needs attn_fp8_ws_bytes(B, N, H) of scratch
 int64_t attn_fp8_ws_bytes(int B, int N, int H);
@@ -280,6 +282,7 @@ int attn_fp8(const void* qkv3, void* ws, int64_t ws_bytes, float* out, void* out
 int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms, hipStream_t st,
                 float img_scale = 1.f, float out_scale = 1.f);
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
-                int act, int terms, hipStream_t st, float ab_scale = 1.f, float c_scale = 1.f);
+                int act, int terms, hipStream_t st, float ab_scale = 1.f, float c_scale = 1.f, const float* ss_in = nullptr, float eps = 0.f,
+                float* ss_out = nullptr);
 
 }  // namespace avd

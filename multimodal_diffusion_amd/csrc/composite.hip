@@ -115,6 +115,15 @@ static bool core_use_split(const avd_core_weights* w, int64_t M) {
     return true;
 }
 
+// split path with RMSNorm folded into its neighbours (bf16 planes only: the un-normalised residual stream has no bound an fp16 image
+// could be scaled by): needs the scale-carrying weight images and 64-column chunks for the sums of squares
+static bool core_use_split_fold(const avd_core_weights* w) {
+    if (g_no_fold || w->norm_kind != 0 || w->split_terms == 3 || w->d % 64 != 0) return false;
+    for (int l = 0; l < w->n_layers; ++l)
+        if (!w->blocks[l].in_proj_weight3n || !w->blocks[l].fc1_weight3n) return false;
+    return true;
+}
+
 // fp32 path with RMSNorm folded into the neighbouring GEMM epilogues: needs the scale-carrying weights and LDS-DMA-able shapes
 static bool core_use_fold(const avd_core_weights* w) {
     if (g_no_fold || w->norm_kind != 0) return false;              // avd_tune_set "no_fold": measurement aid
@@ -141,7 +150,9 @@ static int64_t core_ws_bytes(const avd_core_weights* w, int B, int N) {
     const int64_t wide_b = core_split_wide_bytes(w, B, N);
     // third region: (attn_mode 1) the fp8 attention's operand images
     const int64_t f8_b = w->attn_mode == 1 ? attn_fp8_ws_bytes(B, N, w->n_heads) : 0;
-    const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d)) + align_up(f8_b);
+    // folded norms: a second [M][d] image (the residual stream's) and the table of its rows' sums of squares
+    const int64_t fold_b = core_use_split_fold(w) ? align_up(split3_bytes(M, w->d)) + align_up(M * (w->d / 64) * 4) : 0;
+    const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d)) + align_up(f8_b) + fold_b;
     return split_path > fp32_path ? split_path : fp32_path;
 }
 
@@ -199,6 +210,38 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
         void* hs = cs.take((split3_bytes(M, d) + 3) / 4);
         const int64_t f8_b = w->attn_mode == 1 ? attn_fp8_ws_bytes(B, N, H) : 0;
         float* f8w = cs.take((f8_b + 3) / 4);         // fp8 attention operands (attn_mode 1 only)
+        if (core_use_split_fold(w)) {
+            // RMSNorm folded into its neighbours: the residual epilogues (out_proj, fc2) write the new stream as fp32, as an operand
+            // image and as per-row sums of squares; in_proj / fc1 run on that un-normalised image with weights that carry the norm's
+            // scale and multiply their rows by 1 / (rms + eps) before the bias.  No norm kernel between the first split and the final norm.
+            void* hx = cs.take((split3_bytes(M, d) + 3) / 4);           // image of the residual stream
+            float* ss = cs.take(M * (d / 64));                           // its rows' sums of squares, [M][d / 64]
+            if (int rc = split3_rows_f32(cur, rd, hx, M, d, st, 0.f, ss)) return rc;
+            for (int l = 0; l < w->n_layers; ++l) {
+                const avd_block_weights& b = w->blocks[l];
+                const bool last = l == w->n_layers - 1;
+                const int nq = (last && out_row0 == 0) ? n_out_rows : N;
+                if (int rc = gemm_bf16x3_qkv3(hx, b.in_proj_weight3n, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, terms, st,
+                                              1.f, 1.f, ss, w->norm_eps)) return rc;
+                if (w->attn_mode == 1) {
+                    if (int rc = attn_fp8(qkv, f8w, f8_b, nullptr, hs, B, N, H, nq, st, terms, 1.f, 1.f)) return rc;
+                } else {
+                    if (int rc = attn_bf16x3(qkv, nullptr, hs, B, N, H, nq, terms, st, 1.f, 1.f)) return rc;
+                }
+                if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, hx, M, d, d, AVD_ACT_NONE, terms, st, 1.f, 1.f, nullptr,
+                                         0.f, ss)) return rc;
+                cur = y;
+                if (int rc = gemm_bf16x3(hx, b.fc1_weight3n, b.fc1_bias, nullptr, nullptr, wide3, M, hid, d, AVD_ACT_GELU, terms, st, 1.f, 1.f, ss,
+                                         w->norm_eps)) return rc;
+                if (last) {     // nothing reads the stream's image after the last block: the final norm takes the fp32 rows
+                    if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, nullptr, M, d, hid, AVD_ACT_NONE, terms, st)) return rc;
+                } else {
+                    if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, hx, M, d, hid, AVD_ACT_NONE, terms, st, 1.f, 1.f, nullptr, 0.f,
+                                             ss)) return rc;
+                }
+            }
+            return rmsnorm_f32(y, rd, w->final_norm_scale, y, rd, M, d, w->norm_eps, st);
+        }
         for (int l = 0; l < w->n_layers; ++l) {
             const avd_block_weights& b = w->blocks[l];
             const bool last = l == w->n_layers - 1;

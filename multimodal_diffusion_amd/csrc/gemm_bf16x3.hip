@@ -39,10 +39,11 @@ namespace avd {
 // ---------------------------------------------------------------------------------------------------------
 // producers
 // ---------------------------------------------------------------------------------------------------------
-// x [rows][K] (row stride ld) -> split3 image; rows in [rows, rows_pad) are written as zeros
+// x [rows][K] (row stride ld) -> split3 image; rows in [rows, rows_pad) are written as zeros.  ss != null (K % 64 == 0): also the
+// rows' sums of squares per 64-column chunk, ss[row][K / 64] — the table a norm-folded GEMM reads (S3Args::ss_in)
 template <bool F16>   // F16: f16x2 image with scale s (avd_common.h)
 __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x, RowMap xm, unsigned char* __restrict__ out,
-                                                     int64_t rows, int64_t rows_pad, int K, float s) {
+                                                     int64_t rows, int64_t rows_pad, int K, float s, float* __restrict__ ss) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int per_row = K >> 3;
     if (i >= rows_pad * per_row) return;
@@ -56,6 +57,13 @@ __global__ __launch_bounds__(256) void split3_kernel(const float* __restrict__ x
     }
     if constexpr (F16) store_split8_h2(out, r, k, K, v, s);
     else store_split8(out, r, k, K, v);
+    if (ss) {       // 8 consecutive threads hold one 64-column chunk of one row (K % 64 == 0 keeps the groups inside a row)
+        float q = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+        q += __shfl_xor(q, 1, 64);
+        q += __shfl_xor(q, 2, 64);
+        q += __shfl_xor(q, 4, 64);
+        if ((threadIdx.x & 7) == 0 && r < rows) ss[r * (K >> 6) + (k >> 6)] = q;
+    }
 }
 
 // RMSNorm (mmdt.py:39-42, eps outside the sqrt) writing the split3 image of its output; one wave per row
@@ -156,7 +164,9 @@ __global__ __launch_bounds__(256) void layernorm_act_split3_kernel(const float* 
 // ---------------------------------------------------------------------------------------------------------
 // GEMM
 // ---------------------------------------------------------------------------------------------------------
-enum { S3_EPI_BIAS = 0, S3_EPI_RES = 2, S3_EPI_GELU_SPLIT = 3, S3_EPI_QKV3 = 4, S3_EPI_SPLIT = 5 };   // 5: bias, image out, no activation
+// 5: bias, image out, no activation.  6: bias + residual, fp32 out AND its operand image AND the rows' sums of squares (the
+// producer side of a folded RMSNorm)
+enum { S3_EPI_BIAS = 0, S3_EPI_RES = 2, S3_EPI_GELU_SPLIT = 3, S3_EPI_QKV3 = 4, S3_EPI_SPLIT = 5, S3_EPI_RES_IMG = 6 };
 
 struct S3Args {
     const unsigned char* A;   // split3 image of [M][K]
@@ -173,6 +183,13 @@ struct S3Args {
     int first_gen;              // ... if it belongs to the first generation of blocks (blockIdx < 2 x CUs of the device)
     int terms;                  // 6 (default), 9 (strict), 1 (plain bf16 operands) or 3 (f16x2 images)
     float ab_inv, c_scale;      // terms 3: 1 / (A image scale x W image scale) applied to the sums; scale of the image written
+    // RMSNorm folding (mmdt.py:39-42 moved into its neighbours, as gemm_f32.hip does on the fp32 path).
+    // Consumer (image epilogues): ss_in[row][K / 64] = sums of squares of the UN-normalised rows whose image is A; W carries the norm's
+    // scale; every output row is multiplied by 1 / (sqrt(sum_c ss_in[row][c]) / ss_sqrt_d + ss_eps) before the bias.
+    // Producer (EPI_RES_IMG): ss_out[row][N / 64] receives the sums of squares of the rows it writes.
+    const float* ss_in;
+    float* ss_out;
+    float ss_sqrt_d, ss_eps;
 #ifdef AVD_S3_STAMPS            // diagnostic build only (tools/micro/s3_stamps.py), never in the product library
     unsigned long long* dbg;
 #endif
@@ -301,6 +318,175 @@ __device__ __forceinline__ void s3_epilogue(const S3Args& g, f32x16 (&acc)[4][2]
     }
 }
 
+// Image epilogues (fc1 + GELU -> operand image, head input_proj -> image, in_proj -> q|k|v image) work on TRANSPOSED accumulator
+// tiles: the kernel multiplies W fragments as the MFMA's A operand and X fragments as its B operand, so lane (l31, hi) of tile (i, j)
+// holds output row m = 32 i + l31 and columns n = 32 j + 8 (r >> 2) + 4 hi + (r & 3) in register r.  One v_permlane32_swap per
+// register pair then gives every lane 8 CONSECUTIVE columns of its row — lanes hi = 0 the 16-byte chunks 0 and 2 of the 32 columns,
+// lanes hi = 1 chunks 1 and 3 — which is exactly what an image stores per (row, 8-k chunk): bias / GELU / split run on registers and
+// every wave store writes 1 KiB of contiguous image (32 rows x 32 B).  No LDS slab, no barrier, no transposing ds_write / ds_read
+// (rounds 1-2 went through the slab: ~6,000 instructions per wave, a third of them exec-mask bookkeeping of the per-pair range
+// check; the GELU -> image epilogue was 39-46 % of a block's life and paced the launch, tools/micro/s3_stamps.py).
+// `big` (wave-uniform; bf16 planes only): some value of this wave's VALID rows may come within reach of the top of the bf16 range
+// (|v| > largest finite bf16, or inf) — only then is split8's edge handling executed.  The test is made once per wave tile, and it
+// selects nothing but the (exact) split: bias, scaling and GELU are one piece of code on both sides, so a wave's results do not
+// depend on which side it took, i.e. not on what its neighbouring rows — or the never-written rows past M — hold.
+#ifdef AVD_LAB_NOSTORE     // diagnostic build: the epilogue's arithmetic runs, (almost) nothing is stored
+#define S3_ROW_OK(m) ((m) < g.M && __float_as_uint(v[0]) == 0x7fc12345u)
+#else
+#define S3_ROW_OK(m) ((m) < g.M)
+#endif
+template <int EPI, bool F16>
+__device__ __forceinline__ void s3_epilogue_img_t(const S3Args& g, f32x16 (&acc)[4][2], int64_t mwave0, int nbase, int lane, bool big) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    // bias of this lane's chunks: tile column j, chunk group cg -> columns nbase + 32 j + 8 (2 cg + hi) + (0..7)
+    float bv[2][2][8];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+            const float* bp = g.bias + nbase + 32 * j + 8 * (2 * cg + hi);
+            *reinterpret_cast<f32x4*>(bv[j][cg]) = *reinterpret_cast<const f32x4*>(bp);
+            *reinterpret_cast<f32x4*>(bv[j][cg] + 4) = *reinterpret_cast<const f32x4*>(bp + 4);
+        }
+    [[maybe_unused]] float mul = 1.0f;
+    [[maybe_unused]] float ssq[4] = {0.f, 0.f, 0.f, 0.f};      // EPI_RES_IMG: this lane's part of its rows' sums of squares
+    [[maybe_unused]] int64_t qbase = 0;       // EPI_QKV3: byte offset of (part, sample 0, head, token 0)
+    if constexpr (EPI == S3_EPI_QKV3) {
+        const int dmodel = g.heads * 64;
+        const int part = nbase / dmodel, head = (nbase % dmodel) >> 6;       // a wave's 64 columns are one (part, head)
+        mul = part == 0 ? g.qscale : 1.0f;
+        qbase = (((int64_t)part * (g.M / g.tokN)) * g.heads + head) * (int64_t)g.tokNpad * QKV3_ROWB;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = mwave0 + 32 * i + l31;
+        // folded RMSNorm: factor of this lane's row from the partial sums of squares (fixed summation order)
+        float rinv = 1.0f;
+        if (EPI != S3_EPI_RES_IMG && g.ss_in != nullptr && m < g.M) {
+            const int nc = g.K >> 6;
+            const float* sp = g.ss_in + m * nc;
+            float ssum = 0.f;
+            if (nc == 8) {
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(sp), p1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                const f32x4 t = p0 + p1;
+                ssum = (t[0] + t[1]) + (t[2] + t[3]);
+            } else {
+                for (int c = 0; c < nc; ++c) ssum += sp[c];
+            }
+            rinv = 1.0f / (sqrtf(ssum) / g.ss_sqrt_d + g.ss_eps);
+        }
+        [[maybe_unused]] unsigned char* qrow = nullptr;
+        [[maybe_unused]] int qsw = 0;
+        if constexpr (EPI == S3_EPI_QKV3) {
+            const unsigned b = (unsigned)m / (unsigned)g.tokN, tok = (unsigned)m - b * (unsigned)g.tokN;      // M < 2^31 (checked by the host)
+            const int dmodel = g.heads * 64;
+            qrow = g.C3 + qbase + ((int64_t)b * g.heads * g.tokNpad + tok) * QKV3_ROWB;
+            qsw = qkv3_swizzle(nbase / dmodel, (int)tok);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                // registers 8 cg .. 8 cg + 3 (columns 4 hi + ..) and 8 cg + 4 .. + 7 (columns 8 + 4 hi + ..): swap across the lane halves
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * cg + e]), __float_as_uint(acc[i][j][8 * cg + 4 + e]),
+                                                                     false, false);
+                    v[e] = __uint_as_float(sw[0]);
+                    v[4 + e] = __uint_as_float(sw[1]);
+                }
+                if constexpr (EPI == S3_EPI_QKV3) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = ((F16 ? v[e] * g.ab_inv : v[e]) * rinv + bv[j][cg][e]) * mul;
+                    if (S3_ROW_OK(m)) {
+                        const int c = 4 * j + 2 * cg + hi;                                  // 8-d chunk of the head
+                        unsigned char* dst = qrow + ((c ^ qsw) << 4);
+                        if constexpr (F16) {
+                            u32x4 Hh, Lo;
+                            split8_h2(v, g.c_scale, Hh, Lo);
+                            *reinterpret_cast<u32x4*>(dst) = Hh;
+                            *reinterpret_cast<u32x4*>(dst + 128) = Lo;
+                        } else {
+                            u32x4 Hh, Mi, Lo;
+                            if (big) split8<true>(v, Hh, Mi, Lo);
+                            else split8<false>(v, Hh, Mi, Lo);
+                            *reinterpret_cast<u32x4*>(dst) = Hh;
+                            *reinterpret_cast<u32x4*>(dst + 128) = Mi;
+                            *reinterpret_cast<u32x4*>(dst + 256) = Lo;
+                        }
+                    }
+                } else if constexpr (EPI == S3_EPI_RES_IMG) {
+                    // new residual stream: fp32 [M][N] (8 consecutive floats of the lane's row), its operand image, its sum of squares
+                    const int n = nbase + 32 * j + 8 * (2 * cg + hi);
+                    if (m < g.M) {
+                        const float* rp = g.R + m * g.N + n;
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = ((F16 ? v[e] * g.ab_inv : v[e]) + bv[j][cg][e]) + (e < 4 ? r0[e] : r1[e - 4]);
+                        float* cp = g.C + m * g.N + n;
+                        *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                        ssq[i] += ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+                        if constexpr (F16) store_split8_h2(g.C3, m, n, g.N, v, g.c_scale);
+                        else if (big) store_split8<true>(g.C3, m, n, g.N, v);
+                        else store_split8<false>(g.C3, m, n, g.N, v);
+                    }
+                } else {
+                    const int n = nbase + 32 * j + 8 * (2 * cg + hi);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float t = (F16 ? v[e] * g.ab_inv : v[e]) * rinv + bv[j][cg][e];
+                        v[e] = EPI == S3_EPI_GELU_SPLIT ? gelu_erf(t) : t;
+                    }
+                    if (S3_ROW_OK(m)) {
+                        if constexpr (F16) store_split8_h2(g.C3, m, n, g.N, v, g.c_scale);
+                        else if (big) store_split8<true>(g.C3, m, n, g.N, v);
+                        else store_split8<false>(g.C3, m, n, g.N, v);
+                    }
+                }
+            }
+    }
+    if constexpr (EPI == S3_EPI_RES_IMG) {
+        // the two lane halves of a row hold its columns 4 hi + .. of every 8: one exchange, then lane hi = 0 owns the wave's 64 columns
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float tot = ssq[i] + __shfl_xor(ssq[i], 32, 64);
+            const int64_t m = mwave0 + 32 * i + l31;
+            if (hi == 0 && m < g.M) g.ss_out[m * (g.N >> 6) + (nbase >> 6)] = tot;
+        }
+    }
+}
+
+template <int EPI, bool F16>
+__device__ __forceinline__ void s3_epilogue_img(const S3Args& g, f32x16 (&acc)[4][2], int64_t mwave0, int nbase, int lane) {
+    bool big = false;
+    if constexpr (!F16) {       // fp16 planes: out-of-range turns into inf / NaN by itself
+        // |raw sum| bounds what the epilogue can produce only loosely (bias, q scale), so the test is generous: anything past 2^100
+        const int l31 = lane & 31;
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a = fmaxf(a, fabsf(acc[i][j][r]));     // NaN operands are ignored: NaN stays NaN either way
+            if (mwave0 + 32 * i + l31 < g.M) amax = fmaxf(amax, a);                 // rows past M hold whatever was in memory
+        }
+        float bmax = 0.f;
+#pragma unroll
+        for (int e = 0; e < 64; e += 4) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + nbase + e);
+            bmax = fmaxf(fmaxf(bmax, fmaxf(fabsf(b4[0]), fabsf(b4[1]))), fmaxf(fabsf(b4[2]), fabsf(b4[3])));
+        }
+        big = __any(!(amax < 1.2676506e30f) || !(bmax < 1.2676506e30f) || !(fabsf(g.qscale) < 1.0e6f));
+        // the residual stream is unbounded and is read only inside the epilogue: its image always takes the checked split
+        if constexpr (EPI == S3_EPI_RES_IMG) big = true;
+    }
+    s3_epilogue_img_t<EPI, F16>(g, acc, mwave0, nbase, lane, big);
+}
+
 // wait until at most `tiles` x STEP of this wave's DMA pieces are still in flight (tiles is wave-uniform; capped at MAXN, < 0 = 0)
 template <int MAXN, int STEP>
 __device__ __forceinline__ void wait_vm_tiles(int tiles) {
@@ -355,6 +541,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_kernel(S3Args g) {
     constexpr int BM = Cf::BM, BN = Cf::BN, WM = 128, WN = 64, TM = 4, TN = 2;
     constexpr int RCH = Cf::RCH, STAGE = Cf::STAGE, PPW = Cf::PPW, NST = Cf::NST;
     constexpr bool F16 = TERMS == 3;
+    // image epilogues take the accumulator tiles transposed (s3_epilogue_img): W fragments as the MFMA's A operand
+    constexpr bool TR = EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
     [[maybe_unused]] const unsigned long long t_entry = S3_T(), rt_entry = S3_RT();
@@ -463,7 +651,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_kernel(S3Args g) {
 #pragma unroll
         for (int i = i0; i < i1; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = mma16<F16>(A_[i], B_[j], acc[i][j]);
+            for (int j = 0; j < TN; ++j) acc[i][j] = TR ? mma16<F16>(B_[j], A_[i], acc[i][j]) : mma16<F16>(A_[i], B_[j], acc[i][j]);
     };
 
     // prologue: the whole ring is put in flight, tile 0 is awaited and its fragments read
@@ -574,13 +762,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_kernel(S3Args g) {
     }
 #undef S3_SB
     [[maybe_unused]] const unsigned long long t_end = S3_T();
-    __syncthreads();      // the slabs overlay the stages: every wave is past its last fragment read, no DMA is in flight
-
-    constexpr int CLD = WN + 4;
-    float* slab = reinterpret_cast<float*>(smem3) + wave * 64 * CLD;
-    s3_epilogue<EPI, F16>(g, acc, slab, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane);
+    if constexpr (TR) {
+        s3_epilogue_img<EPI, F16>(g, acc, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane);      // registers only: no barrier, no LDS
+    } else {
+        __syncthreads();      // the slabs overlay the stages: every wave is past its last fragment read, no DMA is in flight
+        constexpr int CLD = WN + 4;
+        float* slab = reinterpret_cast<float*>(smem3) + wave * 64 * CLD;
+        s3_epilogue<EPI, F16>(g, acc, slab, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane);
+    }
 #ifdef AVD_S3_STAMPS
+    const unsigned long long t_issued = S3_T();      // every store issued, none awaited
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    S3_DBG(4, t_issued);
     S3_DBG(0, t_entry); S3_DBG(1, t_loop); S3_DBG(2, t_end); S3_DBG(3, S3_T());
     S3_DBG(8, (unsigned long long)nk); S3_DBG(9, S3_RT()); S3_DBG(10, rt_entry);
 #endif
@@ -598,8 +791,9 @@ int split3_f32(const float* x, int64_t ld, void* out, int64_t rows, int K, hipSt
     return split3_rows_f32(x, RowMap{ld, 0, 0}, out, rows, K, st, h2_scale);
 }
 
-int split3_rows_f32(const float* x, RowMap xm, void* out, int64_t rows, int K, hipStream_t st, float h2_scale) {
+int split3_rows_f32(const float* x, RowMap xm, void* out, int64_t rows, int K, hipStream_t st, float h2_scale, float* ss) {
     AVD_REQUIRE(x && out, AVD_EINVAL, "split3: null pointer");
+    AVD_REQUIRE(!ss || K % 64 == 0, AVD_EUNSUPPORTED, "split3: sums of squares need K %% 64 == 0 (K=%d)", K);
     const int64_t ld = xm.ld;
     AVD_REQUIRE(rows > 0 && K > 0 && K % 16 == 0 && ld >= K && ld % 4 == 0 && xm.stride % 4 == 0, AVD_EUNSUPPORTED,
                 "split3: need rows > 0, K %% 16 == 0, ld %% 4 == 0 (rows=%lld K=%d ld=%lld)", (long long)rows, K, (long long)ld);
@@ -612,10 +806,10 @@ int split3_rows_f32(const float* x, RowMap xm, void* out, int64_t rows, int K, h
     ProfScope prof(tag, (double)rows * K * image_rw_bytes(h2_scale), st);
     if (h2_scale > 0.f)
         hipLaunchKernelGGL(split3_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, xm,
-                           static_cast<unsigned char*>(out), rows, rows_pad, K, h2_scale);
+                           static_cast<unsigned char*>(out), rows, rows_pad, K, h2_scale, ss);
     else
         hipLaunchKernelGGL(split3_kernel<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, xm,
-                           static_cast<unsigned char*>(out), rows, rows_pad, K, 0.f);
+                           static_cast<unsigned char*>(out), rows, rows_pad, K, 0.f, ss);
     AVD_CHECK_LAUNCH("split3");
     return AVD_OK;
 }
@@ -724,9 +918,9 @@ static int launch_s3w(S3Args g, hipStream_t st) {
     // is fetched into the XCD's L2 once (in_proj at C3: 2.02 -> 1.84 ms per step)
     if (tile && g.nbn <= 16) sn = g.nbn;
     int total = tile ? 32 : 16;
-    {   // AVD_S3_SN / AVD_S3_SUPER: measurement aids (super-tile width in blocks / blocks per super-tile)
+    {   // AVD_S3_SN / AVD_S3_SUPER4 / AVD_S3_SUPER8: measurement aids (super-tile width in blocks / blocks per super-tile)
         static const int e_sn = getenv("AVD_S3_SN") ? atoi(getenv("AVD_S3_SN")) : 0;
-        static const int e_tot = getenv("AVD_S3_SUPER") ? atoi(getenv("AVD_S3_SUPER")) : 0;
+        static const int e_tot = getenv(tile ? "AVD_S3_SUPER4" : "AVD_S3_SUPER8") ? atoi(getenv(tile ? "AVD_S3_SUPER4" : "AVD_S3_SUPER8")) : 0;
         if (e_sn > 0) { sn = e_sn < g.nbn ? e_sn : g.nbn; while (g.nbn % sn) --sn; }
         if (e_tot > 0) total = e_tot;
     }
@@ -765,9 +959,14 @@ static int launch_s3(const S3Args& a, hipStream_t st) {
 
 // C = act(A W^T + bias) (+ residual).  C3 != null: the output is written as a split3 image (act must be GELU);
 // otherwise fp32 row-major into C (act NONE; residual optional, may alias C).
+// Folded RMSNorm (see S3Args): ss_in -> image outputs scale their rows by 1 / (||row of the un-normalised A|| / sqrt(K) + eps);
+// C, C3, R and ss_out all given -> the new residual stream as fp32, as an image and as sums of squares in one epilogue.
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
-                int act, int terms, hipStream_t st, float ab_scale, float c_scale) {
+                int act, int terms, hipStream_t st, float ab_scale, float c_scale, const float* ss_in, float eps, float* ss_out) {
     AVD_REQUIRE(A3 && W3 && (C || C3), AVD_EINVAL, "gemm_bf16x3: null pointer");
+    AVD_REQUIRE(!ss_in || (C3 && !C && K % 64 == 0), AVD_EUNSUPPORTED, "gemm_bf16x3: a folded norm needs an image output and K %% 64 == 0");
+    AVD_REQUIRE(!ss_out || (C && C3 && R && bias && N % 64 == 0 && act == AVD_ACT_NONE && terms != 3), AVD_EUNSUPPORTED,
+                "gemm_bf16x3: sums of squares are written by the fp32 + image residual epilogue only (bf16 planes)");
     AVD_REQUIRE(ab_scale > 0.f && ab_scale < __builtin_inff() && c_scale > 0.f && c_scale < __builtin_inff(), AVD_EINVAL,
                 "gemm_bf16x3: image scales must be positive and finite");
     AVD_REQUIRE(gemm_bf16x3_supported(M, N, K), AVD_EUNSUPPORTED, "gemm_bf16x3: need N %% 256 == 0 and K %% 16 == 0 (M=%lld N=%d K=%d)",
@@ -775,7 +974,12 @@ int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* 
     AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(C) && aligned16(C3) && aligned16(bias) && aligned16(R), AVD_EUNSUPPORTED,
                 "gemm_bf16x3: pointers must be 16-byte aligned");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, R, C,
-             static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0, 0, 0, 0, 0.f, 0, 0, terms, 1.0f / ab_scale, c_scale};
+             static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0, 0, 0, 0, 0.f, 0, 0, terms, 1.0f / ab_scale, c_scale,
+             ss_in, ss_out, (float)sqrt((double)K), eps};
+    if (C && C3) {
+        AVD_REQUIRE(ss_out, AVD_EUNSUPPORTED, "gemm_bf16x3: fp32 and image output together imply the residual + sums-of-squares epilogue");
+        return launch_s3<S3_EPI_RES_IMG>(a, st);
+    }
     if (C3) {
         AVD_REQUIRE((act == AVD_ACT_GELU || act == AVD_ACT_NONE) && !R && bias, AVD_EUNSUPPORTED,
                     "gemm_bf16x3: image output implies bias, act NONE or GELU, no residual");
@@ -788,17 +992,20 @@ int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* 
 
 // in_proj for the bf16x3 attention: qkv = A W^T + bias written as the qkv3 image (q pre-multiplied by qscale)
 int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* img, int64_t M, int tokens, int heads, int K, float qscale,
-                     int terms, hipStream_t st, float ab_scale, float c_scale) {
+                     int terms, hipStream_t st, float ab_scale, float c_scale, const float* ss_in, float eps) {
+    AVD_REQUIRE(!ss_in || K % 64 == 0, AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: a folded norm needs K %% 64 == 0");
     AVD_REQUIRE(A3 && W3 && bias && img, AVD_EINVAL, "gemm_bf16x3_qkv3: null pointer");
     AVD_REQUIRE(ab_scale > 0.f && ab_scale < __builtin_inff() && c_scale > 0.f && c_scale < __builtin_inff(), AVD_EINVAL,
                 "gemm_bf16x3_qkv3: image scales must be positive and finite");
     const int N = 3 * heads * 64;
     AVD_REQUIRE(tokens > 0 && heads > 0 && M > 0 && M % tokens == 0, AVD_EINVAL, "gemm_bf16x3_qkv3: rows %lld not a multiple of tokens %d",
                 (long long)M, tokens);
+    AVD_REQUIRE(M < (1ll << 31) - 256, AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: more than 2^31 rows");
     AVD_REQUIRE(gemm_bf16x3_supported(M, N, K), AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: need 3*heads*64 %% 256 == 0 and K %% 16 == 0");
     AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(bias) && aligned16(img), AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: alignment");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, nullptr, nullptr,
-             static_cast<unsigned char*>(img), M, N, K, 0, 0, 0, tokens, qkv3_npad(tokens), heads, qscale, 0, 0, terms, 1.0f / ab_scale, c_scale};
+             static_cast<unsigned char*>(img), M, N, K, 0, 0, 0, tokens, qkv3_npad(tokens), heads, qscale, 0, 0, terms, 1.0f / ab_scale, c_scale,
+             ss_in, nullptr, (float)sqrt((double)K), eps};
     return launch_s3<S3_EPI_QKV3>(a, st);
 }
 

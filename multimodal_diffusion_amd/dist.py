@@ -86,6 +86,16 @@ def max_over_ranks(value: float, device: torch.device) -> float:
     return float(t.item())
 
 
+def gather_scalars(value: float, device: torch.device) -> list:
+    """[value of rank 0, value of rank 1, ...] on every rank (verification aid, outside the data path)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(value)]
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, t)
+    return [float(p.item()) for p in parts]
+
+
 def barrier():
     if dist.is_initialized() and dist.get_world_size() > 1:
         dist.barrier()

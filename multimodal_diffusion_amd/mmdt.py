@@ -260,6 +260,14 @@ class MMDiT(nn.Module):
                 if sc:
                     for j in range(8):
                         arr[i].f16x2_scale[j] = sc[j]
+                elif self.fold_norms:
+                    # bf16 plane modes: images of W * norm.scale[None, :] let the composite fold norm1 / norm2 into the neighbouring
+                    # epilogues (csrc/composite.hip core_use_split_fold)
+                    for k, scn in (("in_proj_weight", "norm1_scale"), ("fc1_weight", "norm2_scale")):
+                        wn = self._folded_weight(f"{i}.{k}", L.dev_f32(ps[k].detach(), k), L.dev_f32(ps[scn].detach(), scn))
+                        img = self._split3_image(f"{i}.{k}.n", wn)
+                        keep.append(img)
+                        setattr(arr[i], k + "3n", img.data_ptr())
         ln = isinstance(self.final_norm, LayerNorm)
         fin = L.dev_f32((self.final_norm.weight if ln else self.final_norm.scale).detach(), "final_norm.scale")
         keep.append(fin)

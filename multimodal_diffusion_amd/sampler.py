@@ -100,6 +100,21 @@ def tokens_to_latents_audio(tokens: torch.Tensor, Ca: int, l_chunk: int, Fa: int
 # batched on-device loop
 # ----------------------------------------------------------------------------------------------------------
 
+class _CapturedPair:
+    """A captured two-step HIP graph of one engine.  ``replay()`` first re-checks the engine's weight tables: parameters updated in
+    place behind unchanged pointers are picked up (derived images are refreshed in place), a re-allocated parameter or a changed
+    by-value scale raises instead of replaying kernels that hold the old value."""
+
+    def __init__(self, engine: "DenoiseEngine", graph: "torch.cuda.CUDAGraph"):
+        self.engine, self.graph = engine, graph
+
+    def replay(self) -> None:
+        self.engine._sync_weights()
+        if not self.engine._captured:
+            raise L.AvdError("this captured graph is stale (the engine's tables changed since capture_pair()); capture again")
+        self.graph.replay()
+
+
 class DenoiseEngine:
     """One direction (``target`` in {"video","audio"}) of the CFG + DDIM loop for a batch of independent samples.
 
@@ -221,19 +236,39 @@ class DenoiseEngine:
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         self._ptrs = self._table_ptrs()
+        self._scalars = self._table_scalars()
         self._wkey = self._weights_key()
 
     def _table_ptrs(self):
         return tuple(t.data_ptr() for t in self._keep_core[1]) + tuple(t.data_ptr() for t in self._keep_head[1]) + \
             (self._aw.data_ptr(), self._ab.data_ptr())
 
+    def _table_scalars(self):
+        """Every BY-VALUE number of the tables: a captured HIP graph bakes these into its kernel arguments (the f16x2 image scales
+        become 1/(s_A s_W) factors and split scales of the launches), so unlike weights behind unchanged pointers they do not follow
+        an in-place parameter update."""
+        cw, hw = self._core_tab, self._head_tab
+        blocks = self._keep_core[0]
+        out = [cw.d, cw.n_layers, cw.n_heads, cw.mlp_hidden, cw.norm_eps, cw.norm_kind, cw.split_terms, cw.attn_mode,
+               hw.d_in, hw.hidden, hw.d_out, hw.n_shared, hw.ln_eps, hw.act, hw.split_terms, self.guidance, self.eta]
+        if cw.split_terms == 3:
+            for i in range(cw.n_layers):
+                out += list(blocks[i].f16x2_scale)
+        if hw.split_terms == 3 and hw.f16x2_scale:
+            out += [hw.f16x2_scale[i] for i in range(2 * (hw.n_shared + 2))]
+        return tuple(float(v) for v in out)
+
     def _sync_weights(self) -> None:
         if self._weights_key() == self._wkey:
             return
-        old = self._ptrs
+        old, old_sc = self._ptrs, self._scalars
         self._bind_weights()             # derived copies are refreshed in place where shapes allow
         if self._captured and self._ptrs != old:
             raise L.AvdError("a parameter was re-allocated after a HIP graph of this engine was captured; capture again")
+        if self._captured and self._scalars != old_sc:
+            self._captured = False       # the next capture_pair() starts from the new tables
+            raise L.AvdError("an in-place parameter update changed a scale that the captured HIP graph holds by value (f16x2 image "
+                             "scales follow max|w| and the norm gains): replaying it would divide by the old scales; capture again")
         if self._prompt_latent is not None:
             self.set_prompt(self._prompt_latent)     # the cached prompt rows depend on the prompt adapter
 
@@ -313,7 +348,7 @@ class DenoiseEngine:
                                           L.stream_ptr(self.device)))
         self.step(src, self._tn, self._tp, out=dst)
 
-    def capture_pair(self, za: torch.Tensor, zb: torch.Tensor) -> "torch.cuda.CUDAGraph":
+    def capture_pair(self, za: torch.Tensor, zb: torch.Tensor) -> "_CapturedPair":
         """Capture two steps (za -> zb -> za) into one HIP graph; replaying it advances the trajectory by two."""
         if self.eta > 0:
             raise NotImplementedError("graph replay with eta > 0 would replay the same noise")
@@ -323,7 +358,7 @@ class DenoiseEngine:
             self.advance(za, zb)
             self.advance(zb, za)
         self._captured = True
-        return g
+        return _CapturedPair(self, g)
 
     GRAPH_BELOW_ROWS = 6144      # 2B*N under which a step's ~60-95 launches are host-bound: replay them from a HIP graph
 

@@ -16,6 +16,16 @@ GOLDEN = ROOT / "tests" / "golden"
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_first: a GPU test that launches child processes; ordered before every other test")
+
+
+def pytest_collection_modifyitems(config, items):
+    """Tests marked `gpu_first` start child processes that use the GPU (torch.distributed.run): they must run BEFORE this process
+    touches the device (on the GPU boxes a process that has initialised HIP may not fork + exec another program), so they go first."""
+    first = [it for it in items if it.get_closest_marker("gpu_first")]
+    if first:
+        rest = [it for it in items if not it.get_closest_marker("gpu_first")]
+        items[:] = first + rest
 
 
 def load_golden(name):

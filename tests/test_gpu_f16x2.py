@@ -383,8 +383,15 @@ def test_two_stream_cfg_halves_are_bit_identical(dev, full, mode):
         eng.set_prompt(za)
         outs[split] = (eng.run(z, sched, graph=False), eng.run(z, sched, graph=True))
     assert torch.isfinite(outs[True][0]).all()
-    assert torch.equal(outs[False][0], outs[True][0]) and torch.equal(outs[False][1], outs[True][1])
-    assert torch.equal(outs[True][0], outs[True][1])
+
+    def same(a, b, what):
+        d = (a - b).abs()
+        bad = ((d > 0) | torch.isnan(d)).nonzero()
+        assert torch.equal(a, b), f"{what}: max |diff| {float(d.max()):.3e} in {len(bad)} elements of samples {bad[:, 0].unique().tolist()}"
+
+    same(outs[False][0], outs[True][0], "two streams vs one, eager")
+    same(outs[False][1], outs[True][1], "two streams vs one, graph replay")
+    same(outs[True][0], outs[True][1], "two streams: eager vs graph replay")
     core, head, av, aa = _full_modules(dev, ws)
     auto = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z.shape),
                            prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=mode)
@@ -686,3 +693,62 @@ def test_f16x2_fuzz_weight_and_input_scales(dev, seed):
         assert torch.isfinite(y).all(), mode
         errs[mode] = rel_err(y[:1], ref)
     assert errs["f16x2"] < max(TOL, 3.0 * errs["f32"]), errs
+
+
+def test_captured_graph_refuses_stale_scales(dev, full):
+    """a captured f16x2 step holds the image scales BY VALUE (kernel arguments).  An in-place update that moves max|w|
+    across a power of two (here a norm gain x64 with in_proj / 64) leaves every pointer unchanged — the replay must raise instead
+    of dividing by the old scales; an update that keeps the scales replays and follows the new weights; capturing again works."""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd import schedule_utils as su, _lib as L
+    ws, _ = full
+    B = 4
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(B, 8, 12, 32, 32, generator=g).to(dev)
+    za = torch.randn(B, 8, 150, generator=g).to(dev)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    sched = su.make_sampling_schedule(1000, 6)
+    core, head, av, aa = _full_modules(dev, ws)
+    eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z.shape),
+                          prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul="f16x2")
+    eng.set_prompt(za)
+    eng.begin(sched)
+    a, b = z.clone(), torch.empty_like(z)
+    eng.advance(a, b)                       # lazy init outside capture
+    eng.rewind()
+    a.copy_(z)
+    graph = eng.capture_pair(a, b)
+    graph.replay()
+    torch.cuda.synchronize()
+    first = a.clone()
+    # an update that keeps every scale: a bias moves (biases are far below the bounds' power-of-two steps)
+    with torch.no_grad():
+        core.blocks[2].mlp.fc2.bias.add_(1e-3)
+    eng.rewind()
+    a.copy_(z)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all() and not torch.equal(a, first), "the replay did not follow an in-place update behind unchanged pointers"
+    # an update that moves scales by 2^6
+    with torch.no_grad():
+        core.blocks[0].norm1.scale.mul_(64.0)
+        core.blocks[0].attn.mha.in_proj_weight.mul_(1.0 / 64.0)
+    eng.rewind()
+    a.copy_(z)
+    with pytest.raises(L.AvdError, match="capture again"):
+        graph.replay()
+    with pytest.raises(L.AvdError, match="capture again"):
+        graph.replay()                      # stays refused
+    graph2 = eng.capture_pair(a, b)
+    eng.rewind()
+    a.copy_(z)
+    graph2.replay()
+    torch.cuda.synchronize()
+    ref_eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z.shape),
+                              prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul="f16x2")
+    ref_eng.set_prompt(za)
+    ref_eng.begin(sched)
+    c, d = z.clone(), torch.empty_like(z)
+    ref_eng.advance(c, d)
+    ref_eng.advance(d, c)
+    assert torch.equal(a, c)

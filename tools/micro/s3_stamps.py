@@ -95,5 +95,6 @@ for mode, terms in (("f16x2", 3), ("bf16x3", 6), ("bf16", 1)):
         rt = (d[:, 9] - d[:, 10]).astype(np.float64) / 100e6      # s_memrealtime: 100 MHz, block entry -> exit
         ghz = float(np.median(life / 1e9 / np.maximum(rt, 1e-9)))
         per_step = float(((d[:, 2] - d[:, 1]) / steps).mean())
+        drain = float(((d[:, 3] - d[:, 4]) / life).mean())        # share of the block's life between the last store's issue and its completion
         print(f"{mode:6s} {name:34s} {us:7.1f} us  blocks {len(d):4d}  clock ~{ghz:.2f} GHz | block life: prologue {pro.mean():.2f} loop {loop.mean():.2f} "
-              f"epilogue {epil.mean():.2f} ({life.mean():.0f} cyc) | {per_step:6.0f} cyc per K step (MFMA issue floor {mfma_per_step} per wave, x2 waves per SIMD = {2 * mfma_per_step})")
+              f"epilogue {epil.mean():.2f} of which store drain {drain:.2f} ({life.mean():.0f} cyc) | {per_step:6.0f} cyc per K step (MFMA issue floor {mfma_per_step} per wave, x2 waves per SIMD = {2 * mfma_per_step})")
