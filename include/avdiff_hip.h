@@ -320,7 +320,9 @@ int64_t avd_core_workspace_bytes(const avd_core_weights* w, int B, int N);
 /* MMDiT.forward(x) -> y, x,y: [B,N,d] (y may alias x).  n_out_rows: number of leading rows per sample whose
  * output is needed (N = reference behaviour; fewer lets the last block skip dead rows when the caller only
  * consumes the first n_out_rows — the engine passes the target-row count). out_row0: first needed row.
- * key_padding_mask: NULL or bytes [B,N], see avd_attn_fwd_f32 (a mask keeps the step on the fp32 kernels). */
+ * key_padding_mask: NULL or bytes [B,N], see avd_attn_fwd_f32.  A mask, or norm_kind 1 (LayerNorm), keeps the whole forward on the fp32
+ * MFMA kernels whatever split_terms says — the split-operand attention takes no mask and the split producers are RMSNorm's; results
+ * are the fp32 path's, at its speed.  attn_mode 1 (fp8 attention) with either of them is refused (AVD_EUNSUPPORTED). */
 int avd_core_forward_f32(const avd_core_weights* w, const float* x, float* y, int B, int N,
                          int out_row0, int n_out_rows, const uint8_t* key_padding_mask, void* workspace,
                          int64_t workspace_bytes, avd_stream_t stream);

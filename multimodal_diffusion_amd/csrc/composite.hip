@@ -200,6 +200,11 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
     const RowMap rd{d, 0, 0}, r3{3 * d, 0, 0}, rh{hid, 0, 0};
     const float scale = 1.0f / sqrtf((float)(d / H));
     const float* cur = x;                                           // residual stream lives in y after the first write
+    // a key-padding mask or norm="layernorm" keeps the whole forward on the fp32 kernels (the split-operand attention has no mask
+    // input, the split producers are RMSNorm's): same results at fp32-MFMA speed, documented in the header.  The fp8 attention is an
+    // explicit reduced-precision request and is refused rather than silently replaced.
+    AVD_REQUIRE(!(w->attn_mode == 1 && (kpm || w->norm_kind != 0)), AVD_EUNSUPPORTED,
+                "core: attn_mode 1 (fp8 attention) cannot be combined with a key_padding_mask or norm_kind 1 (LayerNorm)");
     if (!kpm && core_use_split(w, M)) {
         // same op sequence with the four projections on the bf16 matrix pipe (gemm_bf16x3.hip); hs / wide3 are split3 images
         const int terms = w->split_terms;
