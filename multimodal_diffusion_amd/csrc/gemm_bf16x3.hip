@@ -227,44 +227,7 @@ __device__ __forceinline__ void s3_epilogue(const S3Args& g, f32x16 (&acc)[4][2]
 #pragma unroll
                 for (int r = 0; r < 16; ++r) slab[(i * 32 + mfma32_row(r, hi)) * CLD + j * 32 + l31] = acc[ps * 2 + i][j][r];
         const int64_t m0 = mwave0 + ps * 64;
-        if constexpr (EPI == S3_EPI_QKV3) {
-            // packed in_proj output -> the qkv3 image attn_bf16x3.hip reads: a wave's 64 columns are one (part, head)
-            const int cr = lane >> 3, c = lane & 7;
-            const int n = nbase + c * 8;
-            const int dmodel = g.heads * 64;
-            const int part = nbase / dmodel, head = (nbase % dmodel) >> 6;
-            const int Bt = (int)(g.M / g.tokN);
-            float bv[8];
-            *reinterpret_cast<f32x4*>(bv) = *reinterpret_cast<const f32x4*>(g.bias + n);
-            *reinterpret_cast<f32x4*>(bv + 4) = *reinterpret_cast<const f32x4*>(g.bias + n + 4);
-            const float mul = part == 0 ? g.qscale : 1.0f;
-            unsigned char* pbase = g.C3 + (((int64_t)part * Bt) * g.heads + head) * (int64_t)g.tokNpad * QKV3_ROWB;
-#pragma unroll
-            for (int it = 0; it < 8; ++it) {
-                const int64_t m = m0 + cr + it * 8;
-                float v[8];
-                *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + c * 8);
-                *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(slab + (cr + it * 8) * CLD + c * 8 + 4);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = ((F16 ? v[e] * g.ab_inv : v[e]) + bv[e]) * mul;
-                if (m < g.M) {
-                    const int b = (int)(m / g.tokN), tok = (int)(m - (int64_t)b * g.tokN);
-                    unsigned char* dst = pbase + ((int64_t)b * g.heads * g.tokNpad + tok) * QKV3_ROWB + ((c ^ qkv3_swizzle(part, tok)) << 4);
-                    if constexpr (F16) {
-                        u32x4 Hh, Lo;
-                        split8_h2(v, g.c_scale, Hh, Lo);
-                        *reinterpret_cast<u32x4*>(dst) = Hh;
-                        *reinterpret_cast<u32x4*>(dst + 128) = Lo;
-                    } else {
-                        u32x4 Hh, Mi, Lo;
-                        split8(v, Hh, Mi, Lo);
-                        *reinterpret_cast<u32x4*>(dst) = Hh;
-                        *reinterpret_cast<u32x4*>(dst + 128) = Mi;
-                        *reinterpret_cast<u32x4*>(dst + 256) = Lo;
-                    }
-                }
-            }
-        } else if constexpr (EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT) {
+        if constexpr (EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT) {      // (kept for reference builds; the kernel takes the register epilogue)
             // 8 lanes per row (8 columns each), 8 rows per wave instruction
             const int cr = lane >> 3, cc = (lane & 7) * 8;
             const int n = nbase + cc;

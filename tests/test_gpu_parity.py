@@ -1038,6 +1038,33 @@ def test_full_step_f32_512(dev, full):
     assert rel_err(out[:1], ref) < TOL
 
 
+@pytest.mark.parametrize("matmul", ["bf16x3", "f16x2", "bf16x3_strict"])
+def test_full_step_c3_batch32_split_modes(dev, full, matmul):
+    """The bench's workload exactly — BASELINE C3: 256x256, 384 + 37 tokens, batch 32 (2B*N = 26,944 rows: the 8-wave 256x256 and the
+    4-wave 256x128 split GEMMs, folded norms, four rounds of attention blocks) — in the headline mode (bf16x3), its strict variant and
+    the speed mode (f16x2), one CFG step against the CPU oracle on samples from the start, the middle and the end of the batch
+    (only bench.py checked B = 32; smaller batches take other tile counts and super-tile shapes)."""
+    import multimodal_diffusion_amd as A
+    ws, mods = full
+    core, head, av, aa = mods
+    B, idx = 32, [0, 17, 31]
+    g = torch.Generator().manual_seed(2560)
+    z_v = torch.randn(B, 8, 12, 32, 32, generator=g)
+    z_a = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn = torch.tensor(([982, 500, 16, 999] * B)[:B])
+    tp = torch.tensor(([966, 480, -1, 979] * B)[:B])
+    eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z_v.shape),
+                          prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=matmul)
+    eng.set_prompt(z_a.to(dev))
+    out = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)).cpu()
+    ref = R.denoise_step_a2v(z_v[idx], z_a[idx], tn[idx], tp[idx], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"], core=ws["core"],
+                             head=ws["head"], n_layers=8, n_heads=8, guidance=3.5)
+    err = rel_err(out[idx], ref)
+    print(f"C3 batch 32, {matmul}: rel err vs CPU oracle {err:.3e}")
+    assert torch.isfinite(out).all() and err < TOL
+
+
 def test_full_step_c2_batch32(dev, full):
     """BASELINE C2 shape at its real batch: 64x64, N = 61, B = 32 (3,904 rows -> the 64x64 tiles), fp32; first two samples."""
     ws, mods = full
