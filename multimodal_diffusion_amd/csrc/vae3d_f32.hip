@@ -398,8 +398,8 @@ __global__ __launch_bounds__(256) void gn_pool_tolat_kernel(const float* __restr
 // [54][3 planes][64 out][32 ch] with its 16-byte chunks pre-swizzled for the LDS reads.
 // =========================================================================================================
 constexpr int A3_ROWB = 384;                   // bytes per voxel of the act3 buffer
-constexpr int W3_STAGE = 3 * 64 * 64;          // weight bytes per (tap, half-tap) stage
-constexpr int W3_BYTES = 54 * W3_STAGE;
+constexpr int W3_STAGE = 3 * 64 * 32;          // weight bytes per (16-channel slab, tap) stage: [plane][64 out][32 B]
+constexpr int W3_BYTES = 108 * W3_STAGE;
 
 struct Conv3Args {
     const unsigned char* X3;   // act3, padded [B, T+2, H+2, W+2] voxels x 384 B
@@ -428,30 +428,30 @@ __global__ void pow2_scale_kernel(float* ws) {
     ws[3] = 1.0f / s;
 }
 
-// Wt [64 out][27 taps][64 in] fp32 -> weight image: stage kt = 2*tap + half holds [plane][out][4 chunks of 8 in-channels],
-// chunk c of row `out` at slot c ^ ((out>>2)&3)
+// Wt [64 out][27 taps][64 in] fp32 -> weight image of the halo-tile kernel: stage kt = 27 * slab + tap (slab = 16 input channels)
+// holds [plane][64 out][32 B]; the 16-byte chunk `half` (8 in-channels) of row `out` sits at slot half ^ ((out >> 3) & 1)
 template <bool F16>
 __global__ __launch_bounds__(256) void conv3_weight_kernel(const float* __restrict__ Wt, unsigned char* __restrict__ img, float sc) {
     const int i = blockIdx.x * 256 + threadIdx.x;          // one thread = 8 in-channels of one (stage, out)
-    if (i >= 54 * 64 * 4) return;
-    const int c = i & 3, out = (i >> 2) & 63, kt = i >> 8;
-    const int tap = kt >> 1, half = kt & 1;
+    if (i >= 108 * 64 * 2) return;
+    const int half = i & 1, out = (i >> 1) & 63, kt = i >> 7;
+    const int slab = kt / 27, tap = kt % 27;
     float v[8];
-    const float* src = Wt + ((int64_t)out * 27 + tap) * VC + half * 32 + c * 8;
+    const float* src = Wt + ((int64_t)out * 27 + tap) * VC + slab * 16 + half * 8;
     *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(src);
     *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(src + 4);
-    unsigned char* dst = img + (int64_t)kt * W3_STAGE + out * 64 + ((c ^ ((out >> 2) & 3)) << 4);
+    unsigned char* dst = img + (int64_t)kt * W3_STAGE + out * 32 + ((half ^ ((out >> 3) & 1)) << 4);
     if constexpr (F16) {
         u32x4 Hh, Lo;
         split8_h2(v, sc, Hh, Lo);
         *reinterpret_cast<u32x4*>(dst) = Hh;
-        *reinterpret_cast<u32x4*>(dst + 4096) = Lo;
+        *reinterpret_cast<u32x4*>(dst + 2048) = Lo;
     } else {
         u32x4 Hh, Mi, Lo;
         split8(v, Hh, Mi, Lo);
         *reinterpret_cast<u32x4*>(dst) = Hh;
-        *reinterpret_cast<u32x4*>(dst + 4096) = Mi;
-        *reinterpret_cast<u32x4*>(dst + 8192) = Lo;
+        *reinterpret_cast<u32x4*>(dst + 2048) = Mi;
+        *reinterpret_cast<u32x4*>(dst + 4096) = Lo;
     }
 }
 
@@ -530,16 +530,43 @@ __global__ __launch_bounds__(256) void gn_apply_pad3_kernel(const float* __restr
     store_act3<F16>(X3, pv, c8, o, sc);
 }
 
-// conv 3x3x3 64 -> 64 + bias + GELU + GroupNorm partial statistics, bf16x3.  128 voxels x 64 out per block, 4 waves (64 x 32 each),
-// K-stage = half a tap (32 channels = two MFMA k-steps), two 36 KiB LDS stages, two blocks per CU.
-// LDS image of a stage: A [plane][128 voxels][64 B], W [plane][64 out][64 B]; 16-byte chunk c of row r at slot c ^ ((r>>2)&3).
+// conv 3x3x3 64 -> 64 + bias + GELU + GroupNorm partial statistics on the 16-bit matrix pipe — HALO-TILE kernel (round 3).
+// Rounds 1-2 ran this as an implicit GEMM that re-fetched the block's A tile from global memory for every tap (27 x), 12-24 MFMAs
+// per wave between barriers on a 64 x 32 wave tile: 0.30 of the matrix peak, a K stage of ~2,150 cycles of which ~770 were MFMA.
+// Here a block owns an OUTPUT tile of 4 x TH x 16 voxels (TH = 8 for two planes, 4 for three) and, per slab of 16 input channels,
+// stages the INPUT tile with its one-voxel halo — 6 x (TH+2) x 18 voxels — in LDS ONCE; the 27 taps are then 27 MFMA k-steps whose A
+// fragments are read from that tile at constant row shifts, and only the 4-6 KiB weight stage of a (slab, tap) is moved per step
+// (ring of three).  Global -> LDS traffic per MFMA drops ~9x; a wave owns one t-slice: TH x 16 voxels x 64 output channels
+// (TM = TH / 2 row tiles of 2 x 16 voxels, 2 column tiles), 24 MFMAs per step, fragments one step ahead in registers.
+// LDS image of the halo tile: [voxel (tz, hy, wx)][2 NPL chunks of 16 B = (plane, k-half)], chunk c of a voxel at slot
+//   two planes:   c ^ ((wx >> 1) & 3)          three planes:   (c + 3 ((wx >> 1) & 1)) mod 6
+// — found by exhaustive search: every ds_read_b128 of a 2 x 16-voxel fragment is bank-conflict free at all 27 tap shifts.
+// Weight stage: [plane][64 out][32 B], k-half at slot half ^ ((out >> 3) & 1) (conv3_weight_kernel).
+constexpr int HT_T = 4, HT_W = 16, HT_HW = HT_W + 2;
+template <int TERMS> struct HaloCfg {
+    static constexpr int NPL = s3_planes(TERMS);
+    static constexpr int TH = NPL == 2 ? 8 : 4, HH = TH + 2;
+    static constexpr int TM = TH / 2;                                  // 32-voxel row tiles per wave
+    static constexpr int NCH = 2 * NPL, RB = 16 * NCH;                // chunks / bytes per voxel of one 16-channel slab
+    static constexpr int HVOX = (HT_T + 2) * HH * HT_HW;              // 1,080 / 648 voxels
+    static constexpr int NPIECE = (HVOX * NCH + 63) / 64;             // 1-KiB DMA pieces of one halo tile: 68 / 61
+    static constexpr int HALO_B = NPIECE * 1024;
+    static constexpr int WST = 64 * 32 * NPL;                         // live bytes of a weight stage: 4 / 6 KiB
+    static constexpr int NWS = 3;                                     // weight ring
+    static constexpr int SLAB_B = 4 * 64 * 68 * 4;                    // epilogue slabs (4 waves x 64 rows), overlay everything
+    static constexpr int LDS = HALO_B + NWS * WST > SLAB_B ? HALO_B + NWS * WST : SLAB_B;
+    static constexpr int VOX = HT_T * TH * HT_W;                      // output voxels per block: 512 / 256
+};
+
 template <int TERMS>     // 6: bf16x3; 3: f16x2 (planes h, l of the same buffers; the third plane is neither moved nor read)
 __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
-    constexpr int BM = VBM, WM = 64, WN = 32, TM = 2;
-    constexpr int NPL = s3_planes(TERMS);
+    using Cf = HaloCfg<TERMS>;
+    constexpr int NPL = Cf::NPL, TH = Cf::TH, HH = Cf::HH, TM = Cf::TM, NCH = Cf::NCH, RB = Cf::RB, NWS = Cf::NWS, WST = Cf::WST;
     constexpr bool F16 = TERMS == 3;
-    constexpr int A_ST = 3 * BM * 64, STAGE = A_ST + W3_STAGE;       // 24 KiB + 12 KiB
+    constexpr int NSTEP = 4 * 27;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+    unsigned char* halo = smem3;
+    unsigned char* wring = smem3 + Cf::HALO_B;
 
     const int nwg = gridDim.x;
     int wg;
@@ -547,146 +574,237 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
         const int b = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
         wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
     }
-    const int smp = wg / g.tiles, tile = wg % g.tiles;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // tiles of one sample: nt x nh x nw, w fastest (neighbouring blocks of an XCD share halo voxels in its L2)
+    const int nw_t = (g.W + HT_W - 1) / HT_W, nh_t = (g.H + TH - 1) / TH, nt_t = (g.T + HT_T - 1) / HT_T;
+    const int per_smp = nw_t * nh_t * nt_t;
+    const int smp = wg / per_smp, tile = wg % per_smp;
+    const int w0 = (tile % nw_t) * HT_W, h0 = ((tile / nw_t) % nh_t) * TH, t0 = (tile / (nw_t * nh_t)) * HT_T;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // = the t-slice this wave owns
     const int l31 = lane & 31, hi = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int THW = g.T * g.H * g.W;
     const int Hp = g.H + 2, Wp = g.W + 2;
+    const int THW = g.T * g.H * g.W;
 
-    // DMA A: piece q = plane*8 + rowset (16 voxel rows x 64 B of one plane); wave w takes q = w + 4 i, i.e. row sets w and w + 4 of
-    // every plane.  Lane -> voxel row 16*rowset + lane/4, physical chunk lane%4.
-    const int r16 = lane >> 2, pc = lane & 3;
-    const unsigned char* a_src[2];
-#pragma unroll
-    for (int rs = 0; rs < 2; ++rs) {
-        const int trow = (wave + 4 * rs) * 16 + r16;
-        int v = tile * BM + trow;
-        v = v < THW ? v : THW - 1;
-        const int w = v % g.W, h = (v / g.W) % g.H, t = v / (g.W * g.H);
-        const int64_t pv = (((int64_t)smp * (g.T + 2) + t) * Hp + h) * Wp + w;      // tap (0,0,0) of this voxel
-        a_src[rs] = g.X3 + pv * A3_ROWB + ((pc ^ ((trow >> 2) & 3)) << 4);
-    }
-    auto stage = [&](int kt, int buf) {
-        unsigned char* as = smem3 + buf * STAGE;
-        const int tap = kt >> 1, half = kt & 1;
-        const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
-        const int64_t offA = (int64_t)((dt * Hp + dh) * Wp + dw) * A3_ROWB + half * 64;   // same shift for every voxel of the tile
-#pragma unroll
-        for (int i = 0; i < 2 * NPL; ++i) {
-            const int plane = i >> 1, rs = i & 1;
-            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(a_src[rs] + offA + plane * 128),
-                                             AVD_LDS_PTR(as + plane * (BM * 64) + (wave + 4 * rs) * 1024), 16, 0, 0);
+    // ---- halo fill: piece q = 64 consecutive 16-byte chunks of the LDS image; lane -> (voxel, physical chunk) -> source address
+    auto fill_halo = [&](int slab) {
+#pragma unroll 1
+        for (int q = wave; q < Cf::NPIECE; q += 4) {
+            int L = q * 64 + lane;
+            L = L < Cf::HVOX * NCH ? L : Cf::HVOX * NCH - 1;        // tail of the last piece: any valid chunk (lands past the image)
+            const int hv = L / NCH, pc = L - hv * NCH;
+            const int tz = hv / (HH * HT_HW), rem = hv - tz * (HH * HT_HW);
+            const int hy = rem / HT_HW, wx = rem - hy * HT_HW;
+            int c;
+            if constexpr (NPL == 2) c = pc ^ ((wx >> 1) & 3);
+            else { c = pc - 3 * ((wx >> 1) & 1); c = c < 0 ? c + 6 : c; }
+            // padded coordinates, clamped to the buffer for ragged tiles (those voxels only feed outputs that are never stored)
+            int tt = t0 + tz, hh = h0 + hy, ww = w0 + wx;
+            tt = tt < g.T + 2 ? tt : g.T + 1;
+            hh = hh < Hp ? hh : Hp - 1;
+            ww = ww < Wp ? ww : Wp - 1;
+            const int64_t pv = (((int64_t)smp * (g.T + 2) + tt) * Hp + hh) * Wp + ww;
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(g.X3 + pv * A3_ROWB + (c >> 1) * 128 + slab * 32 + (c & 1) * 16),
+                                             AVD_LDS_PTR(halo + q * 1024), 16, 0, 0);
         }
+    };
+    // ---- weight stage kt = 27 slab + tap: NPL pieces of 2 KiB... 1-KiB pieces 2 NPL, dealt over the four waves
+    auto fill_w = [&](int kt) {
+        unsigned char* dst = wring + (kt % NWS) * WST;
 #pragma unroll
-        for (int j = 0; j < NPL; ++j) {
-            const int r = wave + 4 * j;
-            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(g.W3 + (int64_t)kt * W3_STAGE + r * 1024 + lane * 16),
-                                             AVD_LDS_PTR(as + A_ST + r * 1024), 16, 0, 0);
+        for (int i = 0; i < (2 * NPL + 3) / 4; ++i) {
+            const int pce = wave + 4 * i;
+            if (pce < 2 * NPL)
+                __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(g.W3 + (int64_t)kt * W3_STAGE + pce * 1024 + lane * 16), AVD_LDS_PTR(dst + pce * 1024), 16, 0, 0);
         }
     };
 
-    f32x16 acc[TM];
+    f32x16 acc[TM][2];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-    constexpr int nk = 54;
-    stage(0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0f70);
-    __syncthreads();
-
-    int a_row[TM], a_sw[TM];
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int r = wm * WM + i * 32 + l31;
-        a_row[i] = r * 64;
-        a_sw[i] = (r >> 2) & 3;
-    }
-    const int br = wn * WN + l31;
-    const int b_row = A_ST + br * 64, b_sw = (br >> 2) & 3;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, cur ^ 1);
-        const unsigned char* st = smem3 + cur * STAGE;
+    // fragment addressing.  A: lane (l31, hi) of row tile i reads voxel (tz = wave + dt, hy = 2 i + (l31 >> 4) + dh, wx = (l31 & 15) + dw),
+    // chunk (plane, hi) at its swizzled slot; B: out channel 32 j + l31, k-half hi
+    const int wl = l31 & 15, h2 = l31 >> 4;
+    const int a_vox0 = (wave * HH + h2) * HT_HW + wl;                 // tap (0,0,0), row tile 0
+    const int b_off0 = l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) << 4);      // column tile 0 (tile 1: + 1024; (out >> 3) & 1 is the same)
+    struct Frag { bf16x8 a[TM][NPL]; bf16x8 b[2][NPL]; };
+    auto load_frags = [&](Frag& f, int dt, int dh, int dw, const unsigned char* wst) {
+        const int wx = wl + dw;
+        const int vbase = a_vox0 + (dt * HH + dh) * HT_HW + dw;
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 af[TM][NPL], bf[NPL];
+        for (int p = 0; p < NPL; ++p) {
+            int pc;
+            if constexpr (NPL == 2) pc = (2 * p + hi) ^ ((wx >> 1) & 3);
+            else { pc = 2 * p + hi + 3 * ((wx >> 1) & 1); pc = pc >= 6 ? pc - 6 : pc; }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                f.a[i][p] = *reinterpret_cast<const bf16x8*>(halo + (vbase + 2 * i * HT_HW) * RB + pc * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) f.b[j][p] = *reinterpret_cast<const bf16x8*>(wst + p * 2048 + j * 1024 + b_off0);
+        }
+    };
+    constexpr int NT = F16 ? 3 : 6;
+    constexpr int PA[6] = {F16 ? 0 : 2, F16 ? 1 : 0, F16 ? 0 : 1, 1, 0, 0};      // f16x2: hl, lh, hh; bf16x3: small terms first
+    constexpr int PB[6] = {F16 ? 1 : 0, F16 ? 0 : 2, F16 ? 0 : 1, 0, 1, 0};
+    auto mma_step = [&](const Frag& f) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int p = 0; p < NPL; ++p)
-                    af[i][p] = *reinterpret_cast<const bf16x8*>(st + p * (BM * 64) + a_row[i] + (((2 * s + hi) ^ a_sw[i]) << 4));
-#pragma unroll
-            for (int p = 0; p < NPL; ++p) bf[p] = *reinterpret_cast<const bf16x8*>(st + p * 4096 + b_row + (((2 * s + hi) ^ b_sw) << 4));
-            constexpr int NT = F16 ? 3 : 6;
-            constexpr int PA[6] = {F16 ? 0 : 2, F16 ? 1 : 0, F16 ? 0 : 1, 1, 0, 0};      // f16x2: hl, lh, hh
-            constexpr int PB[6] = {F16 ? 1 : 0, F16 ? 0 : 2, F16 ? 0 : 1, 0, 1, 0};
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) acc[i] = mma16<F16>(af[i][PA[t]], bf[PB[t]], acc[i]);
-        }
-        __builtin_amdgcn_s_waitcnt(0x0f70);
-        __syncthreads();
-    }
+                for (int j = 0; j < 2; ++j) acc[i][j] = mma16<F16>(f.a[i][PA[t]], f.b[j][PB[t]], acc[i][j]);
+    };
 
-    // ---- epilogue (as conv3d_k3_gelu_stats_kernel): slab -> bias + GELU -> NDHWC store + GroupNorm partial statistics ----
-    constexpr int CLD = WN + 4;
-    float* slab = reinterpret_cast<float*>(smem3) + wave * WM * CLD;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) slab[(i * 32 + mfma32_row(r, hi)) * CLD + l31] = acc[i][r];
+    // prologue: halo of slab 0, weight stages 0 and 1; fragments of step 0
+    fill_halo(0);
+    fill_w(0);
+    fill_w(1);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
+    // three planes: 64 accumulator registers leave room for the fragments of TWO steps (those of step q+1 are read under the MFMAs
+    // of step q); two planes: 128 accumulator registers, one fragment set, read at the top of its step (the co-resident block covers)
+    constexpr bool PREFETCH = NPL == 3;
+    Frag f0, f1;
+    if constexpr (PREFETCH) load_frags(f0, 0, 0, 0, wring);
 
-    constexpr int LPR = WN / 4, RPI = 64 / LPR, NIT = WM / RPI;
-    const int cr = lane / LPR, cc = (lane % LPR) * 4;
-    const int n = wn * WN + cc;
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + n);
-    const float ab_inv = F16 ? g.ab_inv * (g.a_inv_dev ? g.a_inv_dev[0] : 1.0f) : 1.0f;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int v = tile * BM + wm * WM + cr + it * RPI;
-        f32x4 y = *reinterpret_cast<const f32x4*>(slab + (cr + it * RPI) * CLD + cc);
-        if constexpr (F16) y *= ab_inv;
-        y += bv;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) y[e] = gelu_erf(y[e]);
-        if (v < THW) {
-            *reinterpret_cast<f32x4*>(g.Y + ((int64_t)smp * THW + v) * VC + n) = y;
-            s1 += (y[0] + y[1]) + (y[2] + y[3]);
-            s2 += (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+    // step q = 27 slab + tap.  Top of step q: weight stage q+1 has landed (issued a step ago) -> barrier -> stage q+2 is issued into the
+    // slot stage q-1 vacated (its last read was the prefetch of step q-1's fragments, during step q-2).  The MFMAs of step q run on
+    // registers; the fragments of step q+1 are read meanwhile.  On the last tap of a slab the halo tile is refilled for the next slab:
+    // every wave has finished reading it (its last reads were the prefetch of THIS step), the refill is issued behind the barrier, the
+    // step's MFMAs run while it is in flight, and only then do the waves wait and read the next step's fragments from the new tile.
+    int dt = 0, dh = 0, dw = 0, slab = 0;
+    auto step = [&](int q, const Frag& cur, Frag& nxt) {
+        __builtin_amdgcn_s_waitcnt(0x0070);                 // vmcnt(0) lgkmcnt(0): this wave's DMA landed, its fragment reads returned
+        __builtin_amdgcn_s_barrier();
+        if (q + 2 < NSTEP) fill_w(q + 2);
+        // position of step q+1
+        int ndw = dw + 1, ndh = dh, ndt = dt, nslab = slab;
+        if (ndw == 3) { ndw = 0; ++ndh; }
+        if (ndh == 3) { ndh = 0; ++ndt; }
+        const bool last_tap = ndt == 3;
+        if (last_tap) { ndt = 0; ++nslab; }
+        const unsigned char* wnext = wring + ((q + 1) % NWS) * WST;
+        if (last_tap && nslab < 4) {
+            fill_halo(nslab);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_step(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0f70);
+            __builtin_amdgcn_s_barrier();
+            load_frags(nxt, ndt, ndh, ndw, wnext);
+        } else {
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < NSTEP) load_frags(nxt, ndt, ndh, ndw, wnext);
+            mma_step(cur);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        dt = ndt; dh = ndh; dw = ndw; slab = nslab;
+    };
+    auto step1 = [&](int q, Frag& f) {       // no prefetch: the step's fragments are read at its top
+        __builtin_amdgcn_s_waitcnt(0x0070);
+        __builtin_amdgcn_s_barrier();
+        if (q + 2 < NSTEP) fill_w(q + 2);
+        load_frags(f, dt, dh, dw, wring + (q % NWS) * WST);
+        if (++dw == 3) { dw = 0; ++dh; }
+        if (dh == 3) { dh = 0; ++dt; }
+        if (dt == 3) {                           // last tap of the slab: once every wave holds its fragments the tile is refilled
+            dt = 0;
+            ++slab;
+            if (slab < 4) {
+                __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
+                __builtin_amdgcn_s_barrier();
+                fill_halo(slab);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_step(f);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (PREFETCH) {
+#pragma unroll 1
+        for (int q = 0; q < NSTEP; q += 2) {
+            step(q, f0, f1);
+            step(q + 1, f1, f0);
+        }
+    } else {
+#pragma unroll 1
+        for (int q = 0; q < NSTEP; ++q) step1(q, f0);
     }
-    s1 += __shfl_xor(s1, 1, 64);  s2 += __shfl_xor(s2, 1, 64);
-    s1 += __shfl_xor(s1, 8, 64);  s2 += __shfl_xor(s2, 8, 64);
-    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-    if ((lane & 0x39) == 0) {
-        float* p = g.part + ((((int64_t)smp * g.tiles + tile) * 2 + wm) * VG + wn * 4 + (lane >> 1)) * 2;
-        p[0] = s1;
-        p[1] = s2;
+    __syncthreads();      // slabs overlay the halo tile and the weight ring
+
+    // ---- epilogue: 64-row passes through a per-wave LDS slab -> bias + GELU -> NDHWC store + GroupNorm partial statistics ----
+    constexpr int CLD = 64 + 4;
+    float* slab_f = reinterpret_cast<float*>(smem3) + wave * 64 * CLD;
+    const int cr = lane >> 4, cc = (lane & 15) * 4;          // 16 lanes per row (4 channels each), 4 rows per wave instruction
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + cc);
+    const float ab_inv = F16 ? g.ab_inv * (g.a_inv_dev ? g.a_inv_dev[0] : 1.0f) : 1.0f;
+    const int tt = t0 + wave;
+#pragma unroll
+    for (int ps = 0; ps < TM / 2; ++ps) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) slab_f[(i * 32 + mfma32_row(r, hi)) * CLD + j * 32 + l31] = acc[ps * 2 + i][j][r];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int row = cr + it * 4;                      // slab row: row tile ps*2 + row/32, voxel (h2, wl) = ((row%32)/16, row%16)
+            const int hh = h0 + 2 * (ps * 2 + (row >> 5)) + ((row >> 4) & 1), ww = w0 + (row & 15);
+            f32x4 y = *reinterpret_cast<const f32x4*>(slab_f + row * CLD + cc);
+            if constexpr (F16) y *= ab_inv;
+            y += bv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) y[e] = gelu_erf(y[e]);
+            if (tt < g.T && hh < g.H && ww < g.W) {
+                const int64_t v = ((int64_t)tt * g.H + hh) * g.W + ww;
+                *reinterpret_cast<f32x4*>(g.Y + ((int64_t)smp * THW + v) * VC + cc) = y;
+                s1 += (y[0] + y[1]) + (y[2] + y[3]);
+                s2 += (y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3]);
+            }
+        }
+        // lanes 2k, 2k+1 of a row hold the 8 channels of group k; rows: lane bits 4, 5
+        s1 += __shfl_xor(s1, 1, 64);  s2 += __shfl_xor(s2, 1, 64);
+        s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+        if ((lane & 0x31) == 0) {
+            // one partials entry per 64 stored-or-not voxels: entry index = (block x 4 waves + wave) x (TM / 2) + ps
+            const int64_t e = ((int64_t)tile * 4 + wave) * (TM / 2) + ps;
+            float* pp = g.part + (((int64_t)smp * g.tiles * 2 + e) * VG + (lane >> 1)) * 2;
+            pp[0] = s1;
+            pp[1] = s2;
+        }
     }
 }
 
 // launch of one 64 -> 64 convolution on the 16-bit matrix pipe (terms 0 / 6: bf16x3, 3: f16x2)
 static LdsAttr g_conv3_attr[2];      // dynamic-LDS limit of conv3d_k3_bf16x3_kernel<6> / <3> (per device)
-static int conv3_launch(const Conv3Args& a3, int terms, int B, int tiles, double flops, hipStream_t st) {
-    constexpr int lds3 = 2 * (3 * VBM * 64 + W3_STAGE);
+// blocks per sample of the halo-tile kernel, and the number of 128-voxel "tiles" its GroupNorm partials amount to (one partials
+// entry per 64 voxels of every block, whether the tile is ragged or not): what gn_finalize_kernel sums over for this conv
+template <int TERMS> static int conv3_blocks(int T, int H, int W) {
+    using Cf = HaloCfg<TERMS>;
+    return ((T + HT_T - 1) / HT_T) * ((H + Cf::TH - 1) / Cf::TH) * ((W + HT_W - 1) / HT_W);
+}
+static int conv3_tiles(int terms, int T, int H, int W) {
+    return terms == 3 ? conv3_blocks<3>(T, H, W) * (HaloCfg<3>::VOX / 128) : conv3_blocks<6>(T, H, W) * (HaloCfg<6>::VOX / 128);
+}
+static int conv3_launch(Conv3Args a3, int terms, int B, double flops, hipStream_t st) {
+    a3.tiles = conv3_tiles(terms, a3.T, a3.H, a3.W);
     if (terms == 3) {
-        if (int rc = g_conv3_attr[1].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<3>), lds3, "conv3d f16x2")) return rc;
+        if (int rc = g_conv3_attr[1].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<3>), HaloCfg<3>::LDS, "conv3d f16x2")) return rc;
         static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<3>");
         ProfScope prof(tag, flops, st);
-        hipLaunchKernelGGL(conv3d_k3_bf16x3_kernel<3>, dim3((unsigned)(B * tiles)), dim3(256), lds3, st, a3);
+        hipLaunchKernelGGL(conv3d_k3_bf16x3_kernel<3>, dim3((unsigned)(B * conv3_blocks<3>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<3>::LDS, st, a3);
     } else {
-        if (int rc = g_conv3_attr[0].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<6>), lds3, "conv3d bf16x3")) return rc;
+        if (int rc = g_conv3_attr[0].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<6>), HaloCfg<6>::LDS, "conv3d bf16x3")) return rc;
         static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<6>");
         ProfScope prof(tag, flops, st);
-        hipLaunchKernelGGL(conv3d_k3_bf16x3_kernel<6>, dim3((unsigned)(B * tiles)), dim3(256), lds3, st, a3);
+        hipLaunchKernelGGL(conv3d_k3_bf16x3_kernel<6>, dim3((unsigned)(B * conv3_blocks<6>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<6>::LDS, st, a3);
     }
     AVD_CHECK_LAUNCH("conv3d (split operands)");
     return AVD_OK;
@@ -725,7 +843,11 @@ static int vae_plan(const avd_vae_decode_desc* d, VaePlan& p) {
     p.pad_b = a256((int64_t)d->B * (d->T + 2) * (d->H + 2) * (d->W + 2) * (d->conv_w3 ? A3_ROWB : VC * 4));
     p.y_b = a256((int64_t)d->B * p.THW * VC * 4);
     p.hlow_b = a256((int64_t)d->B * d->Tp * d->Hp * d->Wp * VC * 4);
-    p.part_b = a256((int64_t)d->B * p.tiles * 2 * VG * 2 * 4);
+    {
+        const int t3 = conv3_tiles(3, d->T, d->H, d->W), t6 = conv3_tiles(6, d->T, d->H, d->W);
+        const int tmax = p.tiles > t3 ? (p.tiles > t6 ? p.tiles : t6) : (t3 > t6 ? t3 : t6);
+        p.part_b = a256((int64_t)d->B * tmax * 2 * VG * 2 * 4);
+    }
     p.stats_b = a256((int64_t)d->B * VG * 2 * 4) + 256;       // + the scale slot of the f16x2 decoder (4 floats)
     p.total = p.pad_b + p.y_b + p.hlow_b + p.part_b + p.stats_b;
     return AVD_OK;
@@ -830,20 +952,22 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
     constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
     for (int blk = 0; blk < d->n_blocks; ++blk) {
         ConvArgs a{Xp, d->conv_w[blk], d->conv_b[blk], Y, part, p.T, p.H, p.W, p.tiles};
+        int gn_tiles = p.tiles;           // partials entries / 2 the conv of this block writes (the halo-tile kernel has its own tiling)
         if (s3) {
             Conv3Args a3{X3, static_cast<const unsigned char*>(d->conv_w3[blk]), d->conv_b[blk], Y, part, p.T, p.H, p.W, p.tiles, 1.f, nullptr};
             if (h2) {
                 a3.ab_inv = blk == 0 ? 1.0f / d->conv_w_scale[0] : 1.0f / (d->conv_w_scale[blk] * d->conv_a_scale[blk]);
                 a3.a_inv_dev = blk == 0 ? scale_ws + 3 : nullptr;
             }
-            if (int rc = conv3_launch(a3, h2 ? 3 : 6, B, p.tiles, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st)) return rc;
+            if (int rc = conv3_launch(a3, h2 ? 3 : 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st)) return rc;
+            gn_tiles = conv3_tiles(h2 ? 3 : 6, p.T, p.H, p.W);
         } else {
             static const int tag = prof_tag_id("conv3d_k3_gelu_stats_kernel<64>");
             ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st);
             hipLaunchKernelGGL(conv3d_k3_gelu_stats_kernel<64>, dim3((unsigned)(B * p.tiles)), dim3(256), lds, st, a);
             AVD_CHECK_LAUNCH("conv3d");
         }
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * VG), dim3(256), 0, st, part, stats, p.tiles,
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * VG), dim3(256), 0, st, part, stats, gn_tiles,
                            (double)p.THW * (VC / VG), d->gn_eps);
         AVD_CHECK_LAUNCH("gn_finalize");
         if (blk + 1 < d->n_blocks && s3) {
@@ -902,7 +1026,11 @@ static int vae_enc_plan(const avd_vae_encode_desc* d, VaeEncPlan& p) {
     p.pad4_b = a256(padvox * 4 * 4);
     p.pad_b = d->n_blocks > 1 ? a256(padvox * (d->conv_w3 ? A3_ROWB : VC * 4)) : 0;
     p.y_b = a256((int64_t)d->B * p.THW * VC * 4);
-    p.part_b = a256((int64_t)d->B * p.tiles * 2 * VG * 2 * 4);
+    {
+        const int t3 = conv3_tiles(3, d->T, d->H, d->W), t6 = conv3_tiles(6, d->T, d->H, d->W);
+        const int tmax = p.tiles > t3 ? (p.tiles > t6 ? p.tiles : t6) : (t3 > t6 ? t3 : t6);
+        p.part_b = a256((int64_t)d->B * tmax * 2 * VG * 2 * 4);
+    }
     p.stats_b = a256((int64_t)d->B * VG * 2 * 4);
     p.total = p.pad4_b + p.pad_b + p.y_b + p.part_b + p.stats_b;
     return AVD_OK;
@@ -953,10 +1081,12 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
     constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
     for (int blk = 0; blk < d->n_blocks; ++blk) {
         ConvArgs a{blk == 0 ? Xp4 : Xp, d->conv_w[blk], d->conv_b[blk], Y, part, T, H, W, p.tiles};
+        int gn_tiles = p.tiles;
         if (blk > 0 && s3) {
             Conv3Args a3{X3, static_cast<const unsigned char*>(d->conv_w3[blk]), d->conv_b[blk], Y, part, T, H, W, p.tiles,
                          h2 ? 1.0f / (d->conv_w_scale[blk] * d->conv_a_scale[blk]) : 1.f, nullptr};
-            if (int rc = conv3_launch(a3, h2 ? 3 : 6, B, p.tiles, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st)) return rc;
+            if (int rc = conv3_launch(a3, h2 ? 3 : 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st)) return rc;
+            gn_tiles = conv3_tiles(h2 ? 3 : 6, T, H, W);
         } else if (blk == 0) {
             static const int tag = prof_tag_id("conv3d_k3_gelu_stats_kernel<4>");
             ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * d->in_ch, st);
@@ -967,7 +1097,7 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
             hipLaunchKernelGGL(conv3d_k3_gelu_stats_kernel<64>, dim3((unsigned)(B * p.tiles)), dim3(256), lds, st, a);
         }
         AVD_CHECK_LAUNCH("conv3d(enc)");
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * VG), dim3(256), 0, st, part, stats, p.tiles,
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * VG), dim3(256), 0, st, part, stats, gn_tiles,
                            (double)p.THW * (VC / VG), d->gn_eps);
         AVD_CHECK_LAUNCH("gn_finalize");
         if (blk + 1 < d->n_blocks && s3) {
