@@ -185,34 +185,83 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_gelu_stats_kernel(ConvArgs g
     }
 }
 
-// mean / rstd per (sample, group): fp64 reduction of the per-block partials in a fixed order
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
-                                                          int tiles, double count, float eps) {
-    __shared__ double sh1[256], sh2[256];
-    const int smp = blockIdx.x / VG, grp = blockIdx.x % VG;
-    double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < tiles * 2; i += 256) {
-        const float* p = part + (((int64_t)smp * tiles * 2 + i) * VG + grp) * 2;
-        a += p[0];
-        b += p[1];
-    }
-    sh1[threadIdx.x] = a;
-    sh2[threadIdx.x] = b;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            sh1[threadIdx.x] += sh1[threadIdx.x + o];
-            sh2[threadIdx.x] += sh2[threadIdx.x + o];
+// mean / rstd per (sample, group): fp64 reduction of the per-block partials in a fixed order.  One block of 1,024 threads per sample;
+// a thread reads whole 64-byte entries (the 8 groups x {sum, sum of squares} one conv wave wrote) and carries 16 fp64 sums, the
+// block folds them with xor shuffles and one pass through LDS.  (Rounds 1-2 ran one 256-thread block per (sample, group) over
+// 8-byte strided reads: 96 us per launch at 256 x 256 — latency, not bytes.)
+__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
+                                                           int tiles, double count, float eps) {
+    __shared__ double sh[16][2 * VG];
+    const int smp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double acc[2 * VG];
+#pragma unroll
+    for (int k = 0; k < 2 * VG; ++k) acc[k] = 0.0;
+    const float* base = part + (int64_t)smp * tiles * 2 * (2 * VG);
+    for (int i = tid; i < tiles * 2; i += 1024) {
+        const f32x4* e = reinterpret_cast<const f32x4*>(base + (int64_t)i * (2 * VG));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = e[q];
+            acc[4 * q] += v[0]; acc[4 * q + 1] += v[1]; acc[4 * q + 2] += v[2]; acc[4 * q + 3] += v[3];
         }
-        __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        const double mean = sh1[0] / count;
-        double var = sh2[0] / count - mean * mean;     // biased, as torch.nn.GroupNorm
+#pragma unroll
+    for (int k = 0; k < 2 * VG; ++k) {
+        double a = acc[k];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if (lane == 0) sh[wave][k] = a;
+    }
+    __syncthreads();
+    if (tid < VG) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int w = 0; w < 16; ++w) { s1 += sh[w][2 * tid]; s2 += sh[w][2 * tid + 1]; }
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;     // biased, as torch.nn.GroupNorm
         if (var < 0.0) var = 0.0;
-        stats[blockIdx.x * 2 + 0] = (float)mean;
-        stats[blockIdx.x * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        stats[(smp * VG + tid) * 2 + 0] = (float)mean;
+        stats[(smp * VG + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
+}
+
+// zero the one-voxel halo of a padded activation buffer [B][T+2][H+2][W+2] voxels x rowb bytes (the interior is overwritten by its
+// producer every time; a memset of the whole buffer moved 1.3 GB per decode at 256 x 256)
+__global__ __launch_bounds__(256) void zero_halo_kernel(unsigned char* __restrict__ buf, int B, int T, int H, int W, int rowb) {
+    const int Hp = H + 2, Wp = W + 2;
+    const int64_t n_t = 2ll * Hp * Wp, n_h = 2ll * T * Wp, n_w = 2ll * T * H, per = n_t + n_h + n_w;
+    const int c16 = rowb >> 4;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)B * per * c16) return;
+    const int c = (int)(gid % c16);
+    int64_t hidx = gid / c16;
+    const int smp = (int)(hidx / per);
+    hidx -= (int64_t)smp * per;
+    int t, h, w;
+    if (hidx < n_t) {                       // the two t faces, whole (H+2) x (W+2) planes
+        t = hidx < n_t / 2 ? 0 : T + 1;
+        const int64_t r = hidx % (n_t / 2);
+        h = (int)(r / Wp); w = (int)(r % Wp);
+    } else if (hidx < n_t + n_h) {          // the two h faces of the interior t range
+        const int64_t r = hidx - n_t;
+        const int64_t q = r % (n_h / 2);
+        h = r < n_h / 2 ? 0 : H + 1;
+        t = 1 + (int)(q / Wp); w = (int)(q % Wp);
+    } else {                                // the two w faces of the interior (t, h) range
+        const int64_t r = hidx - n_t - n_h;
+        const int64_t q = r % (n_w / 2);
+        w = r < n_w / 2 ? 0 : W + 1;
+        t = 1 + (int)(q / H); h = 1 + (int)(q % H);
+    }
+    const int64_t pv = (((int64_t)smp * (T + 2) + t) * Hp + h) * Wp + w;
+    *reinterpret_cast<u32x4*>(buf + pv * rowb + c * 16) = u32x4{0u, 0u, 0u, 0u};
+}
+static int zero_halo(void* buf, int B, int T, int H, int W, int rowb, hipStream_t st) {
+    const int64_t per = 2ll * (H + 2) * (W + 2) + 2ll * T * (W + 2) + 2ll * T * H;
+    const int64_t n = (int64_t)B * per * (rowb / 16);
+    AVD_REQUIRE(rowb % 16 == 0 && (n + 255) / 256 < (1ll << 31), AVD_EUNSUPPORTED, "zero_halo: bad geometry");
+    hipLaunchKernelGGL(zero_halo_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, static_cast<unsigned char*>(buf), B, T, H, W, rowb);
+    AVD_CHECK_LAUNCH("zero_halo");
+    return AVD_OK;
 }
 
 // GroupNorm apply: Y (NDHWC) -> interior of the padded NDHWC buffer feeding the next conv
@@ -236,47 +285,57 @@ __global__ __launch_bounds__(256) void gn_apply_pad_kernel(const float* __restri
     *reinterpret_cast<f32x4*>(Xp + pv * VC + c) = o;
 }
 
-// last block: GroupNorm apply + to_img (1x1x1, 64 -> Cout<=4) + sigmoid/tanh, NDHWC -> NCDHW
+// last block: GroupNorm apply + to_img (1x1x1, 64 -> Cout<=4) + sigmoid/tanh, NDHWC -> NCDHW.
+// A block takes 128 consecutive voxels: 16 lanes per voxel read one float4 of channels each (1 KiB per wave instruction, coalesced),
+// the 64-channel dot products are finished with four xor shuffles, and the Cout values of the 128 voxels go through LDS so that
+// every output plane is written as one 512-byte run (round 2 wrote them as 4-byte scattered stores: 1.9 TB/s; now the read rate).
+constexpr int TOIMG_VOX = 128;
 __global__ __launch_bounds__(256) void gn_apply_toimg_kernel(const float* __restrict__ Y, const float* __restrict__ stats,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              const float* __restrict__ Wimg, const float* __restrict__ bimg,
                                                              float* __restrict__ out, int THW, int Cout, int use_tanh,
                                                              int64_t nvox) {
-    // 16 lanes per voxel (one float4 of channels each): coalesced 1 KiB per wave instruction
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t vox = gid >> 4;
-    const int c = (int)(gid & 15) * 4;
-    const bool ok = vox < nvox;
-    const int64_t vx = ok ? vox : nvox - 1;
-    const int smp = (int)(vx / THW);
-    const float mean = stats[(smp * VG + c / 8) * 2], rstd = stats[(smp * VG + c / 8) * 2 + 1];
-    const f32x4 y = *reinterpret_cast<const f32x4*>(Y + vx * VC + c);
+    __shared__ float s_out[4][TOIMG_VOX];
+    const int tid = threadIdx.x;
+    const int c = (tid & 15) * 4, vsub = tid >> 4;
+    const int64_t vox0 = (int64_t)blockIdx.x * TOIMG_VOX;
     const f32x4 gm = *reinterpret_cast<const f32x4*>(gamma + c), bt = *reinterpret_cast<const f32x4*>(beta + c);
-    float xn[4];
+    f32x4 w[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) xn[e] = (y[e] - mean) * rstd * gm[e] + bt[e];
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int o = 0; o < 4; ++o) w[o] = o < Cout ? *reinterpret_cast<const f32x4*>(Wimg + o * VC + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int o = 0; o < 4; ++o) {          // static indices keep acc[] in registers
-        if (o < Cout) {
-            const f32x4 w = *reinterpret_cast<const f32x4*>(Wimg + o * VC + c);
-            float a = xn[0] * w[0] + xn[1] * w[1] + xn[2] * w[2] + xn[3] * w[3];
-            a += __shfl_xor(a, 1, 64);
-            a += __shfl_xor(a, 2, 64);
-            a += __shfl_xor(a, 4, 64);
-            a += __shfl_xor(a, 8, 64);
-            acc[o] = a;
+    for (int it = 0; it < TOIMG_VOX / 16; ++it) {
+        const int vl = it * 16 + vsub;
+        const int64_t vox = vox0 + vl;
+        const int64_t vx = vox < nvox ? vox : nvox - 1;
+        const int smp = (int)(vx / THW);
+        const float mean = stats[(smp * VG + c / 8) * 2], rstd = stats[(smp * VG + c / 8) * 2 + 1];
+        const f32x4 y = *reinterpret_cast<const f32x4*>(Y + vx * VC + c);
+        float xn[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xn[e] = (y[e] - mean) * rstd * gm[e] + bt[e];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {          // static indices keep everything in registers
+            if (o < Cout) {
+                float a = xn[0] * w[o][0] + xn[1] * w[o][1] + xn[2] * w[o][2] + xn[3] * w[o][3];
+                a += __shfl_xor(a, 1, 64);
+                a += __shfl_xor(a, 2, 64);
+                a += __shfl_xor(a, 4, 64);
+                a += __shfl_xor(a, 8, 64);
+                if ((tid & 15) == o) s_out[o][vl] = a;
+            }
         }
     }
-    const int o = (int)(gid & 15);
-    if (ok && o < Cout) {
-        float v = acc[0];
-        if (o == 1) v = acc[1];
-        if (o == 2) v = acc[2];
-        if (o == 3) v = acc[3];
-        v += bimg[o];
-        v = use_tanh ? tanhf(v) : 1.0f / (1.0f + expf(-v));
-        out[((int64_t)smp * Cout + o) * THW + (vx % THW)] = v;
+    __syncthreads();
+    for (int idx = tid; idx < TOIMG_VOX * Cout; idx += 256) {
+        const int o = idx / TOIMG_VOX, vl = idx % TOIMG_VOX;
+        const int64_t vox = vox0 + vl;
+        if (vox < nvox) {
+            float v = s_out[o][vl] + bimg[o];
+            v = use_tanh ? tanhf(v) : 1.0f / (1.0f + expf(-v));
+            const int64_t smp = vox / THW;
+            out[(smp * Cout + o) * THW + (vox - smp * THW)] = v;
+        }
     }
 }
 
@@ -905,11 +964,8 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
         for (int blk = 0; blk < d->n_blocks; ++blk) AVD_REQUIRE(d->conv_w3[blk], AVD_EINVAL, "vae_decode: null conv_w3[%d]", blk);
         if (int rc = check_conv_terms(d->conv_terms, d->conv_w_scale, d->conv_a_scale, d->n_blocks, 0, true)) return rc;
     }
-    // zero halo (whole padded buffer; interiors are overwritten below, the halo stays zero for every conv)
-    {
-        hipError_t e = hipMemsetAsync(Xp, 0, (size_t)B * (p.T + 2) * (p.H + 2) * (p.W + 2) * (s3 ? A3_ROWB : VC * 4), st);
-        if (e != hipSuccess) return set_error(AVD_ELAUNCH, "vae_decode memset: %s", hipGetErrorString(e));
-    }
+    // zero halo (interiors are overwritten below by the upsample / GroupNorm-apply passes, the halo stays zero for every conv)
+    if (int rc = zero_halo(Xp, B, p.T, p.H, p.W, s3 ? A3_ROWB : VC * 4, st)) return rc;
     {   // from_lat on the latent grid, then trilinear upsample into the padded conv input
         const int vol = d->Tp * d->Hp * d->Wp;
         const int64_t total = (int64_t)B * vol * VC;
@@ -967,7 +1023,7 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
             hipLaunchKernelGGL(conv3d_k3_gelu_stats_kernel<64>, dim3((unsigned)(B * p.tiles)), dim3(256), lds, st, a);
             AVD_CHECK_LAUNCH("conv3d");
         }
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * VG), dim3(256), 0, st, part, stats, gn_tiles,
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(1024), 0, st, part, stats, gn_tiles,
                            (double)p.THW * (VC / VG), d->gn_eps);
         AVD_CHECK_LAUNCH("gn_finalize");
         if (blk + 1 < d->n_blocks && s3) {
@@ -992,7 +1048,7 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
             const int64_t nvox = (int64_t)B * p.THW;
             static const int tag = prof_tag_id("gn_apply_toimg_kernel");
             ProfScope prof(tag, 4.0 * ((double)nvox * VC + (double)nvox * d->out_ch), st);
-            hipLaunchKernelGGL(gn_apply_toimg_kernel, dim3((unsigned)((nvox * 16 + 255) / 256)), dim3(256), 0, st, Y, stats,
+            hipLaunchKernelGGL(gn_apply_toimg_kernel, dim3((unsigned)((nvox + TOIMG_VOX - 1) / TOIMG_VOX)), dim3(256), 0, st, Y, stats,
                                d->gn_w[blk], d->gn_b[blk], d->to_img_w, d->to_img_b, out, (int)p.THW, d->out_ch,
                                d->out_tanh, nvox);
             AVD_CHECK_LAUNCH("gn_apply_toimg");
@@ -1059,7 +1115,6 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
     float* part = reinterpret_cast<float*>(w + p.pad4_b + p.pad_b + p.y_b);
     float* stats = reinterpret_cast<float*>(w + p.pad4_b + p.pad_b + p.y_b + p.part_b);
     const int B = d->B, T = d->T, H = d->H, W = d->W;
-    const int64_t padvox = (int64_t)B * (T + 2) * (H + 2) * (W + 2);
 
     const bool s3 = d->conv_w3 != nullptr && d->n_blocks > 1;     // split operands for the 64 -> 64 convolutions (block 0 is 4 -> 64, fp32)
     const bool h2 = s3 && d->conv_terms == 3;
@@ -1068,9 +1123,9 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
         for (int blk = 1; blk < d->n_blocks; ++blk) AVD_REQUIRE(d->conv_w3[blk], AVD_EINVAL, "vae_encode: null conv_w3[%d]", blk);
         if (int rc = check_conv_terms(d->conv_terms, d->conv_w_scale, d->conv_a_scale, d->n_blocks, 1, false)) return rc;
     }
-    hipError_t e = hipMemsetAsync(Xp4, 0, (size_t)padvox * 16, st);
-    if (e == hipSuccess && d->n_blocks > 1) e = hipMemsetAsync(Xp, 0, (size_t)padvox * (s3 ? A3_ROWB : VC * 4), st);
-    if (e != hipSuccess) return set_error(AVD_ELAUNCH, "vae_encode memset: %s", hipGetErrorString(e));
+    if (int rc = zero_halo(Xp4, B, T, H, W, 16, st)) return rc;
+    if (d->n_blocks > 1)
+        if (int rc = zero_halo(Xp, B, T, H, W, s3 ? A3_ROWB : VC * 4, st)) return rc;
     {
         const int64_t nvox = (int64_t)B * p.THW;
         hipLaunchKernelGGL(rgb_to_ndhwc4_pad_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, x, Xp4, d->in_ch,
@@ -1097,7 +1152,7 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
             hipLaunchKernelGGL(conv3d_k3_gelu_stats_kernel<64>, dim3((unsigned)(B * p.tiles)), dim3(256), lds, st, a);
         }
         AVD_CHECK_LAUNCH("conv3d(enc)");
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B * VG), dim3(256), 0, st, part, stats, gn_tiles,
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(1024), 0, st, part, stats, gn_tiles,
                            (double)p.THW * (VC / VG), d->gn_eps);
         AVD_CHECK_LAUNCH("gn_finalize");
         if (blk + 1 < d->n_blocks && s3) {
