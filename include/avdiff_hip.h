@@ -47,9 +47,10 @@ const char* avd_last_error(void);
 /* gfx arch name of device 0 as seen by the library ("gfx950"); diagnostic only. */
 int         avd_device_arch(char* buf, int buflen);
 /* Measurement / test hooks, process-wide, never needed for correct results: "gemm_tile" (-1 auto, 0 = 128x128, 1 = 128x64,
- * 2 = 64x64 LDS-DMA tile of avd_gemm_bias_act_f32), "gemm_stages" (0 by size, 2 / 3 LDS stages), "gemm_persist" (1 = persistent
- * tile-queue launch of the fp32 GEMM), "gemm_stagger", "s3_streamk" (1 = stream-K launch of the bf16x3 GEMMs), "s3_min_rows"
- * (smallest 2B*N that takes the bf16x3 kernels), "no_fold" (1 = keep RMSNorm as separate kernels in avd_core_forward_f32). */
+ * 2 = 64x64 LDS-DMA tile of avd_gemm_bias_act_f32), "gemm_stages" (0 by size, 2 / 3 LDS stages), "s3_tile" (-1 per epilogue, 0 = 8-wave
+ * 256x256, 1 = 4-wave 256x128 blocks of the split-operand GEMMs), "s3_stagger" (first-generation stagger of co-resident 4-wave blocks,
+ * x 1024 cycles; -1 automatic), "s3_min_rows" (smallest 2B*N that takes the split-operand kernels), "no_fold" (1 = keep RMSNorm as
+ * separate kernels in avd_core_forward_f32, fp32 and bf16-plane paths alike). */
 int         avd_tune_set(const char* key, int64_t value);
 
 /* ---- a6: RMSNorm — avdiff/models/mmdt.py:33-42 (RMSNorm.forward)
