@@ -161,7 +161,7 @@ __device__ __forceinline__ void store_split8(unsigned char* img, int64_t r, int 
     u32x4 H, Mi, Lo;
     split8<RANGE_CHECK>(v, H, Mi, Lo);
     const int rr = (int)(r & 127), half = (k >> 3) & 1;
-    unsigned char* dst = img + ((r >> 7) * (K >> 4) + (k >> 4)) * (int64_t)S3_CHUNK + rr * 32 + ((half ^ ((rr >> 3) & 1)) << 4);
+    unsigned char* dst = img + ((r >> 7) * (K >> 4) + (k >> 4)) * (int64_t)S3_CHUNK + rr * 32 + ((half ^ ((rr >> 4) & 1)) << 4);
     *reinterpret_cast<u32x4*>(dst) = H;
     *reinterpret_cast<u32x4*>(dst + S3_PLANE) = Mi;
     *reinterpret_cast<u32x4*>(dst + 2 * S3_PLANE) = Lo;
@@ -198,7 +198,7 @@ __device__ __forceinline__ void store_split8_h2(unsigned char* img, int64_t r, i
     u32x4 H, L;
     split8_h2(v, s, H, L);
     const int rr = (int)(r & 127), half = (k >> 3) & 1;
-    unsigned char* dst = img + ((r >> 7) * (K >> 4) + (k >> 4)) * (int64_t)S3_CHUNK + rr * 32 + ((half ^ ((rr >> 3) & 1)) << 4);
+    unsigned char* dst = img + ((r >> 7) * (K >> 4) + (k >> 4)) * (int64_t)S3_CHUNK + rr * 32 + ((half ^ ((rr >> 4) & 1)) << 4);
     *reinterpret_cast<u32x4*>(dst) = H;
     *reinterpret_cast<u32x4*>(dst + S3_PLANE) = L;
 }
@@ -268,6 +268,7 @@ int layernorm_act_split3_f32(const float* x, const float* gamma, const float* be
 bool gemm_bf16x3_supported(int64_t M, int N, int K);
 int attn_f32_split3(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st);
 extern int g_s3_stagger;
+extern int g_s3_m16;             // 1 (default): bf16x3 GEMMs on v_mfma_f32_16x16x32_bf16, two terms per MFMA; 0: 32x32x16 (avd_tune_set "s3_m16")
 extern int g_s3_tile;            // -1 = per epilogue; 0 / 1 = 8-wave 256x256 / 4-wave 256x128 blocks (avd_tune_set "s3_tile")
 extern thread_local bool t_s3_two_streams;
 // terms == 3 (f16x2): ab_scale = (A image scale) x (W image scale), c_scale = scale of the image written (if one is written)

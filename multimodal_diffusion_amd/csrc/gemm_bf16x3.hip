@@ -12,7 +12,8 @@
 //      hl, lh, hh on v_mfma_f32_32x32x16_f16: half the matrix-pipe work of bf16x3, measured error at or below the fp32 kernels'.
 //
 // Operand image ("split3"): X[rows][K] fp32 -> T[ceil(rows/128)][K/16][3 planes][128 rows][32 B]; inside a 12 KiB chunk
-// the 16 bytes of (plane p, row r, half = (k%16)/8) sit at p*4096 + r*32 + (half ^ ((r>>3)&1))*16.  One block's K-tile of
+// the 16 bytes of (plane p, row r, half = (k%16)/8) sit at p*4096 + r*32 + (half ^ ((r>>4)&1))*16 (conflict-free for the
+// ds_read_b128 fragment reads of BOTH MFMA shapes: 32 rows x k-half, and 16 rows x 4 k-groups).  One block's K-tile of
 // an operand is then contiguous, already bank-swizzled pieces — the global->LDS DMA copies whole 1 KiB pieces (only the planes the
 // mode uses), the ds_read_b128 of fragment rows is conflict free — and a producer's store of one plane for consecutive rows is
 // contiguous too.  Producers write the image directly (rmsnorm_split3_kernel and layernorm_act_split3_kernel here, the attention
@@ -546,7 +547,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_kernel(S3Args g) {
     // fragment addresses inside a stage: the wave's A rows all sit in region wm, its W rows in one W region, and rows 32 apart
     // are 1 KiB apart with the same chunk swizzle — one lane offset per operand, everything else is an immediate
     // (fragment i of plane p at a_base + i * 1024 + p * S3_PLANE)
-    const int swz = (hi ^ ((l31 >> 3) & 1)) << 4;
+    const int swz = (hi ^ ((l31 >> 4) & 1)) << 4;
     const int a_base = wm * RCH + l31 * 32 + swz;
     const int b_base = (2 + (wn * WN) / 128) * RCH + ((wn * WN) & 127) * 32 + l31 * 32 + swz;
 
@@ -743,6 +744,423 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_kernel(S3Args g) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// bf16x3 on v_mfma_f32_16x16x32_bf16, TWO product terms per MFMA (round 3)
+// ---------------------------------------------------------------------------------------------------------
+// Why: under the chip's power management the 16x16x32 shape sustains more than the 32x32x16 shape at equal cycles per FLOP — measured
+// on this pool (tools/micro/mfma_shapes.hip, random operands, two waves per SIMD): 2,07-2,14 against 1,79-1,86 PFLOP/s from registers,
+// 1,90 against 1,73 with every fragment re-read from LDS (MI355X_MICROARCH.md "DVFS give-back" item 7 reports the same 1.12-1.15x).
+// How, without touching the 16-k tiling of the images: the MFMA's K = 32 is fed with TWO planes of the same 16 k — lanes with k-group
+// kq = lane >> 4 in {0,1} carry plane X of k 8 kq .. +7, lanes with kq in {2,3} plane Y of k 8 (kq-2) .. +7 — so one MFMA sums two of
+// the six terms:   [h|l] x [l|h] = hl + lh,   [h|m] x [m|h] = hm + mh,   [h|m] x [h|m] = hh + mm      (small pairs first).
+// A 16-k step of the 128 x 64 wave tile is 3 groups of 32 MFMAs (16 cycles each: the same 1,536 matrix-pipe cycles as 48 of the
+// 32x32x16) on 8 x 4 accumulator tiles of 16 x 16 (128 registers, as before), fed by 28 ds_read_b128 (18 before); the fragment of
+// row tile i is one read per (pair type): lane (l15, kq) reads row 16 i + l15, k-half kq & 1 of plane (kq < 2 ? X : Y).  The image
+// swizzle (half ^ ((row >> 4) & 1)) keeps that read — and the 32-row read of the other modes — bank-conflict free.
+// Ring: the stage of tile kt stays resident during step kt (fragments are read group by group: all of them do not fit beside the
+// accumulators) and is refilled with tile kt + NST at the top of step kt + 1; DMA pieces are spread behind the MFMAs as above.
+// Accumulator tile (i, j), register r:  plain: row 16 i + 4 kq + r, column 16 j + l15;  transposed (image epilogues, W as the first
+// operand): row (of the output) 16 i + l15, columns 16 j + 4 kq + r — one v_permlane16_swap per register pair of two row tiles then
+// leaves every lane with 8 consecutive columns of one row: lane (l15, kq) holds row 16 (i + (kq & 1)) + l15, columns 16 j + 8 (kq >> 1) ...
+typedef float f32x4t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4t mma16x16(bf16x8 a, bf16x8 b, f32x4t c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// fp32 epilogues (bias / bias + residual) from plain accumulator tiles, through the per-wave LDS slab in two 64-row passes
+template <int EPI>
+__device__ __forceinline__ void s3_epilogue16(const S3Args& g, f32x4t (&acc)[8][4], float* slab, int64_t mwave0, int nbase, int lane) {
+    const int l15 = lane & 15, kq = lane >> 4;
+    constexpr int CLD = 64 + 4;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+#pragma unroll
+        for (int il = 0; il < 4; ++il)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) slab[(il * 16 + 4 * kq + r) * CLD + 16 * j + l15] = acc[4 * ps + il][j][r];
+        const int64_t m0 = mwave0 + ps * 64;
+        // 16 lanes per row (4 columns each), 4 rows per wave instruction
+        const int cr = lane >> 4, cc = (lane & 15) * 4;
+        const int n = nbase + cc;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) bv = *reinterpret_cast<const f32x4*>(g.bias + n);
+        float* cptr = g.C + (m0 + cr) * g.N + n;
+        const float* rptr = EPI == S3_EPI_RES ? g.R + (m0 + cr) * g.N + n : nullptr;
+#pragma unroll
+        for (int c0 = 0; c0 < 16; c0 += 8) {
+            f32x4 rv[8];
+            if constexpr (EPI == S3_EPI_RES) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    rv[u] = m0 + cr + (c0 + u) * 4 < g.M ? *reinterpret_cast<const f32x4*>(rptr + (int64_t)(c0 + u) * 4 * g.N) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int it = c0 + u;
+                f32x4 v = *reinterpret_cast<const f32x4*>(slab + (cr + it * 4) * CLD + cc);
+                v += bv;
+                if constexpr (EPI == S3_EPI_RES) v += rv[u];
+                if (m0 + cr + it * 4 < g.M) *reinterpret_cast<f32x4*>(cptr + (int64_t)it * 4 * g.N) = v;
+            }
+        }
+    }
+}
+
+// image epilogues from TRANSPOSED accumulator tiles (see s3_epilogue_img_t for the 32 x 32 version and for `big`)
+template <int EPI>
+__device__ __forceinline__ void s3_epilogue_img16(const S3Args& g, f32x4t (&acc)[8][4], int64_t mwave0, int nbase, int lane) {
+    const int l15 = lane & 15, kq = lane >> 4;
+    // range test over the valid rows (lane (l15, kq) of row tile i holds output row 16 i + l15 before the exchange)
+    bool big = EPI == S3_EPI_RES_IMG;
+    if constexpr (EPI != S3_EPI_RES_IMG) {
+        float amax = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a = fmaxf(a, fabsf(acc[i][j][r]));
+            if (mwave0 + 16 * i + l15 < g.M) amax = fmaxf(amax, a);
+        }
+        float bmax = 0.f;
+#pragma unroll
+        for (int e = 0; e < 64; e += 4) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(g.bias + nbase + e);
+            bmax = fmaxf(fmaxf(bmax, fmaxf(fabsf(b4[0]), fabsf(b4[1]))), fmaxf(fabsf(b4[2]), fabsf(b4[3])));
+        }
+        big = __any(!(amax < 1.2676506e30f) || !(bmax < 1.2676506e30f) || !(fabsf(g.qscale) < 1.0e6f));
+    }
+    // bias of this lane's chunk of every column tile: columns nbase + 16 j + 8 (kq >> 1) + (0..7)
+    float bv[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float* bp = g.bias + nbase + 16 * j + 8 * (kq >> 1);
+        *reinterpret_cast<f32x4*>(bv[j]) = *reinterpret_cast<const f32x4*>(bp);
+        *reinterpret_cast<f32x4*>(bv[j] + 4) = *reinterpret_cast<const f32x4*>(bp + 4);
+    }
+    [[maybe_unused]] float mul = 1.0f;
+    [[maybe_unused]] int64_t qbase = 0;
+    if constexpr (EPI == S3_EPI_QKV3) {
+        const int dmodel = g.heads * 64;
+        const int part = nbase / dmodel, head = (nbase % dmodel) >> 6;
+        mul = part == 0 ? g.qscale : 1.0f;
+        qbase = (((int64_t)part * (g.M / g.tokN)) * g.heads + head) * (int64_t)g.tokNpad * QKV3_ROWB;
+    }
+#pragma unroll
+    for (int ip = 0; ip < 4; ++ip) {         // pairs of row tiles (2 ip, 2 ip + 1): this lane ends up with a row of tile 2 ip + (kq & 1)
+        const int64_t m = mwave0 + 16 * (2 * ip + (kq & 1)) + l15;
+        float rinv = 1.0f;
+        if (EPI != S3_EPI_RES_IMG && g.ss_in != nullptr && m < g.M) {
+            const int nc = g.K >> 6;
+            const float* sp = g.ss_in + m * nc;
+            float ssum = 0.f;
+            if (nc == 8) {
+                const f32x4 p0 = *reinterpret_cast<const f32x4*>(sp), p1 = *reinterpret_cast<const f32x4*>(sp + 4);
+                const f32x4 t = p0 + p1;
+                ssum = (t[0] + t[1]) + (t[2] + t[3]);
+            } else {
+                for (int c = 0; c < nc; ++c) ssum += sp[c];
+            }
+            rinv = 1.0f / (sqrtf(ssum) / g.ss_sqrt_d + g.ss_eps);
+        }
+        [[maybe_unused]] unsigned char* qrow = nullptr;
+        [[maybe_unused]] int qsw = 0;
+        if constexpr (EPI == S3_EPI_QKV3) {
+            const unsigned b = (unsigned)m / (unsigned)g.tokN, tok = (unsigned)m - b * (unsigned)g.tokN;
+            qrow = g.C3 + qbase + ((int64_t)b * g.heads * g.tokNpad + tok) * QKV3_ROWB;
+            qsw = qkv3_swizzle(nbase / (g.heads * 64), (int)tok);
+        }
+        [[maybe_unused]] float ssq = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * ip][j][r]), __float_as_uint(acc[2 * ip + 1][j][r]), false, false);
+                v[r] = __uint_as_float(sw[0]);
+                v[4 + r] = __uint_as_float(sw[1]);
+            }
+            const int n = nbase + 16 * j + 8 * (kq >> 1);
+            if constexpr (EPI == S3_EPI_QKV3) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (v[e] * rinv + bv[j][e]) * mul;
+                if (S3_ROW_OK(m)) {
+                    const int c = 2 * j + (kq >> 1);
+                    unsigned char* dst = qrow + ((c ^ qsw) << 4);
+                    u32x4 Hh, Mi, Lo;
+                    if (big) split8<true>(v, Hh, Mi, Lo);
+                    else split8<false>(v, Hh, Mi, Lo);
+                    *reinterpret_cast<u32x4*>(dst) = Hh;
+                    *reinterpret_cast<u32x4*>(dst + 128) = Mi;
+                    *reinterpret_cast<u32x4*>(dst + 256) = Lo;
+                }
+            } else if constexpr (EPI == S3_EPI_RES_IMG) {
+                if (S3_ROW_OK(m)) {
+                    const float* rp = g.R + m * g.N + n;
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[j][e]) + (e < 4 ? r0[e] : r1[e - 4]);
+                    float* cp = g.C + m * g.N + n;
+                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    ssq += ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+                    store_split8<true>(g.C3, m, n, g.N, v);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = v[e] * rinv + bv[j][e];
+                    v[e] = EPI == S3_EPI_GELU_SPLIT ? gelu_erf(t) : t;
+                }
+                if (S3_ROW_OK(m)) {
+                    if (big) store_split8<true>(g.C3, m, n, g.N, v);
+                    else store_split8<false>(g.C3, m, n, g.N, v);
+                }
+            }
+        }
+        if constexpr (EPI == S3_EPI_RES_IMG) {
+            // lanes kq and kq ^ 2 hold the two 8-column halves of the same row's 16-column groups: one exchange, lanes kq < 2 write
+            const float tot = ssq + __shfl_xor(ssq, 32, 64);
+            if (kq < 2 && m < g.M) g.ss_out[m * (g.N >> 6) + (nbase >> 6)] = tot;
+        }
+    }
+}
+
+template <int EPI, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g) {
+    using Cf = S3Cfg<6, WAVES>;
+    constexpr int BM = Cf::BM, BN = Cf::BN, WM = 128, WN = 64;
+    constexpr int RCH = Cf::RCH, STAGE = Cf::STAGE, PPW = Cf::PPW, NST = Cf::NST;
+    constexpr bool TR = EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+
+    [[maybe_unused]] const unsigned long long t_entry = S3_T(), rt_entry = S3_RT();
+    int bm, bn;
+    {
+        int wg;
+        {
+            const int b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+            wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        }
+        const int per_row = g.sm * g.nbn, per_st = g.sm * g.sn;
+        const int srow = wg / per_row, rem = wg % per_row;
+        const int sc = rem / per_st, rem2 = rem % per_st;
+        bm = srow * g.sm + rem2 / g.sn;
+        bn = sc * g.sn + rem2 % g.sn;
+        if ((int64_t)bm * BM >= g.M) return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    constexpr int WAVES_N = BN / WN;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    if constexpr (WAVES == 4) {
+        if (g.stagger > 0) {
+            unsigned hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            if ((hwid & 1u) && (int)blockIdx.x < g.first_gen)
+                for (int i = 0; i < g.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    const int nk = g.K >> 4;
+    const int nrtA = (int)((g.M + 127) >> 7);
+
+    // fragment addressing (see the header of this section): per-lane base for even row tiles, odd tiles flip the k-half slot;
+    // the plane a lane reads depends on its k-group pair (kq >> 1) and on the fragment's pair type
+    // Only three lane-dependent address registers stay live: the lane's byte offset inside an even / an odd 16-row tile (odd tiles
+    // flip the k-half slot) and one plane stride; everything else is wave-uniform (scalar) or an immediate, and an address is one
+    // add of (lane base, plane part, uniform part) right before its read (hoisted per-type bases spilled into the loop).
+    const int hiq = kq >> 1;
+    const int base_e = l15 * 32 + ((kq & 1) << 4), base_o = l15 * 32 + (((kq & 1) ^ 1) << 4);
+    const int p1 = hiq * S3_PLANE;                                   // [h|m]: p1;  [h|l]: 2 p1;  [m|h]: PLANE - p1;  [l|h]: 2 PLANE - 2 p1
+    const int a_uni = wm * RCH, b_uni = (2 + (wn * WN) / 128) * RCH + ((wn * WN) & 127) * 32;
+    enum { T_HM = 0, T_HL = 1, T_MH = 2, T_LH = 3 };
+    auto plane_of = [&](int type) { return type == T_HM ? p1 : type == T_HL ? 2 * p1 : type == T_MH ? S3_PLANE - p1 : 2 * S3_PLANE - 2 * p1; };
+    auto lda = [&](bf16x8 (&dst)[8], const unsigned char* st, int type, int i0 = 0, int i1 = 8) {
+        const int pl = plane_of(type);
+#pragma unroll
+        for (int i = i0; i < i1; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(st + a_uni + ((i & 1) ? base_o : base_e) + pl + i * 512);
+    };
+    auto ldb = [&](bf16x8 (&dst)[4], const unsigned char* st, int type) {
+        const int pl = plane_of(type);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(st + b_uni + ((j & 1) ? base_o : base_e) + pl + j * 512);
+    };
+
+    constexpr int NRW = WAVES == 4 ? 3 : 1;
+    constexpr int PRW = PPW / NRW;
+    const unsigned char* rbase[NRW];
+    int rdst[NRW];
+#pragma unroll
+    for (int r = 0; r < NRW; ++r) {
+        const int region = WAVES == 4 ? r : wave >> 1;
+        const int within = (WAVES == 4 ? wave * PRW : (wave & 1) * PRW) * 1024;
+        rdst[r] = region * RCH + within;
+        if (region < 2) {
+            int rt = bm * 2 + region;
+            rt = rt < nrtA ? rt : nrtA - 1;
+            rbase[r] = g.A + (int64_t)rt * nk * S3_CHUNK + within;
+        } else {
+            rbase[r] = g.W + (int64_t)(bn * (BN / 128) + region - 2) * nk * S3_CHUNK + within;
+        }
+    }
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto issue_piece = [&](int i, int kt, int buf) {
+        const int r = i / PRW, k = (i % PRW) * 1024;
+        __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(rbase[r] + ((int64_t)kt * S3_CHUNK + k) + lane16),
+                                         AVD_LDS_PTR(smem3 + (buf * STAGE + rdst[r] + k)), 16, 0, 0);
+    };
+
+    f32x4t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4t{0.f, 0.f, 0.f, 0.f};
+    auto mm = [&](const bf16x8 (&A_)[8], const bf16x8 (&B_)[4], int i0, int i1) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = TR ? mma16x16(B_[j], A_[i], acc[i][j]) : mma16x16(A_[i], B_[j], acc[i][j]);
+    };
+
+    // prologue: tiles 0 .. NST-2 in flight; step kt issues tile kt + NST - 1 into the stage tile kt - 1 vacated
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nk) {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) issue_piece(i, t, t);
+        }
+    int st_cur = 0, st_fill = NST - 1;
+#define S3_SB() __builtin_amdgcn_sched_barrier(0)
+    constexpr int NSLOT = 12;                                   // a DMA slot behind every 8 MFMAs
+    constexpr int PER = NST == 2 ? 2 : (PPW + NSLOT - 1) / NSLOT;
+    static_assert(PER * NSLOT >= PPW, "every DMA piece has a slot");
+    auto step = [&](auto main_tag, int kt) {
+        constexpr bool MAIN = decltype(main_tag)::value;
+        // tile kt has landed (the NST - 2 tiles issued after it may stay in flight); every wave is past its reads of tile kt - 1
+        if constexpr (MAIN) wait_vm<(NST - 2) * PPW>();
+        else wait_vm_tiles<NST - 2, PPW>((kt + NST - 2 < nk - 1 ? kt + NST - 2 : nk - 1) - kt);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const unsigned char* st = smem3 + st_cur * STAGE;
+        const int dbuf = st_fill;
+        st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
+        st_fill = st_fill + 1 == NST ? 0 : st_fill + 1;
+        auto slot = [&](int s) {
+#ifdef AVD_LAB_NODMA
+            if constexpr (false) {
+#else
+            if constexpr (MAIN) {
+#endif
+#pragma unroll
+                for (int q = 0; q < PER; ++q)
+                    if (s * PER + q < PPW) { S3_SB(); issue_piece(s * PER + q, kt + NST - 1, dbuf); S3_SB(); }
+            }
+        };
+        bf16x8 ahl[8], ahm[8], bx[4], by[4];
+        S3_SB();
+        lda(ahl, st, T_HL);
+        ldb(bx, st, T_LH);                       // [l|h]
+        slot(0);                                  // the first DMA pieces are issued while those reads are in flight
+        lda(ahm, st, T_HM);
+        ldb(by, st, T_MH);                       // [m|h]
+        S3_SB();
+        mm(ahl, bx, 0, 2); slot(1); S3_SB();     // hl + lh
+        mm(ahl, bx, 2, 4); slot(2); S3_SB();
+        mm(ahl, bx, 4, 6); slot(3); S3_SB();
+        mm(ahl, bx, 6, 8); slot(4); ldb(bx, st, T_HM); S3_SB();       // [h|m] into the dead [l|h] registers
+        mm(ahm, by, 0, 2); slot(5); S3_SB();     // hm + mh
+        mm(ahm, by, 2, 4); slot(6); S3_SB();
+        mm(ahm, by, 4, 6); slot(7); S3_SB();
+        mm(ahm, by, 6, 8); slot(8); S3_SB();
+        mm(ahm, bx, 0, 2); slot(9); S3_SB();     // hh + mm
+        mm(ahm, bx, 2, 4); slot(10); S3_SB();
+        mm(ahm, bx, 4, 6); slot(11); S3_SB();
+        mm(ahm, bx, 6, 8); S3_SB();
+    };
+    // 8 waves (ring of three stages, both waves of a SIMD in one block and in lockstep behind the barrier): the fragments of the
+    // step's FIRST MFMA group are read a step ahead — [h|l] of A and [l|h] of W of tile kt+1 during the last groups of step kt — so
+    // the matrix pipe has work the moment the barrier opens.  That needs tile kt+1 landed at the top of step kt: the DMA of a tile is
+    // front-loaded (two pieces per slot, behind the first 24 MFMAs) and awaited a step later.  The W fragment registers change roles
+    // from step to step (bp: [l|h] then [h|m];  bq: [m|h] then the next step's [l|h]), so the loop is unrolled twice.
+    bf16x8 ahl8[8], bset0[4], bset1[4];
+    auto step8 = [&](int kt, bf16x8 (&bp)[4], bf16x8 (&bq)[4]) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const unsigned char* st = smem3 + st_cur * STAGE;
+        const int dbuf = st_fill;
+        st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
+        st_fill = st_fill + 1 == NST ? 0 : st_fill + 1;
+        const unsigned char* stn = smem3 + st_cur * STAGE;           // stage of tile kt + 1
+        const bool more = kt + NST - 1 < nk;
+        auto slot2 = [&](int s) {                                      // pieces 2 s, 2 s + 1 of tile kt + 2
+#ifndef AVD_LAB_NODMA
+            if (more) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    if (2 * s + q < PPW) { S3_SB(); issue_piece(2 * s + q, kt + NST - 1, dbuf); S3_SB(); }
+            }
+#endif
+        };
+        // A fragments share one pool of registers: [h|m] of tile kt is read pair by pair as the [h|l] pairs die in the first group,
+        // the next step's [h|l] pair by pair as the [h|m] pairs die in the last — reads spread between the MFMAs, ~200 live VGPRs
+        bf16x8 ahm[8];
+        S3_SB();
+        mm(ahl8, bp, 0, 2); slot2(0); ldb(bq, st, T_MH); lda(ahm, st, T_HM, 0, 2); S3_SB();      // hl + lh, on fragments read a step ago
+        mm(ahl8, bp, 2, 4); slot2(1); lda(ahm, st, T_HM, 2, 4); S3_SB();
+        mm(ahl8, bp, 4, 6); slot2(2); lda(ahm, st, T_HM, 4, 6); S3_SB();
+        mm(ahl8, bp, 6, 8); lda(ahm, st, T_HM, 6, 8); ldb(bp, st, T_HM); S3_SB();                 // [h|m] of W into the dead [l|h] registers
+        mm(ahm, bq, 0, 2); S3_SB();              // hm + mh
+        mm(ahm, bq, 2, 4); S3_SB();
+        mm(ahm, bq, 4, 6); S3_SB();
+        mm(ahm, bq, 6, 8); ldb(bq, stn, T_LH); S3_SB();                                         // the next step's [l|h] of W
+        mm(ahm, bp, 0, 2); lda(ahl8, stn, T_HL, 0, 2); S3_SB();                                   // hh + mm
+        mm(ahm, bp, 2, 4); lda(ahl8, stn, T_HL, 2, 4); S3_SB();
+        mm(ahm, bp, 4, 6); lda(ahl8, stn, T_HL, 4, 6); S3_SB();
+        mm(ahm, bp, 6, 8); lda(ahl8, stn, T_HL, 6, 8); S3_SB();
+    };
+    using MainT = std::integral_constant<bool, true>;
+    using TailT = std::integral_constant<bool, false>;
+    [[maybe_unused]] const unsigned long long t_loop = S3_T();
+    if constexpr (WAVES == 8) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // tiles 0 and 1 landed
+        lda(ahl8, smem3, T_HL);
+        ldb(bset0, smem3, T_LH);
+        int kt = 0;
+        for (; kt + 1 < nk; kt += 2) {
+            step8(kt, bset0, bset1);
+            step8(kt + 1, bset1, bset0);
+        }
+        if (kt < nk) step8(kt, bset0, bset1);
+    } else {
+        const int n_main = nk - NST + 1 > 0 ? nk - NST + 1 : 0;       // steps that still have a tile to issue
+        int kt = 0;
+        for (; kt < n_main; ++kt) step(MainT{}, kt);
+        for (; kt < nk; ++kt) step(TailT{}, kt);
+    }
+#undef S3_SB
+    [[maybe_unused]] const unsigned long long t_end = S3_T();
+    // the epilogue's lane-dependent addresses are derived from this copy: opaque to the compiler, so none of them is hoisted above the
+    // K loop (where they cost registers the loop needs; hoisted, they spilled into it)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    if constexpr (TR) {
+        s3_epilogue_img16<EPI>(g, acc, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane_e);
+    } else {
+        __syncthreads();
+        constexpr int CLD = WN + 4;
+        float* slab = reinterpret_cast<float*>(smem3) + wave * 64 * CLD;
+        s3_epilogue16<EPI>(g, acc, slab, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane_e);
+    }
+#ifdef AVD_S3_STAMPS
+    const unsigned long long t_issued = S3_T();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    S3_DBG(4, t_issued);
+    S3_DBG(0, t_entry); S3_DBG(1, t_loop); S3_DBG(2, t_end); S3_DBG(3, S3_T());
+    S3_DBG(8, (unsigned long long)nk); S3_DBG(9, S3_RT()); S3_DBG(10, rt_entry);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
 int64_t split3_bytes(int64_t rows, int K) { return ((rows + 255) / 256 * 256) * (int64_t)K * 6; }
@@ -904,8 +1322,44 @@ static int launch_s3w(S3Args g, hipStream_t st) {
     return AVD_OK;
 }
 
+// bf16x3 (six terms) on the 16x16x32 MFMA with two terms per instruction; avd_tune_set "s3_m16" 0 takes the 32x32x16 kernel instead
+int g_s3_m16 = getenv("AVD_S3_M16") ? atoi(getenv("AVD_S3_M16")) : 1;
+template <int EPI, int WAVES>
+static int launch_s3w16(S3Args g, hipStream_t st) {
+    using Cf = S3Cfg<6, WAVES>;
+    constexpr bool tile = WAVES == 4;
+    static LdsAttr attr;
+    auto kern = gemm_bf16x3_m16_kernel<EPI, WAVES>;
+    if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), Cf::LDS, "gemm_bf16x3 (16x16x32)")) return rc;
+#ifdef AVD_S3_STAMPS
+    g.dbg = g_s3_dbg;
+#endif
+    g.nbn = g.N / Cf::BN;
+    int sn = 8;
+    while (g.nbn % sn) sn >>= 1;
+    if (tile && g.nbn <= 16) sn = g.nbn;
+    const int total = tile ? 32 : 16;
+    g.sn = sn;
+    g.sm = total / sn > 0 ? total / sn : 1;
+    const int64_t nbm = (g.M + Cf::BM - 1) / Cf::BM;
+    const int64_t nwg = (nbm + g.sm - 1) / g.sm * g.sm * g.nbn;
+    AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
+    g.stagger = 0;
+    g.first_gen = 2 * s3_cu_count();
+    if (tile && g.first_gen > 0 && nbm * g.nbn >= 2 * g.first_gen)
+        g.stagger = g_s3_stagger >= 0 ? g_s3_stagger : t_s3_two_streams ? 0 : 48 * (g.K >= 1024 ? 2 : 1);
+    static const int tag = prof_tag_id("gemm_bf16x3_m16_kernel<%d, %d>", EPI, WAVES);
+    ProfScope prof(tag, 2.0 * (double)g.M * g.N * g.K, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WAVES * 64), Cf::LDS, st, g);
+    AVD_CHECK_LAUNCH("gemm_bf16x3 (16x16x32)");
+    return AVD_OK;
+}
+
 template <int EPI, int TERMS>
 static int launch_s3t(const S3Args& a, hipStream_t st) {
+    if constexpr (TERMS == 6) {
+        if (g_s3_m16) return s3_tile_for(EPI, a.M, a.N) ? launch_s3w16<EPI, 4>(a, st) : launch_s3w16<EPI, 8>(a, st);
+    }
     return s3_tile_for(EPI, a.M, a.N) ? launch_s3w<EPI, TERMS, 4>(a, st) : launch_s3w<EPI, TERMS, 8>(a, st);
 }
 

@@ -18,7 +18,7 @@ def _h2_decode(img: np.ndarray, rows: int, K: int) -> np.ndarray:
     """Independent reading of the f16x2 image (split3 geometry, planes 0 and 1 hold fp16): -> [2, rows, K] float64."""
     r = np.arange(rows)[:, None]
     k = np.arange(K)[None, :]
-    f = ((r & 127) >> 3) & 1
+    f = ((r & 127) >> 4) & 1
     half = (k >> 3) & 1
     base = ((r >> 7) * (K // 16) + (k >> 4)) * (128 * 96) + (r & 127) * 32 + ((half ^ f) * 16) + (k & 7) * 2
     f16 = img.view(np.float16)

@@ -618,7 +618,7 @@ def _split3_decode(img: np.ndarray, rows: int, K: int) -> np.ndarray:
     """Independent reading of the split3 image layout (include/avdiff_hip.h, csrc/gemm_bf16x3.hip): -> planes [3, rows, K]."""
     r = np.arange(rows)[:, None]
     k = np.arange(K)[None, :]
-    f = ((r & 127) >> 3) & 1
+    f = ((r & 127) >> 4) & 1
     half = (k >> 3) & 1
     base = ((r >> 7) * (K // 16) + (k >> 4)) * (128 * 96) + (r & 127) * 32 + ((half ^ f) * 16) + (k & 7) * 2
     u16 = img.view(np.uint16)
