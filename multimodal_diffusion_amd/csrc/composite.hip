@@ -523,6 +523,7 @@ extern "C" int avd_tune_set(const char* key, int64_t value) {
     AVD_REQUIRE(key, AVD_EINVAL, "tune_set: null key");
     if (!strcmp(key, "s3_tile")) { g_s3_tile = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_m16")) { g_s3_m16 = (int)value; return AVD_OK; }
+    if (!strcmp(key, "s3_rt")) { g_s3_rt = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_stagger")) { g_s3_stagger = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_tile")) { g_gemm_force_tile = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_stages")) { g_gemm_stages = (int)value; return AVD_OK; }

@@ -807,7 +807,8 @@ __device__ __forceinline__ void s3_epilogue16(const S3Args& g, f32x4t (&acc)[8][
 }
 
 // image epilogues from TRANSPOSED accumulator tiles (see s3_epilogue_img_t for the 32 x 32 version and for `big`)
-template <int EPI>
+// RT = row tiles of the wave that are live (8, or 7 in the 224-row blocks: tile 7 is all zeros and its rows belong to the next wave)
+template <int EPI, int RT = 8>
 __device__ __forceinline__ void s3_epilogue_img16(const S3Args& g, f32x4t (&acc)[8][4], int64_t mwave0, int nbase, int lane) {
     const int l15 = lane & 15, kq = lane >> 4;
     // range test over the valid rows (lane (l15, kq) of row tile i holds output row 16 i + l15 before the exchange)
@@ -849,7 +850,8 @@ __device__ __forceinline__ void s3_epilogue_img16(const S3Args& g, f32x4t (&acc)
     }
 #pragma unroll
     for (int ip = 0; ip < 4; ++ip) {         // pairs of row tiles (2 ip, 2 ip + 1): this lane ends up with a row of tile 2 ip + (kq & 1)
-        const int64_t m = mwave0 + 16 * (2 * ip + (kq & 1)) + l15;
+        const int tile = 2 * ip + (kq & 1);
+        const int64_t m = (RT == 8 || tile < RT) ? mwave0 + 16 * tile + l15 : g.M;      // a dead tile's rows fail every m < M test below
         float rinv = 1.0f;
         if (EPI != S3_EPI_RES_IMG && g.ss_in != nullptr && m < g.M) {
             const int nc = g.K >> 6;
@@ -927,12 +929,19 @@ __device__ __forceinline__ void s3_epilogue_img16(const S3Args& g, f32x4t (&acc)
     }
 }
 
-template <int EPI, int WAVES>
+// RT (8-wave blocks with an image epilogue only): row tiles per wave.  8 = 256-row blocks; 7 = 224-row blocks, chosen by the host when
+// it puts every block into ONE generation on the device's CUs (C3: 26,944 rows x 512 columns = 212 blocks of 256 x 256 on 256 CUs, 83 %
+// of the chip for the whole launch; 242 blocks of 224 x 256 use 95 % of it and each is 7/8 of the work).
+template <int EPI, int WAVES, int RT = 8>
 __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g) {
     using Cf = S3Cfg<6, WAVES>;
-    constexpr int BM = Cf::BM, BN = Cf::BN, WM = 128, WN = 64;
+    constexpr int BM = WAVES == 8 ? 32 * RT : Cf::BM, BN = Cf::BN, WM = 16 * RT, WN = 64;
     constexpr int RCH = Cf::RCH, STAGE = Cf::STAGE, PPW = Cf::PPW, NST = Cf::NST;
     constexpr bool TR = EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG;
+    static_assert(RT == 8 || (RT == 7 && WAVES == 8 && TR), "224-row blocks: 8 waves, register image epilogue");
+    // LDS stage.  4 waves: [region A0 A1 W0][plane][128 rows][32 B] as in the 32x32 kernel.  8 waves: [A | W][plane][256 rows][32 B] —
+    // plane-major over the block's 256 staged rows, so a wave's row tiles are 512 bytes apart wherever its first row falls
+    constexpr int PS = WAVES == 8 ? 256 * 32 : S3_PLANE;              // plane stride in the stage
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
     [[maybe_unused]] const unsigned long long t_entry = S3_T(), rt_entry = S3_RT();
@@ -973,14 +982,19 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
     // add of (lane base, plane part, uniform part) right before its read (hoisted per-type bases spilled into the loop).
     const int hiq = kq >> 1;
     const int base_e = l15 * 32 + ((kq & 1) << 4), base_o = l15 * 32 + (((kq & 1) ^ 1) << 4);
-    const int p1 = hiq * S3_PLANE;                                   // [h|m]: p1;  [h|l]: 2 p1;  [m|h]: PLANE - p1;  [l|h]: 2 PLANE - 2 p1
-    const int a_uni = wm * RCH, b_uni = (2 + (wn * WN) / 128) * RCH + ((wn * WN) & 127) * 32;
+    // the wave's first row tile is odd in the block when RT is odd and wm = 1: its even / odd bases trade places
+    const bool flip_a = ((wm * RT) & 1) != 0;
+    const int abase_e = flip_a ? base_o : base_e, abase_o = flip_a ? base_e : base_o;
+    const int p1 = hiq * PS;                                         // [h|m]: p1;  [h|l]: 2 p1;  [m|h]: PS - p1;  [l|h]: 2 PS - 2 p1
+    const int a_uni = WAVES == 8 ? wm * (RT * 512) : wm * RCH;
+    const int b_uni = WAVES == 8 ? 3 * PS + wn * WN * 32 : (2 + (wn * WN) / 128) * RCH + ((wn * WN) & 127) * 32;
     enum { T_HM = 0, T_HL = 1, T_MH = 2, T_LH = 3 };
-    auto plane_of = [&](int type) { return type == T_HM ? p1 : type == T_HL ? 2 * p1 : type == T_MH ? S3_PLANE - p1 : 2 * S3_PLANE - 2 * p1; };
+    auto plane_of = [&](int type) { return type == T_HM ? p1 : type == T_HL ? 2 * p1 : type == T_MH ? PS - p1 : 2 * PS - 2 * p1; };
     auto lda = [&](bf16x8 (&dst)[8], const unsigned char* st, int type, int i0 = 0, int i1 = 8) {
         const int pl = plane_of(type);
 #pragma unroll
-        for (int i = i0; i < i1; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(st + a_uni + ((i & 1) ? base_o : base_e) + pl + i * 512);
+        for (int i = i0; i < i1; ++i)
+            if (i < RT) dst[i] = *reinterpret_cast<const bf16x8*>(st + a_uni + ((i & 1) ? abase_o : abase_e) + pl + i * 512);
     };
     auto ldb = [&](bf16x8 (&dst)[4], const unsigned char* st, int type) {
         const int pl = plane_of(type);
@@ -988,21 +1002,37 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
         for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(st + b_uni + ((j & 1) ? base_o : base_e) + pl + j * 512);
     };
 
-    constexpr int NRW = WAVES == 4 ? 3 : 1;
+    // DMA pieces (1 KiB = one plane of 32 rows of one 16-k group), all wave-uniform.  4 waves: PRW consecutive pieces of each of the
+    // three regions.  8 waves: piece P = 6 wave + i of 48 — P < 24: plane P / 8, rows 32 (P % 8) .. +31 of the block's A rows, which
+    // start at ANY multiple of 32 (the image keeps 128-row groups: group and 32-row quarter are taken from the global row; rows past
+    // the last group re-read it — their results are never stored); P >= 24: the same over the block's 256 W rows.
+    constexpr int NRW = WAVES == 4 ? 3 : PPW;
     constexpr int PRW = PPW / NRW;
     const unsigned char* rbase[NRW];
     int rdst[NRW];
 #pragma unroll
     for (int r = 0; r < NRW; ++r) {
-        const int region = WAVES == 4 ? r : wave >> 1;
-        const int within = (WAVES == 4 ? wave * PRW : (wave & 1) * PRW) * 1024;
-        rdst[r] = region * RCH + within;
-        if (region < 2) {
-            int rt = bm * 2 + region;
-            rt = rt < nrtA ? rt : nrtA - 1;
-            rbase[r] = g.A + (int64_t)rt * nk * S3_CHUNK + within;
+        if constexpr (WAVES == 4) {
+            const int within = wave * PRW * 1024;
+            rdst[r] = r * RCH + within;
+            if (r < 2) {
+                int rt = bm * 2 + r;
+                rt = rt < nrtA ? rt : nrtA - 1;
+                rbase[r] = g.A + (int64_t)rt * nk * S3_CHUNK + within;
+            } else {
+                rbase[r] = g.W + (int64_t)bn * nk * S3_CHUNK + within;
+            }
         } else {
-            rbase[r] = g.W + (int64_t)(bn * (BN / 128) + region - 2) * nk * S3_CHUNK + within;
+            const int P = wave * PPW + r, isw = P >= 24, pq = isw ? P - 24 : P, pl = pq >> 3, q = pq & 7;
+            rdst[r] = (isw ? 3 * PS : 0) + pl * PS + q * 1024;
+            if (!isw) {
+                const int64_t grow = (int64_t)bm * BM + 32 * q;
+                int64_t grp = grow >> 7;
+                grp = grp < nrtA ? grp : nrtA - 1;
+                rbase[r] = g.A + grp * nk * S3_CHUNK + pl * S3_PLANE + (int)((grow >> 5) & 3) * 1024;
+            } else {
+                rbase[r] = g.W + (int64_t)(bn * 2 + (q >> 2)) * nk * S3_CHUNK + pl * S3_PLANE + (q & 3) * 1024;
+            }
         }
     }
     const unsigned lane16 = (unsigned)lane * 16u;
@@ -1020,8 +1050,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
     auto mm = [&](const bf16x8 (&A_)[8], const bf16x8 (&B_)[4], int i0, int i1) {
 #pragma unroll
         for (int i = i0; i < i1; ++i)
+            if (i < RT) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = TR ? mma16x16(B_[j], A_[i], acc[i][j]) : mma16x16(A_[i], B_[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = TR ? mma16x16(B_[j], A_[i], acc[i][j]) : mma16x16(A_[i], B_[j], acc[i][j]);
+            }
     };
 
     // prologue: tiles 0 .. NST-2 in flight; step kt issues tile kt + NST - 1 into the stage tile kt - 1 vacated
@@ -1078,60 +1110,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
         mm(ahm, bx, 4, 6); slot(11); S3_SB();
         mm(ahm, bx, 6, 8); S3_SB();
     };
-    // 8 waves (ring of three stages, both waves of a SIMD in one block and in lockstep behind the barrier): the fragments of the
-    // step's FIRST MFMA group are read a step ahead — [h|l] of A and [l|h] of W of tile kt+1 during the last groups of step kt — so
-    // the matrix pipe has work the moment the barrier opens.  That needs tile kt+1 landed at the top of step kt: the DMA of a tile is
-    // front-loaded (two pieces per slot, behind the first 24 MFMAs) and awaited a step later.  The W fragment registers change roles
-    // from step to step (bp: [l|h] then [h|m];  bq: [m|h] then the next step's [l|h]), so the loop is unrolled twice.
-    bf16x8 ahl8[8], bset0[4], bset1[4];
-    auto step8 = [&](int kt, bf16x8 (&bp)[4], bf16x8 (&bq)[4]) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        const unsigned char* st = smem3 + st_cur * STAGE;
-        const int dbuf = st_fill;
-        st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
-        st_fill = st_fill + 1 == NST ? 0 : st_fill + 1;
-        const unsigned char* stn = smem3 + st_cur * STAGE;           // stage of tile kt + 1
-        const bool more = kt + NST - 1 < nk;
-        auto slot2 = [&](int s) {                                      // pieces 2 s, 2 s + 1 of tile kt + 2
-#ifndef AVD_LAB_NODMA
-            if (more) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-                    if (2 * s + q < PPW) { S3_SB(); issue_piece(2 * s + q, kt + NST - 1, dbuf); S3_SB(); }
-            }
-#endif
-        };
-        // A fragments share one pool of registers: [h|m] of tile kt is read pair by pair as the [h|l] pairs die in the first group,
-        // the next step's [h|l] pair by pair as the [h|m] pairs die in the last — reads spread between the MFMAs, ~200 live VGPRs
-        bf16x8 ahm[8];
-        S3_SB();
-        mm(ahl8, bp, 0, 2); slot2(0); ldb(bq, st, T_MH); lda(ahm, st, T_HM, 0, 2); S3_SB();      // hl + lh, on fragments read a step ago
-        mm(ahl8, bp, 2, 4); slot2(1); lda(ahm, st, T_HM, 2, 4); S3_SB();
-        mm(ahl8, bp, 4, 6); slot2(2); lda(ahm, st, T_HM, 4, 6); S3_SB();
-        mm(ahl8, bp, 6, 8); lda(ahm, st, T_HM, 6, 8); ldb(bp, st, T_HM); S3_SB();                 // [h|m] of W into the dead [l|h] registers
-        mm(ahm, bq, 0, 2); S3_SB();              // hm + mh
-        mm(ahm, bq, 2, 4); S3_SB();
-        mm(ahm, bq, 4, 6); S3_SB();
-        mm(ahm, bq, 6, 8); ldb(bq, stn, T_LH); S3_SB();                                         // the next step's [l|h] of W
-        mm(ahm, bp, 0, 2); lda(ahl8, stn, T_HL, 0, 2); S3_SB();                                   // hh + mm
-        mm(ahm, bp, 2, 4); lda(ahl8, stn, T_HL, 2, 4); S3_SB();
-        mm(ahm, bp, 4, 6); lda(ahl8, stn, T_HL, 4, 6); S3_SB();
-        mm(ahm, bp, 6, 8); lda(ahl8, stn, T_HL, 6, 8); S3_SB();
-    };
     using MainT = std::integral_constant<bool, true>;
     using TailT = std::integral_constant<bool, false>;
     [[maybe_unused]] const unsigned long long t_loop = S3_T();
-    if constexpr (WAVES == 8) {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // tiles 0 and 1 landed
-        lda(ahl8, smem3, T_HL);
-        ldb(bset0, smem3, T_LH);
-        int kt = 0;
-        for (; kt + 1 < nk; kt += 2) {
-            step8(kt, bset0, bset1);
-            step8(kt + 1, bset1, bset0);
-        }
-        if (kt < nk) step8(kt, bset0, bset1);
-    } else {
+    {
+        // (A variant that read the first group's fragments a step ahead and front-loaded the DMA was built for the 8-wave blocks: it
+        // needs ~30 more live registers, spilled lane addresses into the loop — every reload waits on the DMA queue — and measured
+        // 212 us against this loop's 195 us on the fc2 shape.  DESIGN.md, negative results.)
         const int n_main = nk - NST + 1 > 0 ? nk - NST + 1 : 0;       // steps that still have a tile to issue
         int kt = 0;
         for (; kt < n_main; ++kt) step(MainT{}, kt);
@@ -1144,7 +1129,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
     int lane_e = lane;
     asm volatile("" : "+v"(lane_e));
     if constexpr (TR) {
-        s3_epilogue_img16<EPI>(g, acc, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane_e);
+        s3_epilogue_img16<EPI, RT>(g, acc, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane_e);
     } else {
         __syncthreads();
         constexpr int CLD = WN + 4;
@@ -1324,12 +1309,16 @@ static int launch_s3w(S3Args g, hipStream_t st) {
 
 // bf16x3 (six terms) on the 16x16x32 MFMA with two terms per instruction; avd_tune_set "s3_m16" 0 takes the 32x32x16 kernel instead
 int g_s3_m16 = getenv("AVD_S3_M16") ? atoi(getenv("AVD_S3_M16")) : 1;
-template <int EPI, int WAVES>
+// rows per 8-wave block of the residual + image epilogue: 0 = automatic (224 when that saves a generation of blocks), 7 / 8 forced
+// (avd_tune_set "s3_rt", AVD_S3_RT)
+int g_s3_rt = getenv("AVD_S3_RT") ? atoi(getenv("AVD_S3_RT")) : 0;
+template <int EPI, int WAVES, int RT = 8>
 static int launch_s3w16(S3Args g, hipStream_t st) {
     using Cf = S3Cfg<6, WAVES>;
     constexpr bool tile = WAVES == 4;
+    constexpr int BM = WAVES == 8 ? 32 * RT : Cf::BM;
     static LdsAttr attr;
-    auto kern = gemm_bf16x3_m16_kernel<EPI, WAVES>;
+    auto kern = gemm_bf16x3_m16_kernel<EPI, WAVES, RT>;
     if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), Cf::LDS, "gemm_bf16x3 (16x16x32)")) return rc;
 #ifdef AVD_S3_STAMPS
     g.dbg = g_s3_dbg;
@@ -1341,14 +1330,14 @@ static int launch_s3w16(S3Args g, hipStream_t st) {
     const int total = tile ? 32 : 16;
     g.sn = sn;
     g.sm = total / sn > 0 ? total / sn : 1;
-    const int64_t nbm = (g.M + Cf::BM - 1) / Cf::BM;
+    const int64_t nbm = (g.M + BM - 1) / BM;
     const int64_t nwg = (nbm + g.sm - 1) / g.sm * g.sm * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
     g.stagger = 0;
     g.first_gen = 2 * s3_cu_count();
     if (tile && g.first_gen > 0 && nbm * g.nbn >= 2 * g.first_gen)
         g.stagger = g_s3_stagger >= 0 ? g_s3_stagger : t_s3_two_streams ? 0 : 48 * (g.K >= 1024 ? 2 : 1);
-    static const int tag = prof_tag_id("gemm_bf16x3_m16_kernel<%d, %d>", EPI, WAVES);
+    static const int tag = RT == 8 ? prof_tag_id("gemm_bf16x3_m16_kernel<%d, %d, 8>", EPI, WAVES) : prof_tag_id("gemm_bf16x3_m16_kernel<%d, %d, %d>", EPI, WAVES, RT);
     ProfScope prof(tag, 2.0 * (double)g.M * g.N * g.K, st);
     hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WAVES * 64), Cf::LDS, st, g);
     AVD_CHECK_LAUNCH("gemm_bf16x3 (16x16x32)");
@@ -1358,7 +1347,16 @@ static int launch_s3w16(S3Args g, hipStream_t st) {
 template <int EPI, int TERMS>
 static int launch_s3t(const S3Args& a, hipStream_t st) {
     if constexpr (TERMS == 6) {
-        if (g_s3_m16) return s3_tile_for(EPI, a.M, a.N) ? launch_s3w16<EPI, 4>(a, st) : launch_s3w16<EPI, 8>(a, st);
+        if (g_s3_m16) {
+            if (s3_tile_for(EPI, a.M, a.N)) return launch_s3w16<EPI, 4>(a, st);
+            if constexpr (EPI == S3_EPI_RES_IMG) {
+                // 224-row blocks when they need fewer generations of blocks x rows than 256-row blocks (one block per CU)
+                const int64_t cu = s3_cu_count() > 0 ? s3_cu_count() : 256, nbn = a.N / 256;
+                const int64_t g8 = ((a.M + 255) / 256 * nbn + cu - 1) / cu * 8, g7 = ((a.M + 223) / 224 * nbn + cu - 1) / cu * 7;
+                if (g_s3_rt == 7 || (g_s3_rt != 8 && g7 < g8)) return launch_s3w16<EPI, 8, 7>(a, st);
+            }
+            return launch_s3w16<EPI, 8>(a, st);
+        }
     }
     return s3_tile_for(EPI, a.M, a.N) ? launch_s3w<EPI, TERMS, 4>(a, st) : launch_s3w<EPI, TERMS, 8>(a, st);
 }

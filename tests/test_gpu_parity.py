@@ -1312,6 +1312,42 @@ def test_attention_key_padding_mask(dev):
                        Fn.attention(qkv.to(dev), H))
 
 
+@pytest.mark.parametrize("B", [32, 5])
+def test_split_gemm_block_rows_agree(dev, full, B):
+    """bf16x3 out_proj / fc2 (residual + image + row sums epilogue, 8 waves): the 224-row blocks the host picks when they fit one
+    generation of blocks on the CUs (avd_tune_set "s3_rt" 0 / 7 / 8) read the operand images at row offsets that are multiples of
+    32, not of 128, and leave the last row tile of each wave pair dead — same MFMA sequence per output element, so a whole CFG step is
+    bit-identical with 256-row blocks.  B = 32: the bench shape (26,944 rows, last block past the last 128-row group);
+    B = 5: 4,210 rows with the 8-wave blocks forced (18.8 blocks of 224 rows)."""
+    import multimodal_diffusion_amd as A
+    ws, mods = full
+    core, head, av, aa = mods
+    g = torch.Generator().manual_seed(77 + B)
+    z_v = torch.randn(B, 8, 12, 32, 32, generator=g)
+    z_a = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn = torch.tensor(([982, 500, 16, 999] * B)[:B])
+    tp = torch.tensor(([966, 480, -1, 979] * B)[:B])
+    outs = {}
+    for rt in (7, 8, 0):
+        _tune("s3_rt", rt)
+        _tune("s3_tile", 0 if B < 32 else -1)
+        try:
+            eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z_v.shape),
+                                  prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul="bf16x3")
+            eng.set_prompt(z_a.to(dev))
+            outs[rt] = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)).cpu()
+        finally:
+            _tune("s3_rt", 0)
+            _tune("s3_tile", -1)
+    assert torch.isfinite(outs[7]).all()
+    assert torch.equal(outs[7], outs[8])
+    assert torch.equal(outs[0], outs[8])
+    ref = R.denoise_step_a2v(z_v[:1], z_a[:1], tn[:1], tp[:1], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"], core=ws["core"],
+                             head=ws["head"], n_layers=8, n_heads=8, guidance=3.5)
+    assert rel_err(outs[7][:1], ref) < TOL
+
+
 def test_split_gemm_tile_configurations_agree(dev):
     """The two block configurations of the split-operand GEMM (8 waves 256x256 / 4 waves 256x128, avd_tune_set "s3_tile") sum
     every output element over k in the same order with the same product terms: bit-identical results, in every mode, for the
