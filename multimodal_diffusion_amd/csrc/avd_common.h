@@ -285,6 +285,8 @@ int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, i
                 float img_scale = 1.f, float out_scale = 1.f);
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
                 int act, int terms, hipStream_t st, float ab_scale = 1.f, float c_scale = 1.f, const float* ss_in = nullptr, float eps = 0.f,
-                float* ss_out = nullptr);
+                float* ss_out = nullptr, const float* gamma = nullptr);
+// gamma != null (f16x2 images, N == 512): C = A W^T + bias + R as fp32 AND C3 = image (scale c_scale) of RMSNorm(C; gamma, eps)
+bool gemm_bf16x3_rownorm_supported(int N, int terms);
 
 }  // namespace avd

@@ -124,6 +124,11 @@ static bool core_use_split_fold(const avd_core_weights* w) {
     return true;
 }
 
+// f16x2 path with the norms that follow a residual add finished inside that GEMM's epilogue (blocks that own whole rows)
+static bool core_use_split_rownorm(const avd_core_weights* w) {
+    return !g_no_fold && w->norm_kind == 0 && w->split_terms == 3 && gemm_bf16x3_rownorm_supported(w->d, 3);
+}
+
 // fp32 path with RMSNorm folded into the neighbouring GEMM epilogues: needs the scale-carrying weights and LDS-DMA-able shapes
 static bool core_use_fold(const avd_core_weights* w) {
     if (g_no_fold || w->norm_kind != 0) return false;              // avd_tune_set "no_fold": measurement aid
@@ -151,7 +156,8 @@ static int64_t core_ws_bytes(const avd_core_weights* w, int B, int N) {
     // third region: (attn_mode 1) the fp8 attention's operand images
     const int64_t f8_b = w->attn_mode == 1 ? attn_fp8_ws_bytes(B, N, w->n_heads) : 0;
     // folded norms: a second [M][d] image (the residual stream's) and the table of its rows' sums of squares
-    const int64_t fold_b = core_use_split_fold(w) ? align_up(split3_bytes(M, w->d)) + align_up(M * (w->d / 64) * 4) : 0;
+    const int64_t fold_b = core_use_split_fold(w) ? align_up(split3_bytes(M, w->d)) + align_up(M * (w->d / 64) * 4)
+                         : core_use_split_rownorm(w) ? align_up(split3_bytes(M, w->d)) : 0;        // the normalised stream's image
     const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d)) + align_up(f8_b) + fold_b;
     return split_path > fp32_path ? split_path : fp32_path;
 }
@@ -247,6 +253,10 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
             }
             return rmsnorm_f32(y, rd, w->final_norm_scale, y, rd, M, d, w->norm_eps, st);
         }
+        // f16x2 with d = 512: out_proj / fc2 own whole rows and write the NEXT norm's output image themselves (EPI_RES_NORM); the only
+        // norm kernel left before the final norm is the first block's norm1
+        const bool rown = core_use_split_rownorm(w);
+        void* hn = rown ? cs.take((split3_bytes(M, d) + 3) / 4) : hs;      // image of the normalised stream (hs: attention output)
         for (int l = 0; l < w->n_layers; ++l) {
             const avd_block_weights& b = w->blocks[l];
             const bool last = l == w->n_layers - 1;
@@ -256,22 +266,37 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
             const float* fs = b.f16x2_scale;
             const float s_n1 = h2 ? fs[4] : 0.f, s_qkv = h2 ? fs[5] : 1.f, s_n2 = h2 ? fs[6] : 0.f, s_fc1 = h2 ? fs[7] : 1.f;
             const float w_in = h2 ? fs[0] : 1.f, w_out = h2 ? fs[1] : 1.f, w_fc1 = h2 ? fs[2] : 1.f, w_fc2 = h2 ? fs[3] : 1.f;
-            if (int rc = rmsnorm_split3_f32(cur, b.norm1_scale, hs, M, d, w->norm_eps, st, s_n1)) return rc;
-            if (int rc = gemm_bf16x3_qkv3(hs, b.in_proj_weight3, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, terms, st,
+            if (!rown || l == 0)
+                if (int rc = rmsnorm_split3_f32(cur, b.norm1_scale, hn, M, d, w->norm_eps, st, s_n1)) return rc;
+            if (int rc = gemm_bf16x3_qkv3(hn, b.in_proj_weight3, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, terms, st,
                                           h2 ? s_n1 * w_in : 1.f, s_qkv)) return rc;
             if (w->attn_mode == 1) {
                 if (int rc = attn_fp8(qkv, f8w, f8_b, nullptr, hs, B, N, H, nq, st, terms, s_qkv, s_qkv)) return rc;
             } else {
                 if (int rc = attn_bf16x3(qkv, nullptr, hs, B, N, H, nq, terms, st, s_qkv, s_qkv)) return rc;
             }
-            if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, nullptr, M, d, d, AVD_ACT_NONE, terms, st,
-                                     h2 ? s_qkv * w_out : 1.f, 1.f)) return rc;
-            cur = y;
-            if (int rc = rmsnorm_split3_f32(y, b.norm2_scale, hs, M, d, w->norm_eps, st, s_n2)) return rc;
-            if (int rc = gemm_bf16x3(hs, b.fc1_weight3, b.fc1_bias, nullptr, nullptr, wide3, M, hid, d, AVD_ACT_GELU, terms, st,
+            if (rown) {
+                // new stream (fp32) + image of norm2 of it, in one epilogue
+                if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, hn, M, d, d, AVD_ACT_NONE, terms, st, s_qkv * w_out, s_n2,
+                                         nullptr, w->norm_eps, nullptr, b.norm2_scale)) return rc;
+                cur = y;
+            } else {
+                if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, nullptr, M, d, d, AVD_ACT_NONE, terms, st,
+                                         h2 ? s_qkv * w_out : 1.f, 1.f)) return rc;
+                cur = y;
+                if (int rc = rmsnorm_split3_f32(y, b.norm2_scale, hn, M, d, w->norm_eps, st, s_n2)) return rc;
+            }
+            if (int rc = gemm_bf16x3(hn, b.fc1_weight3, b.fc1_bias, nullptr, nullptr, wide3, M, hid, d, AVD_ACT_GELU, terms, st,
                                      h2 ? s_n2 * w_fc1 : 1.f, s_fc1)) return rc;
-            if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, nullptr, M, d, hid, AVD_ACT_NONE, terms, st,
-                                     h2 ? s_fc1 * w_fc2 : 1.f, 1.f)) return rc;
+            if (rown && !last) {
+                // ... and the next block's norm1 image from fc2's epilogue
+                const avd_block_weights& nb = w->blocks[l + 1];
+                if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, hn, M, d, hid, AVD_ACT_NONE, terms, st, s_fc1 * w_fc2,
+                                         nb.f16x2_scale[4], nullptr, w->norm_eps, nullptr, nb.norm1_scale)) return rc;
+            } else {
+                if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, nullptr, M, d, hid, AVD_ACT_NONE, terms, st,
+                                         h2 ? s_fc1 * w_fc2 : 1.f, 1.f)) return rc;
+            }
         }
         return rmsnorm_f32(y, rd, w->final_norm_scale, y, rd, M, d, w->norm_eps, st);
     }

@@ -167,7 +167,10 @@ __global__ __launch_bounds__(256) void layernorm_act_split3_kernel(const float* 
 // ---------------------------------------------------------------------------------------------------------
 // 5: bias, image out, no activation.  6: bias + residual, fp32 out AND its operand image AND the rows' sums of squares (the
 // producer side of a folded RMSNorm)
-enum { S3_EPI_BIAS = 0, S3_EPI_RES = 2, S3_EPI_GELU_SPLIT = 3, S3_EPI_QKV3 = 4, S3_EPI_SPLIT = 5, S3_EPI_RES_IMG = 6 };
+// 7: bias + residual, fp32 out AND the operand image of RMSNorm(out) — the block owns whole rows (128 x 512 block, N == 512), so the
+// norm that follows the residual add (mmdt.py:97-98 -> 39-42) is finished inside the epilogue; f16x2 images (a normalised row has the
+// bound its image scale needs, the un-normalised stream has none)
+enum { S3_EPI_BIAS = 0, S3_EPI_RES = 2, S3_EPI_GELU_SPLIT = 3, S3_EPI_QKV3 = 4, S3_EPI_SPLIT = 5, S3_EPI_RES_IMG = 6, S3_EPI_RES_NORM = 7 };
 
 struct S3Args {
     const unsigned char* A;   // split3 image of [M][K]
@@ -191,6 +194,7 @@ struct S3Args {
     const float* ss_in;
     float* ss_out;
     float ss_sqrt_d, ss_eps;
+    const float* gamma;         // EPI_RES_NORM: the norm's scale vector [N]; ss_sqrt_d = sqrt(N), ss_eps as above
 #ifdef AVD_S3_STAMPS            // diagnostic build only (tools/micro/s3_stamps.py), never in the product library
     unsigned long long* dbg;
 #endif
@@ -451,6 +455,95 @@ __device__ __forceinline__ void s3_epilogue_img(const S3Args& g, f32x16 (&acc)[4
     s3_epilogue_img_t<EPI, F16>(g, acc, mwave0, nbase, lane, big);
 }
 
+// EPI_RES_NORM (row-owner blocks: 8 waves side by side over the 512 columns of 128 rows).  Pass 1: v = acc + bias + residual is stored
+// as fp32 and kept in the accumulator registers; the rows' sums of squares go wave -> LDS -> every wave (fixed order: lane halves,
+// then waves 0..7).  Pass 2: scale * v / (sqrt(ss) / sqrt(d) + eps), the expression rmsnorm_split3_kernel evaluates, split and stored
+// as the image.  `red` = 8 x 128 floats overlaying the stages.
+template <bool F16>
+__device__ __forceinline__ void s3_epilogue_rownorm(const S3Args& g, f32x16 (&acc)[4][2], int64_t mblock0, int wave, int lane, float* red) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int nbase = wave * 64;
+    float ssq[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        float bv[2][2][8];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int cg = 0; cg < 2; ++cg) {
+                const float* bp = g.bias + nbase + 32 * j + 8 * (2 * cg + hi);
+                *reinterpret_cast<f32x4*>(bv[j][cg]) = *reinterpret_cast<const f32x4*>(bp);
+                *reinterpret_cast<f32x4*>(bv[j][cg] + 4) = *reinterpret_cast<const f32x4*>(bp + 4);
+            }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t m = mblock0 + 32 * i + l31;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * cg + e]), __float_as_uint(acc[i][j][8 * cg + 4 + e]),
+                                                                         false, false);
+                        v[e] = __uint_as_float(sw[0]);
+                        v[4 + e] = __uint_as_float(sw[1]);
+                    }
+                    const int n = nbase + 32 * j + 8 * (2 * cg + hi);
+                    if (m < g.M) {
+                        const float* rp = g.R + m * g.N + n;
+                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = ((F16 ? v[e] * g.ab_inv : v[e]) + bv[j][cg][e]) + (e < 4 ? r0[e] : r1[e - 4]);
+                        float* cp = g.C + m * g.N + n;
+                        *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                        *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                        ssq[i] += ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[i][j][8 * cg + e] = v[e];       // this lane's 8 consecutive columns of row m
+                }
+        }
+    }
+    __syncthreads();          // every wave is past its last fragment read: the stages may be overwritten
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float tot = ssq[i] + __shfl_xor(ssq[i], 32, 64);
+        if (hi == 0) red[wave * 128 + 32 * i + l31] = tot;
+    }
+    __syncthreads();
+    float gv[2][2][8];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+            const float* gp = g.gamma + nbase + 32 * j + 8 * (2 * cg + hi);
+            *reinterpret_cast<f32x4*>(gv[j][cg]) = *reinterpret_cast<const f32x4*>(gp);
+            *reinterpret_cast<f32x4*>(gv[j][cg] + 4) = *reinterpret_cast<const f32x4*>(gp + 4);
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = mblock0 + 32 * i + l31;
+        float ss = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) ss += red[w8 * 128 + 32 * i + l31];
+        const float den = sqrtf(ss) / g.ss_sqrt_d + g.ss_eps;
+        if (S3_ROW_OK(m)) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int cg = 0; cg < 2; ++cg) {
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = gv[j][cg][e] * acc[i][j][8 * cg + e] / den;
+                    const int n = nbase + 32 * j + 8 * (2 * cg + hi);
+                    if constexpr (F16) store_split8_h2(g.C3, m, n, g.N, v, g.c_scale);
+                    else store_split8<true>(g.C3, m, n, g.N, v);
+                }
+        }
+    }
+}
+
 // wait until at most `tiles` x STEP of this wave's DMA pieces are still in flight (tiles is wave-uniform; capped at MAXN, < 0 = 0)
 template <int MAXN, int STEP>
 __device__ __forceinline__ void wait_vm_tiles(int tiles) {
@@ -467,16 +560,17 @@ __device__ __forceinline__ void wait_vm_tiles(int tiles) {
 //              carry the GELU) runs beside the other's main loop.
 // LDS stage = the planes a mode moves, compact: [region (128 rows)][plane][128 rows][32 B]; region stride = planes x 4 KiB; a
 // ring of NST stages.
-template <int TERMS, int WAVES>
+//   ROWN (8 waves, f16x2): 128 x 512 block — the block owns whole rows of an N = 512 output (EPI_RES_NORM); waves 1 x 8.
+template <int TERMS, int WAVES, bool ROWN = false>
 struct S3Cfg {
-    static constexpr int BM = 256, BN = WAVES == 8 ? 256 : 128;
+    static constexpr int BM = ROWN ? 128 : 256, BN = ROWN ? 512 : WAVES == 8 ? 256 : 128;
     static constexpr int NPL = s3_planes(TERMS);              // planes moved and read
     static constexpr int REGIONS = (BM + BN) / 128;           // 128-row regions per stage: A0 A1 W0 (W1)
     static constexpr int RCH = NPL * S3_PLANE;                // one region
     static constexpr int STAGE = REGIONS * RCH;               // 8 waves: 48 / 32 / 16 KiB; 4 waves: 36 / 24 / 12 KiB
     static constexpr int PPR = 4 * NPL;                       // one-KiB pieces per region
     static constexpr int PPW = REGIONS * PPR / WAVES;         // DMA pieces per wave per stage: 2 NPL (8 waves), 3 NPL (4 waves)
-    static constexpr int NST = WAVES == 8 ? (NPL == 3 ? 3 : NPL == 2 ? 4 : 6) : (NPL == 3 ? 2 : NPL == 2 ? 3 : 4);
+    static constexpr int NST = ROWN ? 3 : WAVES == 8 ? (NPL == 3 ? 3 : NPL == 2 ? 4 : 6) : (NPL == 3 ? 2 : NPL == 2 ? 3 : 4);
     static constexpr int SLABS = WAVES * 64 * 68 * 4;         // epilogue slabs, overlay the stages
     static constexpr int LDS = NST * STAGE > SLABS ? NST * STAGE : SLABS;
     static_assert(REGIONS * PPR % WAVES == 0, "pieces divide evenly over the waves");
@@ -501,12 +595,15 @@ struct S3Cfg {
 // (lgkmcnt(0)); behind the barrier all of tile kt+1 is readable and tile kt's stage may be overwritten.
 template <int EPI, int TERMS, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_kernel(S3Args g) {
-    using Cf = S3Cfg<TERMS, WAVES>;
+    constexpr bool ROWN = EPI == S3_EPI_RES_NORM;
+    using Cf = S3Cfg<TERMS, WAVES, ROWN>;
     constexpr int BM = Cf::BM, BN = Cf::BN, WM = 128, WN = 64, TM = 4, TN = 2;
     constexpr int RCH = Cf::RCH, STAGE = Cf::STAGE, PPW = Cf::PPW, NST = Cf::NST;
+    constexpr int RA = BM / 128;                    // 128-row regions of A in a stage (the W regions follow)
     constexpr bool F16 = TERMS == 3;
+    static_assert(!ROWN || WAVES == 8, "row-owner blocks: 8 waves");
     // image epilogues take the accumulator tiles transposed (s3_epilogue_img): W fragments as the MFMA's A operand
-    constexpr bool TR = EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG;
+    constexpr bool TR = EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG || ROWN;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
     [[maybe_unused]] const unsigned long long t_entry = S3_T(), rt_entry = S3_RT();
@@ -549,27 +646,28 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_kernel(S3Args g) {
     // (fragment i of plane p at a_base + i * 1024 + p * S3_PLANE)
     const int swz = (hi ^ ((l31 >> 4) & 1)) << 4;
     const int a_base = wm * RCH + l31 * 32 + swz;
-    const int b_base = (2 + (wn * WN) / 128) * RCH + ((wn * WN) & 127) * 32 + l31 * 32 + swz;
+    const int b_base = (RA + (wn * WN) / 128) * RCH + ((wn * WN) & 127) * 32 + l31 * 32 + swz;
 
     // DMA: the stage image is [A row-tile 0 | A row-tile 1 | W row-tile 0 (| W row-tile 1)], each a 12 KiB chunk in global memory
     // of which the first NPL planes (4 KiB each) are moved in 1-KiB pieces.  4 waves: every wave moves a quarter of each of the
     // three regions; 8 waves: every wave moves half of one region.  A piece's source is a wave-uniform pointer (scalar registers:
     // region base + K-tile + piece) plus the lane's 16 bytes.
-    constexpr int NRW = WAVES == 4 ? 3 : 1;                 // regions a wave moves pieces of
+    // Row-owner blocks (five regions: A0 W0 W1 W2 W3): piece P = PPW wave + i of the stage's pieces, region P / pieces-per-region.
+    constexpr int NRW = ROWN ? PPW : WAVES == 4 ? 3 : 1;    // regions (row-owner: single pieces) a wave moves pieces of
     constexpr int PRW = PPW / NRW;                          // pieces per such region
     const unsigned char* rbase[NRW];
     int rdst[NRW];
 #pragma unroll
     for (int r = 0; r < NRW; ++r) {
-        const int region = WAVES == 4 ? r : wave >> 1;
-        const int within = (WAVES == 4 ? wave * PRW : (wave & 1) * PRW) * 1024;
+        const int region = ROWN ? (wave * PPW + r) / Cf::PPR : WAVES == 4 ? r : wave >> 1;
+        const int within = (ROWN ? (wave * PPW + r) % Cf::PPR : WAVES == 4 ? wave * PRW : (wave & 1) * PRW) * 1024;
         rdst[r] = region * RCH + within;
-        if (region < 2) {
-            int rt = bm * 2 + region;
+        if (region < RA) {
+            int rt = bm * RA + region;
             rt = rt < nrtA ? rt : nrtA - 1;
             rbase[r] = g.A + (int64_t)rt * nk * S3_CHUNK + within;
         } else {
-            rbase[r] = g.W + (int64_t)(bn * (BN / 128) + region - 2) * nk * S3_CHUNK + within;
+            rbase[r] = g.W + (int64_t)(bn * (BN / 128) + region - RA) * nk * S3_CHUNK + within;
         }
     }
     const unsigned lane16 = (unsigned)lane * 16u;
@@ -726,7 +824,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_kernel(S3Args g) {
     }
 #undef S3_SB
     [[maybe_unused]] const unsigned long long t_end = S3_T();
-    if constexpr (TR) {
+    if constexpr (ROWN) {
+        s3_epilogue_rownorm<F16>(g, acc, (int64_t)bm * BM, wave, lane, reinterpret_cast<float*>(smem3));
+    } else if constexpr (TR) {
         s3_epilogue_img<EPI, F16>(g, acc, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane);      // registers only: no barrier, no LDS
     } else {
         __syncthreads();      // the slabs overlay the stages: every wave is past its last fragment read, no DMA is in flight
@@ -1231,6 +1331,8 @@ int layernorm_act_split3_f32(const float* x, const float* gamma, const float* be
 }
 
 bool gemm_bf16x3_supported(int64_t M, int N, int K) { return M > 0 && N > 0 && N % 256 == 0 && K > 0 && K % 16 == 0; }
+// residual + RMSNorm epilogue (a block owns whole rows): 512 columns, f16x2 images
+bool gemm_bf16x3_rownorm_supported(int N, int terms) { return N == 512 && terms == 3; }
 
 // tile configuration: 0 = 256x256, 8 waves, one block per CU; 1 = 256x128, 4 waves, two blocks per CU.
 // AVD_S3_TILE=0|1 forces one (measurement aid, also avd_tune_set "s3_tile"); default: per epilogue, what measured faster in the C3 pipeline.
@@ -1269,7 +1371,7 @@ static int s3_cu_count() {                 // CUs of the current device (looked 
 
 template <int EPI, int TERMS, int WAVES>
 static int launch_s3w(S3Args g, hipStream_t st) {
-    using Cf = S3Cfg<TERMS, WAVES>;
+    using Cf = S3Cfg<TERMS, WAVES, EPI == S3_EPI_RES_NORM>;
     constexpr bool tile = WAVES == 4;
     static LdsAttr attr;
     auto kern = gemm_bf16x3_kernel<EPI, TERMS, WAVES>;
@@ -1346,7 +1448,7 @@ static int launch_s3w16(S3Args g, hipStream_t st) {
 
 template <int EPI, int TERMS>
 static int launch_s3t(const S3Args& a, hipStream_t st) {
-    if constexpr (TERMS == 6) {
+    if constexpr (TERMS == 6 && EPI != S3_EPI_RES_NORM) {
         if (g_s3_m16) {
             if (s3_tile_for(EPI, a.M, a.N)) return launch_s3w16<EPI, 4>(a, st);
             if constexpr (EPI == S3_EPI_RES_IMG) {
@@ -1358,7 +1460,12 @@ static int launch_s3t(const S3Args& a, hipStream_t st) {
             return launch_s3w16<EPI, 8>(a, st);
         }
     }
-    return s3_tile_for(EPI, a.M, a.N) ? launch_s3w<EPI, TERMS, 4>(a, st) : launch_s3w<EPI, TERMS, 8>(a, st);
+    if constexpr (EPI == S3_EPI_RES_NORM) {
+        if constexpr (TERMS == 3) return launch_s3w<EPI, 3, 8>(a, st);
+        else AVD_REQUIRE(false, AVD_EUNSUPPORTED, "gemm_bf16x3: the residual + RMSNorm epilogue exists for f16x2 images only");
+    } else {
+        return s3_tile_for(EPI, a.M, a.N) ? launch_s3w<EPI, TERMS, 4>(a, st) : launch_s3w<EPI, TERMS, 8>(a, st);
+    }
 }
 
 template <int EPI>
@@ -1377,8 +1484,11 @@ static int launch_s3(const S3Args& a, hipStream_t st) {
 // Folded RMSNorm (see S3Args): ss_in -> image outputs scale their rows by 1 / (||row of the un-normalised A|| / sqrt(K) + eps);
 // C, C3, R and ss_out all given -> the new residual stream as fp32, as an image and as sums of squares in one epilogue.
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
-                int act, int terms, hipStream_t st, float ab_scale, float c_scale, const float* ss_in, float eps, float* ss_out) {
+                int act, int terms, hipStream_t st, float ab_scale, float c_scale, const float* ss_in, float eps, float* ss_out,
+                const float* gamma) {
     AVD_REQUIRE(A3 && W3 && (C || C3), AVD_EINVAL, "gemm_bf16x3: null pointer");
+    AVD_REQUIRE(!gamma || (gemm_bf16x3_rownorm_supported(N, terms) && C && C3 && R && bias && !ss_in && !ss_out && act == AVD_ACT_NONE && aligned16(gamma)),
+                AVD_EUNSUPPORTED, "gemm_bf16x3: the residual + RMSNorm epilogue needs N == 512, f16x2 images, fp32 and image outputs, bias and residual");
     AVD_REQUIRE(!ss_in || (C3 && !C && K % 64 == 0), AVD_EUNSUPPORTED, "gemm_bf16x3: a folded norm needs an image output and K %% 64 == 0");
     AVD_REQUIRE(!ss_out || (C && C3 && R && bias && N % 64 == 0 && act == AVD_ACT_NONE && terms != 3), AVD_EUNSUPPORTED,
                 "gemm_bf16x3: sums of squares are written by the fp32 + image residual epilogue only (bf16 planes)");
@@ -1390,7 +1500,11 @@ int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* 
                 "gemm_bf16x3: pointers must be 16-byte aligned");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, R, C,
              static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0, 0, 0, 0, 0.f, 0, 0, terms, 1.0f / ab_scale, c_scale,
-             ss_in, ss_out, (float)sqrt((double)K), eps};
+             ss_in, ss_out, (float)sqrt((double)K), eps, gamma};
+    if (gamma) {
+        a.ss_sqrt_d = (float)sqrt((double)N);
+        return launch_s3<S3_EPI_RES_NORM>(a, st);
+    }
     if (C && C3) {
         AVD_REQUIRE(ss_out, AVD_EUNSUPPORTED, "gemm_bf16x3: fp32 and image output together imply the residual + sums-of-squares epilogue");
         return launch_s3<S3_EPI_RES_IMG>(a, st);
@@ -1420,7 +1534,7 @@ int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* im
     AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(bias) && aligned16(img), AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: alignment");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, nullptr, nullptr,
              static_cast<unsigned char*>(img), M, N, K, 0, 0, 0, tokens, qkv3_npad(tokens), heads, qscale, 0, 0, terms, 1.0f / ab_scale, c_scale,
-             ss_in, nullptr, (float)sqrt((double)K), eps};
+             ss_in, nullptr, (float)sqrt((double)K), eps, nullptr};
     return launch_s3<S3_EPI_QKV3>(a, st);
 }
 

@@ -1348,6 +1348,42 @@ def test_split_gemm_block_rows_agree(dev, full, B):
     assert rel_err(outs[7][:1], ref) < TOL
 
 
+@pytest.mark.parametrize("B", [5, 32])
+def test_f16x2_rownorm_epilogue_matches_norm_kernel(dev, full, B):
+    """f16x2, d = 512: out_proj / fc2 run on 128 x 512 blocks that own whole rows and finish the NEXT RMSNorm (mmdt.py:39-42 after
+    the residual add of :97-98) in their epilogue — fp32 stream + the normalised image, no rmsnorm_split3 launch between blocks.
+    Same expression per element as the norm kernel; only the order in which a row's squares are summed differs, so the step agrees
+    with the unfused pipeline (avd_tune_set "no_fold" 1) to fp32 rounding, and with the CPU oracle to the parity tolerance.
+    B = 5: 4,210 rows (ragged last 128-row block); B = 32: the bench shape."""
+    import multimodal_diffusion_amd as A
+    ws, mods = full
+    core, head, av, aa = mods
+    g = torch.Generator().manual_seed(900 + B)
+    z_v = torch.randn(B, 8, 12, 32, 32, generator=g)
+    z_a = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn = torch.tensor(([982, 500, 16, 999] * B)[:B])
+    tp = torch.tensor(([966, 480, -1, 979] * B)[:B])
+    outs = []
+    for no_fold in (0, 1):
+        _tune("no_fold", no_fold)
+        try:
+            eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z_v.shape),
+                                  prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul="f16x2")
+            eng.set_prompt(z_a.to(dev))
+            outs.append(eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)).cpu())
+        finally:
+            _tune("no_fold", 0)
+    assert torch.isfinite(outs[0]).all()
+    d = rel_err(outs[0], outs[1])
+    print(f"f16x2 row-norm epilogue vs norm kernel, B={B}: {d:.3e}")
+    assert d < 3e-6
+    idx = [0, B - 1]
+    ref = R.denoise_step_a2v(z_v[idx], z_a[idx], tn[idx], tp[idx], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"], core=ws["core"],
+                             head=ws["head"], n_layers=8, n_heads=8, guidance=3.5)
+    assert rel_err(outs[0][idx], ref) < TOL
+
+
 def test_split_gemm_tile_configurations_agree(dev):
     """The two block configurations of the split-operand GEMM (8 waves 256x256 / 4 waves 256x128, avd_tune_set "s3_tile") sum
     every output element over k in the same order with the same product terms: bit-identical results, in every mode, for the
