@@ -472,7 +472,8 @@ def main():
     D.barrier()
     if torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
-    bad = [(m, e) for m, e in gate if m in GATED_MODES and not e < PARITY_TOL]
+    # --attn fp8 is an explicit reduced-precision request (BASELINE C5): its error is reported in the line, never gated as fp32-level
+    bad = [(m, e) for m, e in gate if m in GATED_MODES and args.attn == "default" and not e < PARITY_TOL]
     if bad:
         raise SystemExit("parity gate failed (one step vs the CPU oracle, tolerance %g): %s" % (PARITY_TOL, bad))
 

@@ -50,7 +50,9 @@ int         avd_device_arch(char* buf, int buflen);
  * 2 = 64x64 LDS-DMA tile of avd_gemm_bias_act_f32), "gemm_stages" (0 by size, 2 / 3 LDS stages), "s3_tile" (-1 per epilogue, 0 = 8-wave
  * 256x256, 1 = 4-wave 256x128 blocks of the split-operand GEMMs), "s3_stagger" (first-generation stagger of co-resident 4-wave blocks,
  * x 1024 cycles; -1 automatic), "s3_min_rows" (smallest 2B*N that takes the split-operand kernels), "no_fold" (1 = keep RMSNorm as
- * separate kernels in avd_core_forward_f32, fp32 and bf16-plane paths alike). */
+ * separate kernels in avd_core_forward_f32, in every mode), "s3_m16" (1 default: bf16x3 GEMMs on v_mfma_f32_16x16x32_bf16 with two product
+ * terms per instruction; 0: the 32x32x16 kernel), "s3_rt" (rows per 8-wave block of the bf16x3 residual + image epilogue: 0 automatic,
+ * 7 = 224 rows, 8 = 256 rows; results are bit-identical). */
 int         avd_tune_set(const char* key, int64_t value);
 
 /* ---- a6: RMSNorm — avdiff/models/mmdt.py:33-42 (RMSNorm.forward)

@@ -288,5 +288,11 @@ int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* 
                 float* ss_out = nullptr, const float* gamma = nullptr);
 // gamma != null (f16x2 images, N == 512): C = A W^T + bias + R as fp32 AND C3 = image (scale c_scale) of RMSNorm(C; gamma, eps)
 bool gemm_bf16x3_rownorm_supported(int N, int terms);
+// split-K for residual GEMMs that cannot fill the chip (small batches): slices to use (0 = none), workspace, launch
+extern int g_s3_splitk;          // slices tried (0 off; avd_tune_set "s3_splitk")
+int gemm_bf16x3_splitk_slices(int64_t M, int N, int K, int terms);
+int64_t gemm_bf16x3_splitk_ws_floats(int64_t M, int N, int ns);
+int gemm_bf16x3_splitk(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, float* ss, int64_t M, int N,
+                       int K, int terms, int ns, float* part, hipStream_t st);
 
 }  // namespace avd

@@ -158,7 +158,10 @@ static int64_t core_ws_bytes(const avd_core_weights* w, int B, int N) {
     // folded norms: a second [M][d] image (the residual stream's) and the table of its rows' sums of squares
     const int64_t fold_b = core_use_split_fold(w) ? align_up(split3_bytes(M, w->d)) + align_up(M * (w->d / 64) * 4)
                          : core_use_split_rownorm(w) ? align_up(split3_bytes(M, w->d)) : 0;        // the normalised stream's image
-    const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d)) + align_up(f8_b) + fold_b;
+    // split-K partial sums of fc2 for batches that cannot fill the chip (folded bf16-plane path only)
+    const int ns = core_use_split_fold(w) ? gemm_bf16x3_splitk_slices(M, w->d, w->mlp_hidden, w->split_terms) : 0;
+    const int64_t sk_b = ns ? align_up(gemm_bf16x3_splitk_ws_floats(M, w->d, ns) * 4) : 0;
+    const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d)) + align_up(f8_b) + fold_b + sk_b;
     return split_path > fp32_path ? split_path : fp32_path;
 }
 
@@ -227,6 +230,8 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
             // scale and multiply their rows by 1 / (rms + eps) before the bias.  No norm kernel between the first split and the final norm.
             void* hx = cs.take((split3_bytes(M, d) + 3) / 4);           // image of the residual stream
             float* ss = cs.take(M * (d / 64));                           // its rows' sums of squares, [M][d / 64]
+            const int ns = gemm_bf16x3_splitk_slices(M, d, hid, terms);
+            float* part = ns ? cs.take(gemm_bf16x3_splitk_ws_floats(M, d, ns)) : nullptr;
             if (int rc = split3_rows_f32(cur, rd, hx, M, d, st, 0.f, ss)) return rc;
             for (int l = 0; l < w->n_layers; ++l) {
                 const avd_block_weights& b = w->blocks[l];
@@ -244,7 +249,10 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
                 cur = y;
                 if (int rc = gemm_bf16x3(hx, b.fc1_weight3n, b.fc1_bias, nullptr, nullptr, wide3, M, hid, d, AVD_ACT_GELU, terms, st, 1.f, 1.f, ss,
                                          w->norm_eps)) return rc;
-                if (last) {     // nothing reads the stream's image after the last block: the final norm takes the fp32 rows
+                if (ns) {       // too few blocks for the chip: K slices + a deterministic reduction that writes what the epilogue would
+                    if (int rc = gemm_bf16x3_splitk(wide3, b.fc2_weight3, b.fc2_bias, y, y, last ? nullptr : hx, last ? nullptr : ss, M, d, hid,
+                                                    terms, ns, part, st)) return rc;
+                } else if (last) {     // nothing reads the stream's image after the last block: the final norm takes the fp32 rows
                     if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, nullptr, M, d, hid, AVD_ACT_NONE, terms, st)) return rc;
                 } else {
                     if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, y, y, hx, M, d, hid, AVD_ACT_NONE, terms, st, 1.f, 1.f, nullptr, 0.f,
@@ -549,6 +557,7 @@ extern "C" int avd_tune_set(const char* key, int64_t value) {
     if (!strcmp(key, "s3_tile")) { g_s3_tile = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_m16")) { g_s3_m16 = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_rt")) { g_s3_rt = (int)value; return AVD_OK; }
+    if (!strcmp(key, "s3_splitk")) { g_s3_splitk = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_stagger")) { g_s3_stagger = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_tile")) { g_gemm_force_tile = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_stages")) { g_gemm_stages = (int)value; return AVD_OK; }

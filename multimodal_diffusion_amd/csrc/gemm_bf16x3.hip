@@ -25,7 +25,11 @@
 // the following tiles spread between them (see the kernel):
 //   WAVES = 8   256x256 block, one block per CU, ring of 3 / 4 / 6 stages (3 / 2 / 1 planes);
 //   WAVES = 4   256x128 block, two blocks per CU, 2 / 3 / 4 stages — for the heavy epilogues (image outputs) and for batches
-//               that do not fill 256-row tiles.
+//               that do not fill 256-row tiles;
+//   EPI_RES_NORM (f16x2, N = 512): 128x512 row-owner block, 8 waves side by side — the RMSNorm that follows the residual add is
+//               finished in the epilogue.
+// bf16x3 (six terms) runs by default on gemm_bf16x3_m16_kernel<EPI, WAVES, RT> below: v_mfma_f32_16x16x32_bf16 with TWO product terms
+// per instruction (same matrix-pipe cycles, higher sustained clock), 224-row blocks (RT = 7) where that keeps a launch in one generation.
 // What caps the rate is power: bf16x3 holds 2.07 GHz at 1.33 kW, f16x2 1.91 GHz at the 1.4 kW cap.
 #include "avd_common.h"
 
@@ -640,6 +644,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_kernel(S3Args g) {
     }
     const int nk = g.K >> 4;
     const int nrtA = (int)((g.M + 127) >> 7);
+    // split-K launches (gemm_bf16x3_splitk): blockIdx.y = K slice z of gridDim.y; g.K is ONE slice's length, the images hold all of
+    // them (a row group's k-groups are nk * gridDim.y apart), slice z writes its partial sums to C + z * M * N
+    const int nz = gridDim.y, kz = blockIdx.y;
+    if (nz > 1) g.C += (int64_t)kz * g.M * g.N;
 
     // fragment addresses inside a stage: the wave's A rows all sit in region wm, its W rows in one W region, and rows 32 apart
     // are 1 KiB apart with the same chunk swizzle — one lane offset per operand, everything else is an immediate
@@ -665,9 +673,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_kernel(S3Args g) {
         if (region < RA) {
             int rt = bm * RA + region;
             rt = rt < nrtA ? rt : nrtA - 1;
-            rbase[r] = g.A + (int64_t)rt * nk * S3_CHUNK + within;
+            rbase[r] = g.A + ((int64_t)rt * nz + kz) * nk * S3_CHUNK + within;
         } else {
-            rbase[r] = g.W + (int64_t)(bn * (BN / 128) + region - RA) * nk * S3_CHUNK + within;
+            rbase[r] = g.W + ((int64_t)(bn * (BN / 128) + region - RA) * nz + kz) * nk * S3_CHUNK + within;
         }
     }
     const unsigned lane16 = (unsigned)lane * 16u;
@@ -1370,7 +1378,7 @@ static int s3_cu_count() {                 // CUs of the current device (looked 
 }
 
 template <int EPI, int TERMS, int WAVES>
-static int launch_s3w(S3Args g, hipStream_t st) {
+static int launch_s3w(S3Args g, hipStream_t st, int nz = 1) {
     using Cf = S3Cfg<TERMS, WAVES, EPI == S3_EPI_RES_NORM>;
     constexpr bool tile = WAVES == 4;
     static LdsAttr attr;
@@ -1403,8 +1411,8 @@ static int launch_s3w(S3Args g, hipStream_t st) {
         g.stagger = g_s3_stagger >= 0 ? g_s3_stagger : t_s3_two_streams ? 0 : (TERMS == 3 ? 24 : TERMS == 1 ? 12 : 48) * (g.K >= 1024 ? 2 : 1);
     // tag = the kernel name as rocprofv3 prints its template arguments (EPI, TERMS, WAVES)
     static const int tag = prof_tag_id("gemm_bf16x3_kernel<%d, %d, %d>", EPI, TERMS, WAVES);
-    ProfScope prof(tag, 2.0 * (double)g.M * g.N * g.K, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WAVES * 64), Cf::LDS, st, g);
+    ProfScope prof(tag, 2.0 * (double)g.M * g.N * g.K * nz, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)nz), dim3(WAVES * 64), Cf::LDS, st, g);
     AVD_CHECK_LAUNCH("gemm_bf16x3");
     return AVD_OK;
 }
@@ -1517,6 +1525,89 @@ int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* 
     AVD_REQUIRE(act == AVD_ACT_NONE, AVD_EUNSUPPORTED, "gemm_bf16x3: fp32 output supports act NONE only");
     if (R) return launch_s3<S3_EPI_RES>(a, st);
     return launch_s3<S3_EPI_BIAS>(a, st);
+}
+
+// ---- split-K for launches that cannot fill the chip (fc2 of the small configurations: 3,904 rows x 512 columns are 64 blocks) ----
+// Slice z of NS multiplies k in [z K / NS, (z + 1) K / NS) and stores its fp32 partial sums; this kernel adds them in slice order, then
+// bias and residual as the residual epilogues do, and writes what they write: the fp32 stream and (IMG) its operand image and the
+// rows' sums of squares per 64-column chunk.  Deterministic: fixed order, no atomics.  One thread per 8 columns.
+template <bool IMG>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int ns, const float* __restrict__ bias,
+                                                            const float* R, float* C, unsigned char* __restrict__ C3,
+                                                            float* __restrict__ ss, int64_t M, int N) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = N >> 3;
+    const int64_t m = i / per_row;
+    const int n = (int)(i % per_row) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (m < M) {
+        const int64_t o = m * N + n;
+        *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(part + o);
+        *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(part + o + 4);
+        for (int z = 1; z < ns; ++z) {
+            const float* pz = part + (int64_t)z * M * N + o;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(pz), b = *reinterpret_cast<const f32x4*>(pz + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+        }
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + n), b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
+        const f32x4 r0 = *reinterpret_cast<const f32x4*>(R + o), r1 = *reinterpret_cast<const f32x4*>(R + o + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = (v[e] + b0[e]) + r0[e]; v[4 + e] = (v[4 + e] + b1[e]) + r1[e]; }
+        *reinterpret_cast<f32x4*>(C + o) = f32x4{v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(C + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+        if constexpr (IMG) store_split8<true>(C3, m, n, N, v);
+    }
+    if constexpr (IMG) {      // 8 consecutive threads hold one 64-column chunk of one row (N % 64 == 0)
+        float q = ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+        q += __shfl_xor(q, 1, 64);
+        q += __shfl_xor(q, 2, 64);
+        q += __shfl_xor(q, 4, 64);
+        if ((threadIdx.x & 7) == 0 && m < M) ss[m * (N >> 6) + (n >> 6)] = q;
+    }
+}
+
+// K slices for a residual GEMM of [M][N] over K, 0 = do not split: only when the 256x128 blocks cover at most half of the CUs
+// and a slice keeps >= 32 k-steps.  avd_tune_set "s3_splitk" (AVD_S3_SPLITK): 0 off, else the slice count tried (default 4).
+int g_s3_splitk = getenv("AVD_S3_SPLITK") ? atoi(getenv("AVD_S3_SPLITK")) : 4;
+int gemm_bf16x3_splitk_slices(int64_t M, int N, int K, int terms) {
+    const int ns = g_s3_splitk;
+    if (ns < 2 || terms == 3 || ((terms == 0 || terms == 6) && g_s3_m16) || N % 128 || K % (16 * ns) || K / ns < 512) return 0;
+    const int cu = s3_cu_count();
+    return (M + 255) / 256 * (N / 128) * 2 <= cu ? ns : 0;
+}
+int64_t gemm_bf16x3_splitk_ws_floats(int64_t M, int N, int ns) { return (int64_t)ns * M * N; }
+
+// C = A W^T + bias + R (fp32), optionally C3 = operand image of C and ss = its rows' sums of squares; bf16-plane images
+int gemm_bf16x3_splitk(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, float* ss, int64_t M, int N,
+                       int K, int terms, int ns, float* part, hipStream_t st) {
+    AVD_REQUIRE(A3 && W3 && bias && R && C && part && ns >= 2, AVD_EINVAL, "gemm_bf16x3_splitk: null pointer");
+    AVD_REQUIRE((C3 != nullptr) == (ss != nullptr), AVD_EINVAL, "gemm_bf16x3_splitk: the image and the sums of squares come together");
+    AVD_REQUIRE(K % (16 * ns) == 0 && N % 128 == 0 && N % 64 == 0 && gemm_bf16x3_supported(M, N, K / ns), AVD_EUNSUPPORTED,
+                "gemm_bf16x3_splitk: shape (M=%lld N=%d K=%d slices=%d)", (long long)M, N, K, ns);
+    AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(C) && aligned16(C3) && aligned16(bias) && aligned16(R) && aligned16(part),
+                AVD_EUNSUPPORTED, "gemm_bf16x3_splitk: pointers must be 16-byte aligned");
+    S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), nullptr, nullptr, part, nullptr, M, N, K / ns,
+             0, 0, 0, 0, 0, 0, 0.f, 0, 0, terms, 1.0f, 1.0f, nullptr, nullptr, 1.0f, 0.f, nullptr};
+    int rc;
+    switch (terms) {
+        case 1: rc = launch_s3w<S3_EPI_BIAS, 1, 4>(a, st, ns); break;
+        case 9: rc = launch_s3w<S3_EPI_BIAS, 9, 4>(a, st, ns); break;
+        case 0: case 6: rc = launch_s3w<S3_EPI_BIAS, 6, 4>(a, st, ns); break;
+        default: AVD_REQUIRE(false, AVD_EUNSUPPORTED, "gemm_bf16x3_splitk: bf16-plane modes only (terms %d)", terms);
+    }
+    if (rc) return rc;
+    const int64_t threads = M * (N >> 3);
+    static const int tag = prof_tag_id("splitk_reduce_kernel");
+    ProfScope prof(tag, (double)M * N * 4.0 * (ns + 2) + (C3 ? (double)M * N * 6.0 : 0.0), st);
+    if (C3)
+        hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, part, ns, bias, R, C,
+                           static_cast<unsigned char*>(C3), ss, M, N);
+    else
+        hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, part, ns, bias, R, C,
+                           nullptr, nullptr, M, N);
+    AVD_CHECK_LAUNCH("splitk_reduce");
+    return AVD_OK;
 }
 
 // in_proj for the bf16x3 attention: qkv = A W^T + bias written as the qkv3 image (q pre-multiplied by qscale)

@@ -1384,6 +1384,34 @@ def test_f16x2_rownorm_epilogue_matches_norm_kernel(dev, full, B):
     assert rel_err(outs[0][idx], ref) < TOL
 
 
+@pytest.mark.parametrize("matmul", ["bf16", "bf16x3_strict"])
+def test_splitk_small_batch_fc2(dev, full, matmul):
+    """BASELINE C2 geometry (64x64, B = 32: 3,904 rows).  fc2's 256x128 blocks cover a quarter of the CUs, so its K = 2,048 is cut
+    into four slices (blockIdx.y) whose fp32 partial sums a reduction kernel adds in slice order before bias and residual, writing the
+    stream, its operand image and the rows' sums of squares as the fused epilogue would (avd_tune_set "s3_splitk"; no atomics:
+    repeatable bit for bit).  Against the unsplit launch only the summation order differs; the strict nine-term mode (exact operands,
+    forced onto the split kernels at this size) is held to the parity tolerance against the CPU oracle."""
+    ws, mods = full
+    outs = []
+    try:
+        _tune("s3_min_rows", 0)
+        for ns in (4, 0, 4):
+            _tune("s3_splitk", ns)
+            out, ref = _one_step(dev, mods, ws, 64, 32, 2, matmul=matmul)
+            outs.append(out)
+    finally:
+        _tune("s3_splitk", 4)
+        _tune("s3_min_rows", 6144)
+    assert torch.isfinite(outs[0]).all()
+    assert torch.equal(outs[0], outs[2])
+    d = rel_err(outs[0], outs[1])
+    print(f"split-K fc2 vs one launch, {matmul}: {d:.3e}")
+    assert d < 3e-6
+    assert not torch.equal(outs[0], outs[1]) or matmul == "bf16x3_strict"      # the split path really ran (summation order shows)
+    if matmul == "bf16x3_strict":
+        assert rel_err(outs[0][:2], ref) < TOL
+
+
 def test_split_gemm_tile_configurations_agree(dev):
     """The two block configurations of the split-operand GEMM (8 waves 256x256 / 4 waves 256x128, avd_tune_set "s3_tile") sum
     every output element over k in the same order with the same product terms: bit-identical results, in every mode, for the
