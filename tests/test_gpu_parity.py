@@ -1384,7 +1384,7 @@ def test_f16x2_rownorm_epilogue_matches_norm_kernel(dev, full, B):
     assert rel_err(outs[0][idx], ref) < TOL
 
 
-@pytest.mark.parametrize("matmul", ["bf16", "bf16x3_strict"])
+@pytest.mark.parametrize("matmul", ["bf16x3_strict", "bf16"])
 def test_splitk_small_batch_fc2(dev, full, matmul):
     """BASELINE C2 geometry (64x64, B = 32: 3,904 rows).  fc2's 256x128 blocks cover a quarter of the CUs, so its K = 2,048 is cut
     into four slices (blockIdx.y) whose fp32 partial sums a reduction kernel adds in slice order before bias and residual, writing the
@@ -1405,11 +1405,16 @@ def test_splitk_small_batch_fc2(dev, full, matmul):
     assert torch.isfinite(outs[0]).all()
     assert torch.equal(outs[0], outs[2])
     d = rel_err(outs[0], outs[1])
-    print(f"split-K fc2 vs one launch, {matmul}: {d:.3e}")
-    assert d < 3e-6
-    assert not torch.equal(outs[0], outs[1]) or matmul == "bf16x3_strict"      # the split path really ran (summation order shows)
+    e = rel_err(outs[0][:2], ref)
+    print(f"split-K fc2 vs one launch, {matmul}: {d:.3e}; vs CPU oracle {e:.3e}")
+    assert not torch.equal(outs[0], outs[1])      # the split path really ran (the summation order shows)
     if matmul == "bf16x3_strict":
-        assert rel_err(outs[0][:2], ref) < TOL
+        assert d < 3e-6
+        assert e < TOL
+    else:
+        # one-plane operands: a 1e-7 change of the stream flips 8-bit operand roundings downstream, so two summation orders differ by
+        # about the mode's own error (measured 1.1e-2 between them, 7.1e-3 / 7.5e-3 against the oracle): reported-error bound only
+        assert e < 3e-2 and d < 3e-2
 
 
 def test_split_gemm_tile_configurations_agree(dev):
