@@ -532,7 +532,7 @@ __device__ __forceinline__ void s3_epilogue_rownorm(const S3Args& g, f32x16 (&ac
 #pragma unroll
         for (int w8 = 0; w8 < 8; ++w8) ss += red[w8 * 128 + 32 * i + l31];
         const float den = sqrtf(ss) / g.ss_sqrt_d + g.ss_eps;
-        if (S3_ROW_OK(m)) {
+        if (m < g.M) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
