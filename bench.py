@@ -219,7 +219,7 @@ def roofline_of(rep, matmul: str, n_steps: int):
     achieved = work / (ms * 1e-3) / 1e12
 
     def peak_of(name):
-        if name.startswith("gemm_bf16x3_m16"):        # <EPI, WAVES, RT>: always the six bf16x3 terms (two per 16x16x32 MFMA, same MFMA cycles)
+        if name.startswith(("gemm_bf16x3_m16", "gemm_bf16x3_w128")):      # <EPI, WAVES, RT> / <EPI, RT>: always the six bf16x3 terms (two per 16x16x32 MFMA)
             return PEAK_BF16_MATRIX_TFLOPS / 6
         if name.startswith("gemm_bf16x3"):            # <EPI, TERMS, ...>
             return PEAK_BF16_MATRIX_TFLOPS / int(name.split("<")[1].split(",")[1].strip(" >"))

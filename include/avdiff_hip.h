@@ -52,7 +52,8 @@ int         avd_device_arch(char* buf, int buflen);
  * x 1024 cycles; -1 automatic), "s3_min_rows" (smallest 2B*N that takes the split-operand kernels), "no_fold" (1 = keep RMSNorm as
  * separate kernels in avd_core_forward_f32, in every mode), "s3_m16" (1 default: bf16x3 GEMMs on v_mfma_f32_16x16x32_bf16 with two product
  * terms per instruction; 0: the 32x32x16 kernel), "s3_rt" (rows per 8-wave block of the bf16x3 residual + image epilogue: 0 automatic,
- * 7 = 224 rows, 8 = 256 rows; results are bit-identical), "s3_splitk" (K slices of the fc2 launch when its blocks cover at most half of the
+ * 7 = 224 rows, 8 = 256 rows; results are bit-identical), "s3_w128" (1 default: the bf16x3 residual + image GEMMs run as four waves
+ * with a 128 x 128 wave tile and accumulators in AGPRs; 0: eight waves with 128 x 64 tiles; bit-identical), "s3_splitk" (K slices of the fc2 launch when its blocks cover at most half of the
  * CUs — small batches; 0 = never, default 4; partial sums are added in slice order by a reduction kernel, no atomics). */
 int         avd_tune_set(const char* key, int64_t value);
 

@@ -557,6 +557,7 @@ extern "C" int avd_tune_set(const char* key, int64_t value) {
     if (!strcmp(key, "s3_tile")) { g_s3_tile = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_m16")) { g_s3_m16 = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_rt")) { g_s3_rt = (int)value; return AVD_OK; }
+    if (!strcmp(key, "s3_w128")) { g_s3_w128 = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_splitk")) { g_s3_splitk = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_stagger")) { g_s3_stagger = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_tile")) { g_gemm_force_tile = (int)value; return AVD_OK; }

@@ -1099,12 +1099,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
     enum { T_HM = 0, T_HL = 1, T_MH = 2, T_LH = 3 };
     auto plane_of = [&](int type) { return type == T_HM ? p1 : type == T_HL ? 2 * p1 : type == T_MH ? PS - p1 : 2 * PS - 2 * p1; };
     auto lda = [&](bf16x8 (&dst)[8], const unsigned char* st, int type, int i0 = 0, int i1 = 8) {
+#ifdef AVD_LAB_NOLDS       // diagnostic build: fragments stay whatever the registers hold (results are wrong by design)
+        if (type >= 0) { asm volatile("" : "+v"(dst[0])); return; }
+#endif
         const int pl = plane_of(type);
 #pragma unroll
         for (int i = i0; i < i1; ++i)
             if (i < RT) dst[i] = *reinterpret_cast<const bf16x8*>(st + a_uni + ((i & 1) ? abase_o : abase_e) + pl + i * 512);
     };
     auto ldb = [&](bf16x8 (&dst)[4], const unsigned char* st, int type) {
+#ifdef AVD_LAB_NOLDS
+        if (type >= 0) { asm volatile("" : "+v"(dst[0])); return; }
+#endif
         const int pl = plane_of(type);
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(st + b_uni + ((j & 1) ? base_o : base_e) + pl + j * 512);
@@ -1244,6 +1250,198 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
         float* slab = reinterpret_cast<float*>(smem3) + wave * 64 * CLD;
         s3_epilogue16<EPI>(g, acc, slab, (int64_t)bm * BM + wm * WM, bn * BN + wn * WN, lane_e);
     }
+#ifdef AVD_S3_STAMPS
+    const unsigned long long t_issued = S3_T();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    S3_DBG(4, t_issued);
+    S3_DBG(0, t_entry); S3_DBG(1, t_loop); S3_DBG(2, t_end); S3_DBG(3, S3_T());
+    S3_DBG(8, (unsigned long long)nk); S3_DBG(9, S3_RT()); S3_DBG(10, rt_entry);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// bf16x3, 16x16x32 MFMA, FOUR waves with a 128 x 128 wave tile (one wave per SIMD, accumulators in the AGPR half of its 512 registers)
+// ---------------------------------------------------------------------------------------------------------
+// Why: diagnostic builds of the 8-wave kernel above (tools/micro/s3_stamps.py --variant, profiles/r03_s3_stamps.txt) put a price on its
+// fragment reads — with them removed fc2 runs 200 us instead of 267 (15 % fewer cycles per step AND 2.39 instead of 2.11 GHz: LDS
+// traffic is power) — and 28 ds_read_b128 per 96 MFMAs is the minimum for a 128 x 64 wave tile.  A 128 x 128 wave tile needs 40 reads
+// per 192 MFMAs (-29 % LDS bytes per FLOP); its 8 x 8 accumulator tiles are 256 registers, so a SIMD holds ONE wave and nothing hides
+// that wave's waits but its own schedule: every fragment a step starts with is read during the step before (the 256 VGPRs beside
+// the accumulators hold two A sets and two W sets: [h|l] of tile kt+1 replaces [h|l] of tile kt as soon as the first MFMA group is
+// through, the W sets trade roles from step to step), the DMA of tile kt+2 is spread behind the MFMAs of step kt and awaited at the top
+// of step kt+1.  Same 256 x 256 (224 x 256) blocks, stage layout and DMA pieces as the 8-wave kernel; image epilogues only.
+template <int EPI, int RT>
+__global__ __launch_bounds__(256, 1) void gemm_bf16x3_w128_kernel(S3Args g) {
+    constexpr int BM = 32 * RT, BN = 256, WM = 16 * RT, PS = 256 * 32, STAGE = 6 * PS, NST = 3, PPW = 12;
+    static_assert(EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG, "register image epilogues only");
+    static_assert(RT == 8 || RT == 7, "row tiles per wave");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
+
+    [[maybe_unused]] const unsigned long long t_entry = S3_T(), rt_entry = S3_RT();
+    int bm, bn;
+    {
+        int wg;
+        {
+            const int b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+            wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+        }
+        const int per_row = g.sm * g.nbn, per_st = g.sm * g.sn;
+        const int srow = wg / per_row, rem = wg % per_row;
+        const int sc = rem / per_st, rem2 = rem % per_st;
+        bm = srow * g.sm + rem2 / g.sn;
+        bn = sc * g.sn + rem2 % g.sn;
+        if ((int64_t)bm * BM >= g.M) return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int nk = g.K >> 4;
+    const int nrtA = (int)((g.M + 127) >> 7);
+
+    const int hiq = kq >> 1;
+    const int base_e = l15 * 32 + ((kq & 1) << 4), base_o = l15 * 32 + (((kq & 1) ^ 1) << 4);
+    const bool flip_a = ((wm * RT) & 1) != 0;
+    const int abase_e = flip_a ? base_o : base_e, abase_o = flip_a ? base_e : base_o;
+    const int p1 = hiq * PS;
+    const int a_uni = wm * (RT * 512), b_uni = 3 * PS + wn * 128 * 32;
+    enum { T_HM = 0, T_HL = 1, T_MH = 2, T_LH = 3 };
+    auto plane_of = [&](int type) { return type == T_HM ? p1 : type == T_HL ? 2 * p1 : type == T_MH ? PS - p1 : 2 * PS - 2 * p1; };
+    auto lda = [&](bf16x8 (&dst)[8], const unsigned char* st, int type, int i0, int i1) {
+        const int pl = plane_of(type);
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+            if (i < RT) dst[i] = *reinterpret_cast<const bf16x8*>(st + a_uni + ((i & 1) ? abase_o : abase_e) + pl + i * 512);
+    };
+    auto ldb = [&](bf16x8 (&dst)[8], const unsigned char* st, int type, int j0, int j1) {
+        const int pl = plane_of(type);
+#pragma unroll
+        for (int j = j0; j < j1; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(st + b_uni + ((j & 1) ? base_o : base_e) + pl + j * 512);
+    };
+
+    // DMA pieces as in the 8-wave kernel: piece P = 12 wave + r of 48; P < 24: A plane P / 8, rows 32 (P % 8) ..; else the same over W
+    const unsigned char* rbase[PPW];
+    int rdst[PPW];
+#pragma unroll
+    for (int r = 0; r < PPW; ++r) {
+        const int P = wave * PPW + r, isw = P >= 24, pq = isw ? P - 24 : P, pl = pq >> 3, q = pq & 7;
+        rdst[r] = (isw ? 3 * PS : 0) + pl * PS + q * 1024;
+        if (!isw) {
+            const int64_t grow = (int64_t)bm * BM + 32 * q;
+            int64_t grp = grow >> 7;
+            grp = grp < nrtA ? grp : nrtA - 1;
+            rbase[r] = g.A + grp * nk * S3_CHUNK + pl * S3_PLANE + (int)((grow >> 5) & 3) * 1024;
+        } else {
+            rbase[r] = g.W + (int64_t)(bn * 2 + (q >> 2)) * nk * S3_CHUNK + pl * S3_PLANE + (q & 3) * 1024;
+        }
+    }
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto issue_piece = [&](int i, int kt, int buf) {
+        __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(rbase[i] + (int64_t)kt * S3_CHUNK + lane16), AVD_LDS_PTR(smem3 + (buf * STAGE + rdst[i])), 16, 0, 0);
+    };
+
+    // The MFMAs of this kernel are asm statements whose accumulator operand is tied to an AGPR ("+a"): left to itself the compiler keeps
+    // the 256 accumulator registers in VGPRs and uses the AGPR half of the wave's 512 registers as spill space (two v_accvgpr moves per
+    // accumulator register per MFMA).  A tile is touched again 63 MFMAs later, fragments are written by ds_read only (the compiler's
+    // s_waitcnt covers asm operands), and the epilogue's first accumulator read sits behind explicit s_nops.
+    f32x4t acc[2][8][4];          // [64-column half][row tile][column tile]
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4t{0.f, 0.f, 0.f, 0.f};
+    // transposed accumulators (W fragment as the MFMA's first operand): the image epilogues want one output row per lane
+    auto mm = [&](const bf16x8 (&A_)[8], const bf16x8 (&B_)[8], int i0, int i1) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i)
+            if (i < RT) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j >> 2][i][j & 3]) : "v"(B_[j]), "v"(A_[i]));
+            }
+    };
+
+#pragma unroll
+    for (int t = 0; t < NST - 1; ++t)
+        if (t < nk) {
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) issue_piece(i, t, t);
+        }
+    int st_cur = 0, st_fill = NST - 1;
+#define S3_SB() __builtin_amdgcn_sched_barrier(0)
+    bf16x8 ahl[8], ahm[8], bset0[8], bset1[8];
+    // step kt: bp = [l|h] of W, read a step ago; bq is free.  Groups of 8 MFMAs (one row tile x 8 column tiles); behind each group a
+    // DMA piece and / or two or three fragment reads
+    auto step = [&](auto main_tag, int kt, bf16x8 (&bp)[8], bf16x8 (&bq)[8]) {
+        constexpr bool MAIN = decltype(main_tag)::value;      // main loop: tile kt + 2 exists, its DMA is unconditional
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // tile kt + 1 has landed, tile kt - 1 is no longer read
+        const unsigned char* st = smem3 + st_cur * STAGE;
+        const int dbuf = st_fill;
+        st_cur = st_cur + 1 == NST ? 0 : st_cur + 1;
+        st_fill = st_fill + 1 == NST ? 0 : st_fill + 1;
+        const unsigned char* stn = smem3 + st_cur * STAGE;           // stage of tile kt + 1
+        const bool more = MAIN || kt + NST - 1 < nk;
+        auto slot = [&](int s) {
+#ifndef AVD_LAB_NODMA
+            if (s < PPW) {
+                if (MAIN || more) { S3_SB(); issue_piece(s, kt + NST - 1, dbuf); S3_SB(); }
+            }
+#endif
+        };
+        S3_SB();
+        // hl + lh on fragments read during the previous step; meanwhile [m|h] of W and [h|m] of A arrive
+        mm(ahl, bp, 0, 1); slot(0); ldb(bq, st, T_MH, 0, 4); lda(ahm, st, T_HM, 0, 1); S3_SB();
+        mm(ahl, bp, 1, 2); slot(1); ldb(bq, st, T_MH, 4, 8); lda(ahm, st, T_HM, 1, 2); S3_SB();
+        mm(ahl, bp, 2, 3); slot(2); lda(ahm, st, T_HM, 2, 4); S3_SB();
+        mm(ahl, bp, 3, 4); slot(3); lda(ahm, st, T_HM, 4, 5); S3_SB();
+        mm(ahl, bp, 4, 5); slot(4); lda(ahm, st, T_HM, 5, 6); S3_SB();
+        mm(ahl, bp, 5, 6); slot(5); lda(ahm, st, T_HM, 6, 7); S3_SB();
+        mm(ahl, bp, 6, 7); slot(6); lda(ahm, st, T_HM, 7, 8); S3_SB();
+        mm(ahl, bp, 7, 8); slot(7); S3_SB();
+        // hm + mh; [h|m] of W goes into the dead [l|h] registers, the next tile's [h|l] of A into the dead [h|l] registers
+        mm(ahm, bq, 0, 1); slot(8); ldb(bp, st, T_HM, 0, 4); S3_SB();
+        mm(ahm, bq, 1, 2); slot(9); ldb(bp, st, T_HM, 4, 8); S3_SB();
+        mm(ahm, bq, 2, 3); slot(10); lda(ahl, stn, T_HL, 0, 2); S3_SB();
+        mm(ahm, bq, 3, 4); slot(11); lda(ahl, stn, T_HL, 2, 4); S3_SB();
+        mm(ahm, bq, 4, 5); lda(ahl, stn, T_HL, 4, 6); S3_SB();
+        mm(ahm, bq, 5, 6); lda(ahl, stn, T_HL, 6, 8); S3_SB();
+        mm(ahm, bq, 6, 7); S3_SB();
+        mm(ahm, bq, 7, 8); S3_SB();
+        // hh + mm; the next tile's [l|h] of W into the dead [m|h] registers
+        mm(ahm, bp, 0, 1); ldb(bq, stn, T_LH, 0, 4); S3_SB();
+        mm(ahm, bp, 1, 2); ldb(bq, stn, T_LH, 4, 8); S3_SB();
+        mm(ahm, bp, 2, 3); S3_SB();
+        mm(ahm, bp, 3, 4); S3_SB();
+        mm(ahm, bp, 4, 5); S3_SB();
+        mm(ahm, bp, 5, 6); S3_SB();
+        mm(ahm, bp, 6, 7); S3_SB();
+        mm(ahm, bp, 7, 8); S3_SB();
+    };
+    [[maybe_unused]] const unsigned long long t_loop = S3_T();
+    {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // tiles 0 and 1 landed
+        lda(ahl, smem3, T_HL, 0, 8);
+        ldb(bset0, smem3, T_LH, 0, 8);
+        using MainT = std::integral_constant<bool, true>;
+        using TailT = std::integral_constant<bool, false>;
+        int kt = 0;
+        for (; kt + 3 < nk; kt += 2) {
+            step(MainT{}, kt, bset0, bset1);
+            step(MainT{}, kt + 1, bset1, bset0);
+        }
+        for (; kt + 1 < nk; kt += 2) {
+            step(TailT{}, kt, bset0, bset1);
+            step(TailT{}, kt + 1, bset1, bset0);
+        }
+        if (kt < nk) step(TailT{}, kt, bset0, bset1);
+    }
+#undef S3_SB
+    [[maybe_unused]] const unsigned long long t_end = S3_T();
+    int lane_e = lane;
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(lane_e));      // the last MFMAs have written their AGPRs before the epilogue reads them
+    s3_epilogue_img16<EPI, RT>(g, acc[0], (int64_t)bm * BM + wm * WM, bn * BN + wn * 128, lane_e);
+    s3_epilogue_img16<EPI, RT>(g, acc[1], (int64_t)bm * BM + wm * WM, bn * BN + wn * 128 + 64, lane_e);
 #ifdef AVD_S3_STAMPS
     const unsigned long long t_issued = S3_T();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1454,16 +1652,54 @@ static int launch_s3w16(S3Args g, hipStream_t st) {
     return AVD_OK;
 }
 
+// 4 waves with a 128 x 128 wave tile (gemm_bf16x3_w128_kernel) in place of the 8-wave blocks of the image epilogues (by default that is the
+// residual + image epilogue of out_proj / fc2: 190 -> 180 us per launch at C3; fc1 / in_proj keep two 4-wave blocks per CU — with one
+// wave per SIMD nothing runs beside their GELU / split epilogue: 389 against 292 us).  avd_tune_set "s3_w128" 0 takes the 8-wave kernel.
+int g_s3_w128 = getenv("AVD_S3_W128") ? atoi(getenv("AVD_S3_W128")) : 1;
+template <int EPI, int RT>
+static int launch_s3w128(S3Args g, hipStream_t st) {
+    constexpr int BM = 32 * RT, LDS = 3 * 6 * 256 * 32;
+    static LdsAttr attr;
+    auto kern = gemm_bf16x3_w128_kernel<EPI, RT>;
+    if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), LDS, "gemm_bf16x3 (128x128 wave tile)")) return rc;
+#ifdef AVD_S3_STAMPS
+    g.dbg = g_s3_dbg;
+#endif
+    g.nbn = g.N / 256;
+    int sn = 8;
+    while (g.nbn % sn) sn >>= 1;
+    g.sn = sn;
+    g.sm = 16 / sn > 0 ? 16 / sn : 1;
+    const int64_t nbm = (g.M + BM - 1) / BM;
+    const int64_t nwg = (nbm + g.sm - 1) / g.sm * g.sm * g.nbn;
+    AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
+    g.stagger = 0;
+    g.first_gen = 0;
+    static const int tag = prof_tag_id("gemm_bf16x3_w128_kernel<%d, %d>", EPI, RT);
+    ProfScope prof(tag, 2.0 * (double)g.M * g.N * g.K, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), LDS, st, g);
+    AVD_CHECK_LAUNCH("gemm_bf16x3 (128x128 wave tile)");
+    return AVD_OK;
+}
+
 template <int EPI, int TERMS>
 static int launch_s3t(const S3Args& a, hipStream_t st) {
     if constexpr (TERMS == 6 && EPI != S3_EPI_RES_NORM) {
         if (g_s3_m16) {
             if (s3_tile_for(EPI, a.M, a.N)) return launch_s3w16<EPI, 4>(a, st);
+            constexpr bool TR = EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG;
+            bool rt7 = false;
             if constexpr (EPI == S3_EPI_RES_IMG) {
                 // 224-row blocks when they need fewer generations of blocks x rows than 256-row blocks (one block per CU)
                 const int64_t cu = s3_cu_count() > 0 ? s3_cu_count() : 256, nbn = a.N / 256;
                 const int64_t g8 = ((a.M + 255) / 256 * nbn + cu - 1) / cu * 8, g7 = ((a.M + 223) / 224 * nbn + cu - 1) / cu * 7;
-                if (g_s3_rt == 7 || (g_s3_rt != 8 && g7 < g8)) return launch_s3w16<EPI, 8, 7>(a, st);
+                rt7 = g_s3_rt == 7 || (g_s3_rt != 8 && g7 < g8);
+            }
+            if constexpr (TR) {
+                if (g_s3_w128) return rt7 ? launch_s3w128<EPI, 7>(a, st) : launch_s3w128<EPI, 8>(a, st);
+            }
+            if constexpr (EPI == S3_EPI_RES_IMG) {
+                if (rt7) return launch_s3w16<EPI, 8, 7>(a, st);
             }
             return launch_s3w16<EPI, 8>(a, st);
         }

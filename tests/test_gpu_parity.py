@@ -13,6 +13,7 @@ from oracle import ref_cpu as R
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
+W128_DEFAULT = 1      # library default of the "s3_w128" tune key
 
 
 @pytest.fixture(scope="module")
@@ -1329,20 +1330,26 @@ def test_split_gemm_block_rows_agree(dev, full, B):
     tn = torch.tensor(([982, 500, 16, 999] * B)[:B])
     tp = torch.tensor(([966, 480, -1, 979] * B)[:B])
     outs = {}
-    for rt in (7, 8, 0):
+    for rt, w128 in ((7, 0), (8, 0), (0, 0), (7, 1), (8, 1)):
         _tune("s3_rt", rt)
+        _tune("s3_w128", w128)
         _tune("s3_tile", 0 if B < 32 else -1)
         try:
             eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z_v.shape),
                                   prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul="bf16x3")
             eng.set_prompt(z_a.to(dev))
-            outs[rt] = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)).cpu()
+            outs[rt, w128] = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)).cpu()
         finally:
             _tune("s3_rt", 0)
+            _tune("s3_w128", W128_DEFAULT)
             _tune("s3_tile", -1)
-    assert torch.isfinite(outs[7]).all()
-    assert torch.equal(outs[7], outs[8])
-    assert torch.equal(outs[0], outs[8])
+    assert torch.isfinite(outs[7, 0]).all()
+    assert torch.equal(outs[7, 0], outs[8, 0])
+    assert torch.equal(outs[0, 0], outs[8, 0])
+    # the 4-wave kernel with a 128 x 128 wave tile (avd_tune_set "s3_w128") issues the same MFMA sequence per output element
+    assert torch.equal(outs[7, 1], outs[8, 0])
+    assert torch.equal(outs[8, 1], outs[8, 0])
+    outs = {7: outs[7, 0]}
     ref = R.denoise_step_a2v(z_v[:1], z_a[:1], tn[:1], tp[:1], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"], core=ws["core"],
                              head=ws["head"], n_layers=8, n_heads=8, guidance=3.5)
     assert rel_err(outs[7][:1], ref) < TOL
