@@ -464,58 +464,52 @@ __device__ __forceinline__ void s3_epilogue_img(const S3Args& g, f32x16 (&acc)[4
 // then waves 0..7).  Pass 2: scale * v / (sqrt(ss) / sqrt(d) + eps), the expression rmsnorm_split3_kernel evaluates, split and stored
 // as the image.  `red` = 8 x 128 floats overlaying the stages.
 template <bool F16>
-__device__ __forceinline__ void s3_epilogue_rownorm(const S3Args& g, f32x16 (&acc)[4][2], int64_t mblock0, int wave, int lane, float* red) {
+__device__ __forceinline__ void rown_pass1(const S3Args& g, f32x16 (&acc)[4][2], int64_t mblock0, int nbase, int lane, float (&ssq)[4]) {
     const int l31 = lane & 31, hi = lane >> 5;
-    const int nbase = wave * 64;
-    float ssq[4] = {0.f, 0.f, 0.f, 0.f};
-    {
-        float bv[2][2][8];
+    float bv[2][2][8];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int cg = 0; cg < 2; ++cg) {
+            const float* bp = g.bias + nbase + 32 * j + 8 * (2 * cg + hi);
+            *reinterpret_cast<f32x4*>(bv[j][cg]) = *reinterpret_cast<const f32x4*>(bp);
+            *reinterpret_cast<f32x4*>(bv[j][cg] + 4) = *reinterpret_cast<const f32x4*>(bp + 4);
+        }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t m = mblock0 + 32 * i + l31;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int cg = 0; cg < 2; ++cg) {
-                const float* bp = g.bias + nbase + 32 * j + 8 * (2 * cg + hi);
-                *reinterpret_cast<f32x4*>(bv[j][cg]) = *reinterpret_cast<const f32x4*>(bp);
-                *reinterpret_cast<f32x4*>(bv[j][cg] + 4) = *reinterpret_cast<const f32x4*>(bp + 4);
-            }
+                float v[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t m = mblock0 + 32 * i + l31;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int cg = 0; cg < 2; ++cg) {
-                    float v[8];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * cg + e]), __float_as_uint(acc[i][j][8 * cg + 4 + e]),
-                                                                         false, false);
-                        v[e] = __uint_as_float(sw[0]);
-                        v[4 + e] = __uint_as_float(sw[1]);
-                    }
-                    const int n = nbase + 32 * j + 8 * (2 * cg + hi);
-                    if (m < g.M) {
-                        const float* rp = g.R + m * g.N + n;
-                        const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = ((F16 ? v[e] * g.ab_inv : v[e]) + bv[j][cg][e]) + (e < 4 ? r0[e] : r1[e - 4]);
-                        float* cp = g.C + m * g.N + n;
-                        *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
-                        *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
-                        ssq[i] += ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
-                    }
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[i][j][8 * cg + e] = v[e];       // this lane's 8 consecutive columns of row m
+                for (int e = 0; e < 4; ++e) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc[i][j][8 * cg + e]), __float_as_uint(acc[i][j][8 * cg + 4 + e]),
+                                                                     false, false);
+                    v[e] = __uint_as_float(sw[0]);
+                    v[4 + e] = __uint_as_float(sw[1]);
                 }
-        }
-    }
-    __syncthreads();          // every wave is past its last fragment read: the stages may be overwritten
+                const int n = nbase + 32 * j + 8 * (2 * cg + hi);
+                if (m < g.M) {
+                    const float* rp = g.R + m * g.N + n;
+                    const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float tot = ssq[i] + __shfl_xor(ssq[i], 32, 64);
-        if (hi == 0) red[wave * 128 + 32 * i + l31] = tot;
+                    for (int e = 0; e < 8; ++e) v[e] = ((F16 ? v[e] * g.ab_inv : v[e]) + bv[j][cg][e]) + (e < 4 ? r0[e] : r1[e - 4]);
+                    float* cp = g.C + m * g.N + n;
+                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
+                    ssq[i] += ((v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3])) + ((v[4] * v[4] + v[5] * v[5]) + (v[6] * v[6] + v[7] * v[7]));
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[i][j][8 * cg + e] = v[e];       // this lane's 8 consecutive columns of row m
+            }
     }
-    __syncthreads();
+}
+
+template <bool F16>
+__device__ __forceinline__ void rown_pass2(const S3Args& g, f32x16 (&acc)[4][2], int64_t mblock0, int nbase, int lane, const float (&den)[4]) {
+    const int l31 = lane & 31, hi = lane >> 5;
     float gv[2][2][8];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -528,10 +522,6 @@ __device__ __forceinline__ void s3_epilogue_rownorm(const S3Args& g, f32x16 (&ac
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int64_t m = mblock0 + 32 * i + l31;
-        float ss = 0.f;
-#pragma unroll
-        for (int w8 = 0; w8 < 8; ++w8) ss += red[w8 * 128 + 32 * i + l31];
-        const float den = sqrtf(ss) / g.ss_sqrt_d + g.ss_eps;
         if (m < g.M) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -539,13 +529,44 @@ __device__ __forceinline__ void s3_epilogue_rownorm(const S3Args& g, f32x16 (&ac
                 for (int cg = 0; cg < 2; ++cg) {
                     float v[8];
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = gv[j][cg][e] * acc[i][j][8 * cg + e] / den;
+                    for (int e = 0; e < 8; ++e) v[e] = gv[j][cg][e] * acc[i][j][8 * cg + e] / den[i];
                     const int n = nbase + 32 * j + 8 * (2 * cg + hi);
                     if constexpr (F16) store_split8_h2(g.C3, m, n, g.N, v, g.c_scale);
                     else store_split8<true>(g.C3, m, n, g.N, v);
                 }
         }
     }
+}
+
+// rows' sums of squares: lane halves, then the eight 64-column parts of the row in part order (red = 8 x 128 floats)
+__device__ __forceinline__ void rown_publish(const float (&ssq)[4], int part, int lane, float* red) {
+    const int l31 = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float tot = ssq[i] + __shfl_xor(ssq[i], 32, 64);
+        if (hi == 0) red[part * 128 + 32 * i + l31] = tot;
+    }
+}
+__device__ __forceinline__ void rown_den(const S3Args& g, int lane, const float* red, float (&den)[4]) {
+    const int l31 = lane & 31;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float ss = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < 8; ++w8) ss += red[w8 * 128 + 32 * i + l31];
+        den[i] = sqrtf(ss) / g.ss_sqrt_d + g.ss_eps;
+    }
+}
+
+template <bool F16>
+__device__ __forceinline__ void s3_epilogue_rownorm(const S3Args& g, f32x16 (&acc)[4][2], int64_t mblock0, int wave, int lane, float* red) {
+    float ssq[4] = {0.f, 0.f, 0.f, 0.f}, den[4];
+    rown_pass1<F16>(g, acc, mblock0, wave * 64, lane, ssq);
+    __syncthreads();          // every wave is past its last fragment read: the stages may be overwritten
+    rown_publish(ssq, wave, lane, red);
+    __syncthreads();
+    rown_den(g, lane, red, den);
+    rown_pass2<F16>(g, acc, mblock0, wave * 64, lane, den);
 }
 
 // wait until at most `tiles` x STEP of this wave's DMA pieces are still in flight (tiles is wave-uniform; capped at MAXN, < 0 = 0)
@@ -1450,6 +1471,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16x3_w128_kernel(S3Args g) {
     S3_DBG(8, (unsigned long long)nk); S3_DBG(9, S3_RT()); S3_DBG(10, rt_entry);
 #endif
 }
+
+// (The f16x2 row-owner GEMM — EPI_RES_NORM — was built in the same shape too: four waves side by side over the 128 x 512 block, 4 x 4
+// tiles of v_mfma_f32_32x32x16_f16 in AGPRs, 16 fragment reads per 48 MFMAs instead of 12 per 24.  Bit-identical and slower: 155 us
+// against 136 us per launch, 164.9 against 176.3 steps/s.  An f16x2 step is 1,536 matrix-pipe cycles per wave, half of bf16x3's, so the
+// per-step barrier and the epilogue's memory latency — which a second wave on the SIMD hides — weigh twice as much.  Removed.)
 
 // ---------------------------------------------------------------------------------------------------------
 // host side
