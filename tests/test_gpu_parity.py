@@ -1313,18 +1313,18 @@ def test_attention_key_padding_mask(dev):
                        Fn.attention(qkv.to(dev), H))
 
 
-@pytest.mark.parametrize("B", [32, 5])
-def test_split_gemm_block_rows_agree(dev, full, B):
+@pytest.mark.parametrize("size,B", [(256, 32), (256, 5), (512, 8)])
+def test_split_gemm_block_rows_agree(dev, full, size, B):
     """bf16x3 out_proj / fc2 (residual + image + row sums epilogue, 8 waves): the 224-row blocks the host picks when they fit one
     generation of blocks on the CUs (avd_tune_set "s3_rt" 0 / 7 / 8) read the operand images at row offsets that are multiples of
     32, not of 128, and leave the last row tile of each wave pair dead — same MFMA sequence per output element, so a whole CFG step is
     bit-identical with 256-row blocks.  B = 32: the bench shape (26,944 rows, last block past the last 128-row group);
-    B = 5: 4,210 rows with the 8-wave blocks forced (18.8 blocks of 224 rows)."""
+    B = 5: 4,210 rows with the 8-wave blocks forced (18.8 blocks of 224 rows); 512x512, B = 8: the C5 geometry (25,168 rows, 1,573 tokens)."""
     import multimodal_diffusion_amd as A
     ws, mods = full
     core, head, av, aa = mods
     g = torch.Generator().manual_seed(77 + B)
-    z_v = torch.randn(B, 8, 12, 32, 32, generator=g)
+    z_v = torch.randn(B, 8, 12, size // 8, size // 8, generator=g)
     z_a = torch.randn(B, 8, 150, generator=g)
     abar = R.alpha_bar_table(R.beta_table(1000))
     tn = torch.tensor(([982, 500, 16, 999] * B)[:B])
@@ -1333,7 +1333,7 @@ def test_split_gemm_block_rows_agree(dev, full, B):
     for rt, w128 in ((7, 0), (8, 0), (0, 0), (7, 1), (8, 1)):
         _tune("s3_rt", rt)
         _tune("s3_w128", w128)
-        _tune("s3_tile", 0 if B < 32 else -1)
+        _tune("s3_tile", 0 if B == 5 else -1)
         try:
             eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z_v.shape),
                                   prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul="bf16x3")
