@@ -293,6 +293,8 @@ bool gemm_bf16x3_rownorm_supported(int N, int terms);
 extern int g_s3_splitk;          // slices tried (0 off; avd_tune_set "s3_splitk")
 int gemm_bf16x3_splitk_slices(int64_t M, int N, int K, int terms);
 int64_t gemm_bf16x3_splitk_ws_floats(int64_t M, int N, int ns);
+constexpr int kS3SplitKMax = 8;  // upper bound of "s3_splitk" (workspaces are sized for it)
+int64_t gemm_bf16x3_splitk_ws_max_floats(int64_t M, int N, int K);
 int gemm_bf16x3_splitk(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, float* ss, int64_t M, int N,
                        int K, int terms, int ns, float* part, hipStream_t st);
 

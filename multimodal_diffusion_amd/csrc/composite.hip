@@ -88,9 +88,11 @@ static inline int64_t align_up(int64_t x) { return (x + 255) & ~(int64_t)255; }
 struct Carver {
     char* base;
     int64_t used, cap;
+    bool ok = true;       // false once a take() went past the capacity: the caller checks before it launches anything
     float* take(int64_t floats) {
         float* p = reinterpret_cast<float*>(base + used);
         used += align_up(floats * (int64_t)sizeof(float));
+        if (used > cap) ok = false;
         return p;
     }
 };
@@ -102,9 +104,9 @@ constexpr int64_t kSplitMinRows = 6144;    // 128x128 geometry at B=32 (8,512 ro
 static int64_t g_s3_min_rows = [] { const char* e = getenv("AVD_S3_MIN_ROWS"); return e ? (int64_t)atoll(e) : kSplitMinRows; }();
 static bool g_no_fold = getenv("AVD_NO_FOLD") != nullptr;
 static int64_t split_min_rows() { return g_s3_min_rows; }      // avd_tune_set "s3_min_rows": measurement aid
-static bool core_use_split(const avd_core_weights* w, int64_t M) {
-    // (the reduced-precision one-term mode is an explicit request, not a speed heuristic: it takes the split kernels at any size)
-    if ((M < split_min_rows() && w->split_terms != 1 && w->attn_mode != 1) || w->norm_kind != 0) return false;
+// what the weights and shapes allow, whatever the process-wide tunables say (workspace sizing: core_ws_bytes)
+static bool core_split_capable(const avd_core_weights* w, int64_t M) {
+    if (w->norm_kind != 0) return false;
     if (!gemm_bf16x3_supported(M, 3 * w->d, w->d) || !gemm_bf16x3_supported(M, w->d, w->d) ||
         !gemm_bf16x3_supported(M, w->mlp_hidden, w->d) || !gemm_bf16x3_supported(M, w->d, w->mlp_hidden))
         return false;
@@ -114,20 +116,27 @@ static bool core_use_split(const avd_core_weights* w, int64_t M) {
     }
     return true;
 }
+static bool core_use_split(const avd_core_weights* w, int64_t M) {
+    // (the reduced-precision one-term mode is an explicit request, not a speed heuristic: it takes the split kernels at any size)
+    if (M < split_min_rows() && w->split_terms != 1 && w->attn_mode != 1) return false;
+    return core_split_capable(w, M);
+}
 
 // split path with RMSNorm folded into its neighbours (bf16 planes only: the un-normalised residual stream has no bound an fp16 image
 // could be scaled by): needs the scale-carrying weight images and 64-column chunks for the sums of squares
-static bool core_use_split_fold(const avd_core_weights* w) {
-    if (g_no_fold || w->norm_kind != 0 || w->split_terms == 3 || w->d % 64 != 0) return false;
+static bool core_split_fold_capable(const avd_core_weights* w) {
+    if (w->norm_kind != 0 || w->split_terms == 3 || w->d % 64 != 0) return false;
     for (int l = 0; l < w->n_layers; ++l)
         if (!w->blocks[l].in_proj_weight3n || !w->blocks[l].fc1_weight3n) return false;
     return true;
 }
+static bool core_use_split_fold(const avd_core_weights* w) { return !g_no_fold && core_split_fold_capable(w); }
 
 // f16x2 path with the norms that follow a residual add finished inside that GEMM's epilogue (blocks that own whole rows)
-static bool core_use_split_rownorm(const avd_core_weights* w) {
-    return !g_no_fold && w->norm_kind == 0 && w->split_terms == 3 && gemm_bf16x3_rownorm_supported(w->d, 3);
+static bool core_split_rownorm_capable(const avd_core_weights* w) {
+    return w->norm_kind == 0 && w->split_terms == 3 && gemm_bf16x3_rownorm_supported(w->d, 3);
 }
+static bool core_use_split_rownorm(const avd_core_weights* w) { return !g_no_fold && core_split_rownorm_capable(w); }
 
 // fp32 path with RMSNorm folded into the neighbouring GEMM epilogues: needs the scale-carrying weights and LDS-DMA-able shapes
 static bool core_use_fold(const avd_core_weights* w) {
@@ -146,21 +155,23 @@ static int64_t core_split_wide_bytes(const avd_core_weights* w, int B, int N) {
     return qkv3 > fc1 ? qkv3 : fc1;
 }
 
+// The requirement is the maximum over every variant the process-wide tunables (avd_tune_set: no_fold, s3_splitk, s3_m16, s3_min_rows)
+// can select for these weights, so a workspace sized once (DenoiseEngine._bind_weights) stays large enough when a tunable is flipped
+// afterwards — tests and tools do that between steps, also inside a graph capture.
 static int64_t core_ws_bytes(const avd_core_weights* w, int B, int N) {
     const int64_t M = (int64_t)B * N;
     const int wide = 3 * w->d > w->mlp_hidden ? 3 * w->d : w->mlp_hidden;
     int64_t fp32_path = align_up(M * w->d * 4) + align_up(M * wide * 4) + 2 * align_up(M * (w->d / 32 + 1) * 4);
-    if (!core_use_split(w, M)) return fp32_path;
+    if (!core_split_capable(w, M)) return fp32_path;
     // + split3 image of the norm / attention output, and the wide buffer must also hold the split3 image of the MLP hidden
     const int64_t wide_b = core_split_wide_bytes(w, B, N);
     // third region: (attn_mode 1) the fp8 attention's operand images
     const int64_t f8_b = w->attn_mode == 1 ? attn_fp8_ws_bytes(B, N, w->n_heads) : 0;
     // folded norms: a second [M][d] image (the residual stream's) and the table of its rows' sums of squares
-    const int64_t fold_b = core_use_split_fold(w) ? align_up(split3_bytes(M, w->d)) + align_up(M * (w->d / 64) * 4)
-                         : core_use_split_rownorm(w) ? align_up(split3_bytes(M, w->d)) : 0;        // the normalised stream's image
-    // split-K partial sums of fc2 for batches that cannot fill the chip (folded bf16-plane path only)
-    const int ns = core_use_split_fold(w) ? gemm_bf16x3_splitk_slices(M, w->d, w->mlp_hidden, w->split_terms) : 0;
-    const int64_t sk_b = ns ? align_up(gemm_bf16x3_splitk_ws_floats(M, w->d, ns) * 4) : 0;
+    const int64_t fold_b = core_split_fold_capable(w) ? align_up(split3_bytes(M, w->d)) + align_up(M * (w->d / 64) * 4)
+                         : core_split_rownorm_capable(w) ? align_up(split3_bytes(M, w->d)) : 0;        // the normalised stream's image
+    // split-K partial sums of fc2 for batches that cannot fill the chip (folded bf16-plane path only), at the largest slice count
+    const int64_t sk_b = core_split_fold_capable(w) ? align_up(gemm_bf16x3_splitk_ws_max_floats(M, w->d, w->mlp_hidden) * 4) : 0;
     const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d)) + align_up(f8_b) + fold_b + sk_b;
     return split_path > fp32_path ? split_path : fp32_path;
 }
@@ -214,6 +225,9 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
     // explicit reduced-precision request and is refused rather than silently replaced.
     AVD_REQUIRE(!(w->attn_mode == 1 && (kpm || w->norm_kind != 0)), AVD_EUNSUPPORTED,
                 "core: attn_mode 1 (fp8 attention) cannot be combined with a key_padding_mask or norm_kind 1 (LayerNorm)");
+    AVD_REQUIRE(!(w->attn_mode == 1 && !core_use_split(w, M)), AVD_EUNSUPPORTED,
+                "core: attn_mode 1 (fp8 attention) reads the q|k|v image of the split-operand projections, which these weights / shapes "
+                "do not take (every block needs its *_weight3 images; 3 d, d and mlp_hidden must be multiples of 256, d of 16)");
     if (!kpm && core_use_split(w, M)) {
         // same op sequence with the four projections on the bf16 matrix pipe (gemm_bf16x3.hip); hs / wide3 are split3 images
         const int terms = w->split_terms;
@@ -232,6 +246,7 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
             float* ss = cs.take(M * (d / 64));                           // its rows' sums of squares, [M][d / 64]
             const int ns = gemm_bf16x3_splitk_slices(M, d, hid, terms);
             float* part = ns ? cs.take(gemm_bf16x3_splitk_ws_floats(M, d, ns)) : nullptr;
+            AVD_REQUIRE(cs.ok, AVD_EWORKSPACE, "core: workspace carve %lld > %lld bytes", (long long)cs.used, (long long)cs.cap);
             if (int rc = split3_rows_f32(cur, rd, hx, M, d, st, 0.f, ss)) return rc;
             for (int l = 0; l < w->n_layers; ++l) {
                 const avd_block_weights& b = w->blocks[l];
@@ -265,6 +280,7 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
         // norm kernel left before the final norm is the first block's norm1
         const bool rown = core_use_split_rownorm(w);
         void* hn = rown ? cs.take((split3_bytes(M, d) + 3) / 4) : hs;      // image of the normalised stream (hs: attention output)
+        AVD_REQUIRE(cs.ok, AVD_EWORKSPACE, "core: workspace carve %lld > %lld bytes", (long long)cs.used, (long long)cs.cap);
         for (int l = 0; l < w->n_layers; ++l) {
             const avd_block_weights& b = w->blocks[l];
             const bool last = l == w->n_layers - 1;
@@ -313,6 +329,7 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
         // in_proj / fc1 GEMMs run on the un-normalised stream with scale-carrying weights and multiply their rows by 1/rms
         float* ssA = cv.take(M * (d / 32 + 1));     // sums of squares of the stream entering norm1
         float* ssB = cv.take(M * (d / 32 + 1));     // ... entering norm2
+        AVD_REQUIRE(cv.ok, AVD_EWORKSPACE, "core: workspace carve %lld > %lld bytes", (long long)cv.used, (long long)cv.cap);
         const float sqrt_d = (float)sqrt((double)d);
         const float* ssA_in = ss_first;                // the front end may already have the rows' sums of squares
         if (!ssA_in) {
@@ -357,8 +374,8 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
 
 // ---------------------------------------------------------------- MultiModalNoiseHead (one modality path)
 // split-operand mode of the head (gemm_bf16x3.hip): all four kinds of Linear must fit the 256-column tiles
-static bool head_use_split(const avd_head_weights* w, int64_t rows) {
-    if (w->split_terms == 0 || rows < split_min_rows()) return false;
+static bool head_split_capable(const avd_head_weights* w, int64_t rows) {
+    if (w->split_terms == 0) return false;
     if (!w->input_proj_weight3 || !w->out_proj_weight3 || (w->n_shared > 0 && !w->shared_lin_weight3)) return false;
     for (int j = 0; j < w->n_shared; ++j)
         if (!w->shared_lin_weight3[j]) return false;
@@ -366,10 +383,11 @@ static bool head_use_split(const avd_head_weights* w, int64_t rows) {
     return gemm_bf16x3_supported(rows, w->hidden, w->d_in) && gemm_bf16x3_supported(rows, w->hidden, w->hidden) &&
            gemm_bf16x3_supported(rows, w->d_out, w->hidden);
 }
+static bool head_use_split(const avd_head_weights* w, int64_t rows) { return rows >= split_min_rows() && head_split_capable(w, rows); }
 
 static int64_t head_ws_bytes(const avd_head_weights* w, int64_t rows) {
     const int64_t fp32_path = 2 * align_up(rows * w->hidden * 4);
-    if (!head_use_split(w, rows)) return fp32_path;
+    if (!head_split_capable(w, rows)) return fp32_path;      // sized for either path: "s3_min_rows" may move between calls
     const int wide = w->d_in > w->hidden ? w->d_in : w->hidden;
     const int64_t split_path = 2 * align_up(split3_bytes(rows, wide)) + align_up(rows * w->hidden * 4);
     return split_path > fp32_path ? split_path : fp32_path;
@@ -558,7 +576,11 @@ extern "C" int avd_tune_set(const char* key, int64_t value) {
     if (!strcmp(key, "s3_m16")) { g_s3_m16 = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_rt")) { g_s3_rt = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_w128")) { g_s3_w128 = (int)value; return AVD_OK; }
-    if (!strcmp(key, "s3_splitk")) { g_s3_splitk = (int)value; return AVD_OK; }
+    if (!strcmp(key, "s3_splitk")) {
+        AVD_REQUIRE(value >= 0 && value <= kS3SplitKMax, AVD_EINVAL, "tune_set: s3_splitk must be in [0, %d]", kS3SplitKMax);
+        g_s3_splitk = (int)value;
+        return AVD_OK;
+    }
     if (!strcmp(key, "s3_stagger")) { g_s3_stagger = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_tile")) { g_gemm_force_tile = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_stages")) { g_gemm_stages = (int)value; return AVD_OK; }

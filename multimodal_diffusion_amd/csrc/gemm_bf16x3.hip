@@ -1372,6 +1372,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16x3_w128_kernel(S3Args g) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4t{0.f, 0.f, 0.f, 0.f};
+    // The compiler does not see an MFMA in the asm statements below, so its hazard recogniser pads neither the zero-init
+    // (v_accvgpr_write) -> first MFMA (accumulator read) pair nor the last MFMA -> epilogue (v_accvgpr_read) pair.  Both are made
+    // explicit: every tile is named as an operand of an empty statement (its init is ordered in front of it), then one s_nop
+    // statement — volatile asm statements keep their order, so the wait states sit between all the inits and the first MFMA.
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[h][i][j]));
+    asm volatile("s_nop 4");
     // transposed accumulators (W fragment as the MFMA's first operand): the image epilogues want one output row per lane
     auto mm = [&](const bf16x8 (&A_)[8], const bf16x8 (&B_)[8], int i0, int i1) {
 #pragma unroll
@@ -1460,7 +1471,15 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16x3_w128_kernel(S3Args g) {
 #undef S3_SB
     [[maybe_unused]] const unsigned long long t_end = S3_T();
     int lane_e = lane;
-    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(lane_e));      // the last MFMAs have written their AGPRs before the epilogue reads them
+    // the last MFMAs have written their AGPRs before the epilogue reads them: the wait states are one statement with the tiles of the
+    // last two MFMA groups (row tiles 6 and 7: RT = 7 blocks skip tile 7) as read-write operands, so no accumulator read of the
+    // epilogue can be scheduled in front of it (MFMAs retire in order: older tiles are complete once these are)
+    asm volatile("s_nop 15\n\ts_nop 15"
+                 : "+v"(lane_e), "+a"(acc[0][6][0]), "+a"(acc[0][6][1]), "+a"(acc[0][6][2]), "+a"(acc[0][6][3]), "+a"(acc[1][6][0]),
+                   "+a"(acc[1][6][1]), "+a"(acc[1][6][2]), "+a"(acc[1][6][3]), "+a"(acc[0][7][0]), "+a"(acc[0][7][1]), "+a"(acc[0][7][2]),
+                   "+a"(acc[0][7][3]), "+a"(acc[1][7][0]), "+a"(acc[1][7][1]), "+a"(acc[1][7][2]), "+a"(acc[1][7][3]));
+    // (row tiles 0..5 were last written >= 16 MFMAs = 256 issue cycles before the loop's final sched_barrier, above which nothing of the
+    // epilogue can be scheduled: they need no wait states.  Naming all 64 tiles here as well made the register allocator spill.)
     s3_epilogue_img16<EPI, RT>(g, acc[0], (int64_t)bm * BM + wm * WM, bn * BN + wn * 128, lane_e);
     s3_epilogue_img16<EPI, RT>(g, acc[1], (int64_t)bm * BM + wm * WM, bn * BN + wn * 128 + 64, lane_e);
 #ifdef AVD_S3_STAMPS
@@ -1831,7 +1850,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 
 // K slices for a residual GEMM of [M][N] over K, 0 = do not split: only when the 256x128 blocks cover at most half of the CUs
 // and a slice keeps >= 32 k-steps.  avd_tune_set "s3_splitk" (AVD_S3_SPLITK): 0 off, else the slice count tried (default 4).
-int g_s3_splitk = getenv("AVD_S3_SPLITK") ? atoi(getenv("AVD_S3_SPLITK")) : 4;
+int g_s3_splitk = [] { const int v = getenv("AVD_S3_SPLITK") ? atoi(getenv("AVD_S3_SPLITK")) : 4; return v < 0 ? 0 : v > kS3SplitKMax ? kS3SplitKMax : v; }();
 int gemm_bf16x3_splitk_slices(int64_t M, int N, int K, int terms) {
     const int ns = g_s3_splitk;
     if (ns < 2 || terms == 3 || ((terms == 0 || terms == 6) && g_s3_m16) || N % 128 || K % (16 * ns) || K / ns < 512) return 0;
@@ -1839,6 +1858,12 @@ int gemm_bf16x3_splitk_slices(int64_t M, int N, int K, int terms) {
     return (M + 255) / 256 * (N / 128) * 2 <= cu ? ns : 0;
 }
 int64_t gemm_bf16x3_splitk_ws_floats(int64_t M, int N, int ns) { return (int64_t)ns * M * N; }
+// the most a split-K launch of this shape can ever ask for, whatever the tunables (s3_splitk <= kS3SplitKMax, s3_m16) say: sizing only
+int64_t gemm_bf16x3_splitk_ws_max_floats(int64_t M, int N, int K) {
+    if (N % 128 || K % 32 || K / 2 < 512) return 0;
+    const int cu = s3_cu_count();
+    return (M + 255) / 256 * (N / 128) * 2 <= cu ? gemm_bf16x3_splitk_ws_floats(M, N, kS3SplitKMax) : 0;
+}
 
 // C = A W^T + bias + R (fp32), optionally C3 = operand image of C and ss = its rows' sums of squares; bf16-plane images
 int gemm_bf16x3_splitk(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, float* ss, int64_t M, int N,

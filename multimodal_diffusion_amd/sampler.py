@@ -102,16 +102,19 @@ def tokens_to_latents_audio(tokens: torch.Tensor, Ca: int, l_chunk: int, Fa: int
 
 class _CapturedPair:
     """A captured two-step HIP graph of one engine.  ``replay()`` first re-checks the engine's weight tables: parameters updated in
-    place behind unchanged pointers are picked up (derived images are refreshed in place), a re-allocated parameter or a changed
-    by-value scale raises instead of replaying kernels that hold the old value."""
+    place behind unchanged pointers are picked up (derived images are refreshed in place).  The graph holds every device pointer
+    and every by-value scale of the tables it was captured with, so it carries the engine's table GENERATION of that moment: a
+    re-allocated parameter, workspace or prompt buffer, or a changed by-value scale, moves the engine to a new generation and every
+    pair captured before stays refused for good — also after the engine has captured again."""
 
     def __init__(self, engine: "DenoiseEngine", graph: "torch.cuda.CUDAGraph"):
-        self.engine, self.graph = engine, graph
+        self.engine, self.graph, self.generation = engine, graph, engine._generation
 
     def replay(self) -> None:
         self.engine._sync_weights()
-        if not self.engine._captured:
-            raise L.AvdError("this captured graph is stale (the engine's tables changed since capture_pair()); capture again")
+        if self.generation != self.engine._generation:
+            raise L.AvdError(f"this captured graph is stale ({self.engine._stale_reason or 'the engine tables changed'} since "
+                             "capture_pair()): replaying it would launch kernels that hold the old values; capture again")
         self.graph.replay()
 
 
@@ -184,11 +187,14 @@ class DenoiseEngine:
         if split_streams is None:
             split_streams = self.matmul == "f16x2" and B * self.N >= 6144
         self._split_streams = bool(split_streams)
-        self._captured = False
+        # generation of the pointer / scalar tables: bumped whenever something a captured HIP graph holds by value changes
+        # (see _CapturedPair); _stale_reason says what changed last
+        self._generation = 0
+        self._stale_reason = ""
         self.workspace: Optional[torch.Tensor] = None
-        self._bind_weights()
         self.Xp: Optional[torch.Tensor] = None
         self._prompt_latent: Optional[torch.Tensor] = None
+        self._bind_weights()
 
     # ---- pointer tables.  They hold derived copies (norm-folded / split3 weights), so they are re-derived whenever a
     # parameter's (address, version) changes: load_state_dict, EMA copy_to, an optimiser step or .to(device) after the
@@ -241,7 +247,7 @@ class DenoiseEngine:
 
     def _table_ptrs(self):
         return tuple(t.data_ptr() for t in self._keep_core[1]) + tuple(t.data_ptr() for t in self._keep_head[1]) + \
-            (self._aw.data_ptr(), self._ab.data_ptr())
+            (self._aw.data_ptr(), self._ab.data_ptr(), self.workspace.data_ptr(), self.alpha_bar.data_ptr())
 
     def _table_scalars(self):
         """Every BY-VALUE number of the tables: a captured HIP graph bakes these into its kernel arguments (the f16x2 image scales
@@ -263,14 +269,15 @@ class DenoiseEngine:
             return
         old, old_sc = self._ptrs, self._scalars
         self._bind_weights()             # derived copies are refreshed in place where shapes allow
-        if self._captured and self._ptrs != old:
-            raise L.AvdError("a parameter was re-allocated after a HIP graph of this engine was captured; capture again")
-        if self._captured and self._scalars != old_sc:
-            self._captured = False       # the next capture_pair() starts from the new tables
-            raise L.AvdError("an in-place parameter update changed a scale that the captured HIP graph holds by value (f16x2 image "
-                             "scales follow max|w| and the norm gains): replaying it would divide by the old scales; capture again")
+        if self._ptrs != old:
+            self._generation += 1
+            self._stale_reason = "a parameter or the workspace was re-allocated"
+        elif self._scalars != old_sc:
+            self._generation += 1
+            self._stale_reason = ("an in-place parameter update changed a scale that a captured HIP graph holds by value (f16x2 image "
+                                  "scales follow max|w| and the norm gains)")
         if self._prompt_latent is not None:
-            self.set_prompt(self._prompt_latent)     # the cached prompt rows depend on the prompt adapter
+            self.set_prompt(self._prompt_latent)     # the cached prompt rows depend on the prompt adapter (same buffer: in place)
 
     # ---- prompt rows: adapter(tokens(prompt latent)) | temb(0); constant over the trajectory ----
     def set_prompt(self, prompt_latent: torch.Tensor) -> torch.Tensor:
@@ -284,7 +291,13 @@ class DenoiseEngine:
         if tok.shape[1] != self.embed.Np:
             raise ValueError(f"prompt yields {tok.shape[1]} tokens, engine was built for {self.embed.Np}")
         d, td = self.d, self.tdim
-        Xp = torch.empty(B, tok.shape[1], d, device=self.device, dtype=torch.float32)
+        # the prompt rows keep their buffer from call to call (a captured graph holds its address); a first call, or one after the
+        # buffer was dropped, starts a new table generation
+        Xp = self.Xp
+        if Xp is None or tuple(Xp.shape) != (B, tok.shape[1], d) or Xp.device != self.device:
+            Xp = torch.empty(B, tok.shape[1], d, device=self.device, dtype=torch.float32)
+            self._generation += 1
+            self._stale_reason = "the prompt rows were (re-)allocated by set_prompt()"
         w, b = self.adapt_p.proj.weight.detach(), self.adapt_p.proj.bias.detach()
         t0 = su.timestep_embedding(torch.zeros(B, dtype=torch.long, device=self.device), td) if td else None
         if self.temb_mode == "add":
@@ -357,7 +370,6 @@ class DenoiseEngine:
         with torch.cuda.graph(g):
             self.advance(za, zb)
             self.advance(zb, za)
-        self._captured = True
         return _CapturedPair(self, g)
 
     GRAPH_BELOW_ROWS = 6144      # 2B*N under which a step's ~60-95 launches are host-bound: replay them from a HIP graph

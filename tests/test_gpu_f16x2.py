@@ -752,3 +752,39 @@ def test_captured_graph_refuses_stale_scales(dev, full):
     ref_eng.advance(c, d)
     ref_eng.advance(d, c)
     assert torch.equal(a, c)
+    # the pair invalidated above stays refused although the engine has captured again since
+    with pytest.raises(L.AvdError, match="capture again"):
+        graph.replay()
+    # a RE-ALLOCATED parameter (new storage behind the same module attribute): the graph holds the old device pointer
+    with torch.no_grad():
+        core.blocks[1].mlp.fc1.bias = torch.nn.Parameter(core.blocks[1].mlp.fc1.bias.detach().clone() + 1e-3)
+    eng.rewind()
+    a.copy_(z)
+    with pytest.raises(L.AvdError, match="capture again"):
+        graph2.replay()
+    with pytest.raises(L.AvdError, match="capture again"):
+        graph2.replay()                     # stays refused: a second replay must not slip through on the refreshed tables
+    # ... while eager steps and a fresh capture follow the new tables, and a later in-place update does not raise spuriously
+    eng.rewind()
+    a.copy_(z)
+    eng.advance(a, b)
+    eng.advance(b, a)
+    torch.cuda.synchronize()
+    eager = a.clone()
+    graph3 = eng.capture_pair(a, b)
+    eng.rewind()
+    a.copy_(z)
+    graph3.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(a, eager)
+    with torch.no_grad():
+        core.blocks[2].mlp.fc2.bias.add_(1e-3)
+    eng.rewind()
+    a.copy_(z)
+    graph3.replay()                         # pointers and scales unchanged: still valid, follows the update
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all() and not torch.equal(a, eager)
+    out = eng.run(z, sched, graph=True)     # run() captures its own pair; its local graph leaves no state behind
+    with torch.no_grad():
+        core.blocks[2].mlp.fc2.bias.add_(1e-3)
+    assert torch.isfinite(eng.run(z, sched, graph=False)).all() and torch.isfinite(out).all()

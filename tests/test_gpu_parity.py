@@ -1545,3 +1545,11 @@ def test_fp8_attention_step_c5(dev, full):
     with pytest.raises(ValueError):
         A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z_v.shape),
                         prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul="f32", attn="fp8")
+    # an fp8 request on a core the split-operand kernels do not take (d = 384: 3d % 256 != 0) is refused, not run in fp32
+    from multimodal_diffusion_amd import _lib as L
+    narrow = A.MMDiT(d_model=384, n_layers=1, n_heads=6).to(dev).eval()
+    narrow.matmul, narrow.attn = "bf16x3", "fp8"
+    with pytest.raises(L.AvdError, match="fp8 attention"):
+        narrow(torch.randn(2, 64, 384, device=dev))
+    narrow.attn = "default"
+    assert torch.isfinite(narrow(torch.randn(2, 64, 384, device=dev))).all()     # same core without the request: fp32 kernels
