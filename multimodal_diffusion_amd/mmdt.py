@@ -154,12 +154,14 @@ class MMDiT(nn.Module):
                                      for _ in range(n_layers)])
         self.final_norm = build_norm(norm, d_model)
         self._ws: Optional[torch.Tensor] = None
+        # "auto" (default): "bf16x3" where the split kernels engage, the norm-folded fp32 MFMA kernels where they do not (small
+        # batches, key-padding masks, LayerNorm, widths off the 256-column tiles) — the fastest fp32-level path at every shape.
         # "f32": fp32 MFMA everywhere.  "bf16x3": the four projections of every block and the attention run on the bf16 matrix
         # pipe with exactly split operands (fp32-level error, csrc/gemm_bf16x3.hip) whenever the batch is large enough;
         # "bf16x3_strict" keeps all nine product terms; "bf16" keeps one (plain bf16 operands — reduced precision, config C2);
         # "f16x2" holds every operand as two scaled fp16 planes (22 significant bits) and keeps three terms: half the matrix-pipe
         # work of bf16x3, scales derived from the weights (_f16x2_scales).
-        self.matmul = "f32"
+        self.matmul = "auto"
         # "default": the attention follows `matmul`.  "fp8": QK^T and PV take e4m3 operands (csrc/attn_fp8.hip; needs a split matmul
         # mode) — reduced precision, BASELINE config C5, never the default.
         self.attn = "default"
@@ -246,7 +248,7 @@ class MMDiT(nn.Module):
                 setattr(arr[i], k, t.data_ptr())
             if self.matmul not in L.MATMUL_TERMS:
                 raise ValueError(f"matmul must be one of {sorted(L.MATMUL_TERMS)}, got {self.matmul!r}")
-            if self.fold_norms and self.matmul == "f32" and not ln:
+            if self.fold_norms and self.matmul in ("f32", "auto") and not ln:
                 for k, sc in (("in_proj_weight", "norm1_scale"), ("fc1_weight", "norm2_scale")):
                     t = self._folded_weight(f"{i}.{k}", L.dev_f32(ps[k].detach(), k), L.dev_f32(ps[sc].detach(), sc))
                     keep.append(t)

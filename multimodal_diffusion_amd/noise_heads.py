@@ -71,9 +71,9 @@ class MultiModalNoiseHead(nn.Module):
         self.out_proj = nn.ModuleDict({m: nn.Linear(self.hidden_dim, self.output_dims[m]) for m in self.modalities})
         self.apply(_init_linear)
         self._ws: Optional[torch.Tensor] = None
-        # matrix-pipe mode of the Linears, as MMDiT.matmul ("f32" | "bf16x3" | "bf16x3_strict" | "bf16" | "f16x2"); shapes the split
-        # kernels do not cover (d_out % 256, fewer than 6144 rows) stay on the fp32 MFMA kernels
-        self.matmul = "f32"
+        # matrix-pipe mode of the Linears, as MMDiT.matmul ("auto" | "f32" | "bf16x3" | "bf16x3_strict" | "bf16" | "f16x2"); shapes the
+        # split kernels do not cover (d_out % 256, fewer than 6144 rows) stay on the fp32 MFMA kernels
+        self.matmul = "auto"
         self._images: dict = {}
 
     def get_output_dim(self, modality: str) -> int:

@@ -54,16 +54,17 @@ def build_components(cfg: Dict, device: torch.device, vid_vae: Optional[nn.Modul
 
     The codec / VAE are built from ``cfg["video"]`` / ``cfg["audio"]`` like the reference unless the caller passes
     its own modules (anything with ``encode`` / ``decode``); they sit outside the per-step path.
-    Extension over the reference config: ``cfg["runtime"]["matmul"]`` in {"f32", "bf16x3", "bf16x3_strict", "f16x2", "bf16"} selects the matrix-pipe mode of the
-    MMDiT core and the VAE decoder (default "f32"; same fp32-level error either way).
+    Extension over the reference config: ``cfg["runtime"]["matmul"]`` in {"auto", "f32", "bf16x3", "bf16x3_strict", "f16x2", "bf16"}
+    selects the matrix-pipe mode of the MMDiT core, the noise head and the VAE (default "auto": the exact three-plane bf16x3 kernels
+    where they engage, fp32 MFMA elsewhere — what ``bench.py`` times; same fp32-level error either way).
     """
-    matmul = str(cfg.get("runtime", {}).get("matmul", "f32"))
+    matmul = str(cfg.get("runtime", {}).get("matmul", "auto"))
     if matmul not in L.MATMUL_TERMS:
         raise ValueError(f"runtime.matmul must be one of {sorted(L.MATMUL_TERMS)}, got {matmul!r}")
     if vid_vae is None and "video" in cfg:
         from .vae_video3d import VideoVAE
         vid_vae = VideoVAE.from_config(cfg["video"]).to(device).eval()
-        vid_vae.matmul = matmul if matmul in ("f32", "bf16x3", "f16x2") else "bf16x3"     # bf16 / strict: the exact three-plane convolutions
+        vid_vae.matmul = matmul if matmul in ("auto", "f32", "bf16x3", "f16x2") else "bf16x3"     # bf16 / strict: the exact three-plane convolutions
     if aud_codec is None and "audio" in cfg:
         from .audio_codec import AudioCodec
         aud_codec = AudioCodec.from_config(cfg["audio"]).to(device).eval()
@@ -80,6 +81,7 @@ def build_components(cfg: Dict, device: torch.device, vid_vae: Optional[nn.Modul
         hidden_dim=int(cfg["model"]["heads"]["video"]["hidden_dim"]), num_shared_layers=2,
         num_modality_specific_layers=1, dropout=float(cfg["model"]["core"].get("dropout", 0.1)),
         activation=cfg["model"]["heads"]["video"].get("activation", "gelu")).to(device).eval()
+    head.matmul = matmul
     return vid_vae, aud_codec, adapt_v, adapt_a, core, head, tstep_dim
 
 
@@ -178,7 +180,8 @@ class DenoiseEngine:
         self.N = e.Nt + e.Np
         self.alpha_bar = alpha_bar.to(self.device, torch.float32).contiguous()
 
-        # matrix-pipe mode of this engine ("f32" | "bf16x3", default: the core's own setting); the core module keeps its setting
+        # matrix-pipe mode of this engine (a key of _lib.MATMUL_TERMS; default: the core's own setting, "auto" unless changed); the core
+        # module keeps its setting
         self.matmul = core.matmul if matmul is None else matmul
         self.attn = core.attn if attn is None else attn
         # cond / null halves as two kernel chains on two HIP streams (bit-identical results).  Default: on where it was measured to

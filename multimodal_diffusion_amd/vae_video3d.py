@@ -73,9 +73,10 @@ class VideoVAE(nn.Module):
         self._ws: Optional[torch.Tensor] = None
         self._relaid = {}
         self._conv3 = {}
-        # "f32": convolutions on fp32 MFMA; "bf16x3": the 64 -> 64 convolutions on the bf16 matrix pipe with exactly split operands;
-        # "f16x2": the same convolutions with two scaled fp16 planes per operand and three product terms (csrc/vae3d_f32.hip)
-        self.matmul = "f32"
+        # "f32": convolutions on fp32 MFMA; "bf16x3" (= "auto", the default): the 64 -> 64 convolutions on the bf16 matrix pipe with
+        # exactly split operands; "f16x2": the same convolutions with two scaled fp16 planes per operand and three product terms
+        # (csrc/vae3d_f32.hip)
+        self.matmul = "auto"
 
     @classmethod
     def from_config(cls, d: Dict) -> "VideoVAE":
@@ -158,8 +159,8 @@ class VideoVAE(nn.Module):
         d.conv_w, d.conv_b = C.cast(cw, C.POINTER(C.c_void_p)), C.cast(cb, C.POINTER(C.c_void_p))
         d.gn_w, d.gn_b = C.cast(gw, C.POINTER(C.c_void_p)), C.cast(gb, C.POINTER(C.c_void_p))
         d.to_lat_w, d.to_lat_b = tlw.data_ptr(), tlb.data_ptr()
-        if self.matmul not in ("f32", "bf16x3", "f16x2"):
-            raise ValueError(f"matmul must be 'f32', 'bf16x3' or 'f16x2', got {self.matmul!r}")
+        if self.matmul not in ("auto", "f32", "bf16x3", "f16x2"):
+            raise ValueError(f"matmul must be 'auto', 'f32', 'bf16x3' or 'f16x2', got {self.matmul!r}")
         if self.matmul != "f32" and nb > 1:
             self._split_conv_desc(d, keep, nb, 1, True, (self.cfg.enc_base // 8) * T2 * H2 * W2)
         d.B = 1
@@ -285,8 +286,8 @@ class VideoVAE(nn.Module):
         d.conv_w, d.conv_b = C.cast(cw, C.POINTER(C.c_void_p)), C.cast(cb, C.POINTER(C.c_void_p))
         d.gn_w, d.gn_b = C.cast(gw, C.POINTER(C.c_void_p)), C.cast(gb, C.POINTER(C.c_void_p))
         d.to_img_w, d.to_img_b = tiw.data_ptr(), L.dev_f32(self.to_img.bias.detach()).data_ptr()
-        if self.matmul not in ("f32", "bf16x3", "f16x2"):
-            raise ValueError(f"matmul must be 'f32', 'bf16x3' or 'f16x2', got {self.matmul!r}")
+        if self.matmul not in ("auto", "f32", "bf16x3", "f16x2"):
+            raise ValueError(f"matmul must be 'auto', 'f32', 'bf16x3' or 'f16x2', got {self.matmul!r}")
         if self.matmul != "f32":
             self._split_conv_desc(d, keep, nb, 0, False, (self.cfg.dec_base // 8) * T * H * W)
         # chunk the batch so the NDHWC activations (2 x 0.85 GB per 48x256x256 sample) stay inside the budget

@@ -1138,6 +1138,51 @@ def test_engine_follows_weight_updates(dev, full, matmul):
     assert rel_err(after[:2], ref) < TOL
 
 
+def test_default_mode_is_the_headline_mode(dev):
+    """modules built through `build_components` from an mvp.yaml-shaped config with NO runtime override run the
+    bench's headline kernels at the bench's size (matmul "auto" -> bf16x3 where the split kernels engage) and the norm-folded fp32
+    MFMA kernels at a small batch; the auto engine's step is bit-identical to an explicit bf16x3 engine's (same kernels)."""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd import _lib as L
+    cfg = {"tokenizer": {"width": 512}, "embeddings": {"timestep_dim": 256},
+           "model": {"core": dict(d_model=512, n_layers=8, n_heads=8, mlp_ratio=4.0, dropout=0.1, attn_dropout=0.0, norm="rmsnorm",
+                                  rope=False, token_dropout=0.0),
+                     "heads": {"video": dict(out_dim=256, hidden_dim=512, num_layers=2, dropout=0.1, activation="gelu"),
+                               "audio": dict(out_dim=32, hidden_dim=512, num_layers=2, dropout=0.1, activation="gelu")}}}
+    torch.manual_seed(0)
+    _, _, av, aa, core, head, tdim = A.build_components(cfg, dev)
+    assert core.matmul == "auto" and head.matmul == "auto" and A.MMDiT().matmul == "auto"
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    g = torch.Generator().manual_seed(4)
+
+    def tags(B, hw, matmul=None):
+        z = torch.randn(B, 8, 12, hw, hw, generator=g).to(dev)
+        za = torch.randn(B, 8, 150, generator=g).to(dev)
+        eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=tdim, target="video", latent_shape=tuple(z.shape),
+                              prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=matmul)
+        eng.set_prompt(za)
+        tn, tp = torch.full((B,), 500, device=dev), torch.full((B,), 480, device=dev)
+        eng.step(z, tn, tp)
+        torch.cuda.synchronize()
+        L.prof_enable(True)
+        out = eng.step(z, tn, tp)
+        torch.cuda.synchronize()
+        L.prof_enable(False)
+        return {k for k, v in L.prof_report().items() if v[0] > 0}, out, (z, za, tn, tp)
+
+    big, out_auto, (z, za, tn, tp) = tags(32, 32)                      # C3: 2 x 32 x 421 = 26,944 rows
+    assert any(k.startswith(("gemm_bf16x3", "mlp_bf16x3")) for k in big) and any(k.startswith("attn_bf16x3") for k in big), big
+    assert not any(k.startswith("gemm_f32_dma") for k in big), big      # no block projection on the fp32 MFMA kernels
+    eng3 = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=tdim, target="video", latent_shape=tuple(z.shape),
+                           prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul="bf16x3")
+    eng3.set_prompt(za)
+    assert torch.equal(eng3.step(z, tn, tp), out_auto)
+    small, out_small, _ = tags(2, 8)                                    # 2 x 2 x 61 rows: below the split kernels' threshold
+    assert not any(k.startswith(("gemm_bf16x3", "attn_bf16x3")) for k in small), small
+    assert any(k.startswith("gemm_f32") for k in small), small
+    assert torch.isfinite(out_small).all()
+
+
 # ------------------------------------------------------------------------------------------------- bf16x3 adversarial suite
 def _bf16x3_vs_f32(dev, x, w, b=None, strict=False):
     """(bf16x3 result, fp32-MFMA result, fp64 reference, sum_k |x_k w_k|) for y = x w^T (+ b)."""
