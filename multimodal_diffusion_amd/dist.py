@@ -78,6 +78,28 @@ def gather_batch(local: torch.Tensor, global_batch: int) -> torch.Tensor:
     return torch.cat([p[:hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
 
 
+def run_sharded(n_items: int, cond: Optional[torch.Tensor], cond_shape: Tuple[int, ...], comm_device: torch.device, fn,
+                src: int = 0) -> torch.Tensor:
+    """The data-parallel layout of SURVEY 8e as one call: ``cond`` [n_items, ...] (held by rank ``src``; the others pass None) is
+    broadcast ONCE, rank r runs ``fn(cond[lo:hi], lo, hi)`` on its contiguous shard ``[lo, hi) = shard_range(n_items, r, world)``
+    — ``fn`` returns a tensor whose first dimension is ``hi - lo`` — and every rank gets the results of the WHOLE batch back in
+    item order (one all-gather, ragged shards allowed).  No communication inside ``fn``.  Single process: ``fn(cond, 0, n_items)``.
+    A rank whose shard is empty (more ranks than items) calls ``fn`` with an empty slice and must return an empty tensor."""
+    if tuple(cond_shape)[:1] != (n_items,):
+        raise ValueError("cond_shape must start with n_items")
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    full = broadcast_conditioning(cond, tuple(cond_shape), comm_device, src=src)
+    lo, hi = shard_range(n_items, rank, world)
+    out = fn(full[lo:hi], lo, hi)
+    if out.shape[0] != hi - lo:
+        raise ValueError(f"fn returned {out.shape[0]} items for the shard [{lo}, {hi})")
+    if world == 1:
+        return out
+    back = out.device
+    return gather_batch(out.to(comm_device).contiguous(), n_items).to(back)
+
+
 def max_over_ranks(value: float, device: torch.device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value

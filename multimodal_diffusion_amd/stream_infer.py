@@ -4,6 +4,9 @@ The reference splits the prompt into windows (3 s window / 1 s hop), calls ``sam
 (B = 1, sequentially) and cross-fades the results on the host.  Windows are independent samples, so here they are one
 batch: the prompt windows are encoded together, ``DenoiseEngine`` steps all windows at once (they are the natural
 large-batch feed for the data-parallel path), the outputs are decoded together and stitched by a HIP kernel.
+With ``shard=True`` under ``torch.distributed`` the windows are the units of the data-parallel layout: rank 0 encodes the
+prompt windows, ONE broadcast hands them to every rank, each rank steps its contiguous share of the windows with no further
+communication, one all-gather returns the finished latents and rank 0 decodes and stitches.
 
 ``split_*`` are host-side slicing (as in the reference); the fade tables are built on the host with the reference's
 fp32 numpy expressions and uploaded; ``crossfade_*`` keep the reference's numpy-in / numpy-out signatures.
@@ -17,6 +20,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import dist as D
 from . import schedule_utils as su
 from .sampler import DenoiseEngine
 
@@ -107,11 +111,20 @@ def crossfade_video(chunks: np.ndarray, hop: int, win: int, fade_f: int, device=
 @torch.no_grad()
 def stream_generate(*, cfg: Dict, vid_vae, aud_codec, adapt_v, adapt_a, core, head, tstep_dim: int, prompt_modality: str,
                     prompt_video: Optional[np.ndarray], prompt_audio: Optional[np.ndarray], device: torch.device,
-                    init_noise: Optional[torch.Tensor] = None, max_windows_per_batch: int = 32) -> Dict[str, np.ndarray]:
+                    init_noise: Optional[torch.Tensor] = None, max_windows_per_batch: int = 32, shard: bool = False,
+                    seed: Optional[int] = None, comm_device: Optional[torch.device] = None) -> Optional[Dict[str, np.ndarray]]:
     """The body of the reference's ``main()`` (stream_infer.py:146-225) minus file I/O, with all windows batched.
 
     Returns {"audio": wav, "sr"} for a video prompt or {"video": frames uint8, "fps"} for an audio prompt.
-    ``init_noise`` [N_windows, *latent] fixes the initial latents (the reference draws them window by window).
+    ``init_noise`` [N_windows, *latent] fixes the initial latents (the reference draws them window by window); ``seed`` draws them
+    from a CPU generator for the WHOLE window list instead (the same numbers whatever the number of ranks).
+
+    ``shard=True`` (every rank of the default process group calls this with the same arguments; one process per GPU): rank 0 encodes
+    the prompt windows, ONE broadcast (``dist.broadcast_conditioning``; over ``comm_device``, default: ``device`` for the nccl = RCCL
+    backend, the CPU for gloo) hands them to all ranks, rank r steps windows ``dist.shard_range(N_windows, r, world)``, one
+    all-gather collects the finished latents, and rank 0 decodes, stitches and returns the result — the other ranks return None.
+    Windows never interact inside the loop, so the stitched output equals the single-process one bit for bit as long as both runs
+    take the same kernels (the matrix-pipe mode "auto" switches kernels at 6,144 rows: fix ``core.matmul`` to compare across sizes).
     """
     st = cfg.get("streaming", {})
     win_s, hop_s = float(st.get("window_seconds", 3.0)), float(st.get("hop_seconds", 1.0))
@@ -124,42 +137,80 @@ def stream_generate(*, cfg: Dict, vid_vae, aud_codec, adapt_v, adapt_a, core, he
     H, W = int(cfg["video"]["size"][0]), int(cfg["video"]["size"][1])
     eta = float(cfg["sampling"].get("ddim_eta", 0.0))
 
+    import torch.distributed as tdist
+    world = tdist.get_world_size() if (shard and tdist.is_initialized()) else 1
+    rank = tdist.get_rank() if world > 1 else 0
+    root = rank == 0
+
+    # the prompt windows and the shape of their encoded form (known on every rank without encoding: only rank 0 runs the encoder)
     if prompt_modality == "video":
         if prompt_video is None:
             raise ValueError("prompt_video frames required for prompt_modality=video")
         chunks, win, hop = split_frames_into_windows(prompt_video, fps=fps, win_s=win_s, hop_s=hop_s)
-        frames = torch.from_numpy(np.ascontiguousarray(chunks)).to(device).float() / 255.0      # [N,T,H,W,3]
-        z_p = vid_vae.encode(frames.permute(0, 4, 1, 2, 3).contiguous())
+        zp_shape = (chunks.shape[0], Cv, chunks.shape[1] // t_down, chunks.shape[2] // s_down, chunks.shape[3] // s_down)
         target, lat = "audio", (Ca, Fa)
-        n_prompt = (z_p.shape[2] // t_p) * (z_p.shape[3] // p) * (z_p.shape[4] // p)
+        n_prompt = (zp_shape[2] // t_p) * (zp_shape[3] // p) * (zp_shape[4] // p)
         guide = float(cfg["sampling"]["guidance_scale"].get("audio", 3.0))
     elif prompt_modality == "audio":
         if prompt_audio is None:
             raise ValueError("prompt_audio required for prompt_modality=audio")
         chunks, win, hop = split_audio_into_windows(prompt_audio, sr=sr, win_s=win_s, hop_s=hop_s)
-        z_p = aud_codec.encode(torch.from_numpy(np.ascontiguousarray(chunks, dtype=np.float32)).to(device)[:, None, :])
+        zp_shape = (chunks.shape[0], Ca, Fa)
         T_in = int(round(cfg["data"]["clip_seconds"] * fps))
         target, lat = "video", (Cv, max(1, T_in // t_down), H // s_down, W // s_down)
-        n_prompt = (z_p.shape[-1] - l_chunk) // s_chunk + 1
+        n_prompt = (Fa - l_chunk) // s_chunk + 1
         guide = float(cfg["sampling"]["guidance_scale"].get("video", 3.0))
     else:
         raise ValueError("prompt_modality must be 'video' or 'audio'")
+    z_p = None
+    if root:
+        if prompt_modality == "video":
+            frames = torch.from_numpy(np.ascontiguousarray(chunks)).to(device).float() / 255.0      # [N,T,H,W,3]
+            z_p = vid_vae.encode(frames.permute(0, 4, 1, 2, 3).contiguous())
+        else:
+            z_p = aud_codec.encode(torch.from_numpy(np.ascontiguousarray(chunks, dtype=np.float32)).to(device)[:, None, :])
+        if tuple(z_p.shape) != zp_shape:
+            raise L.AvdError(f"encoded prompt windows have shape {tuple(z_p.shape)}, the config implies {zp_shape}")
 
     c = cfg["diffusion"][target]
     abar = su.alphas_cumprod_from_betas(su.make_beta_schedule(int(c["steps"]), kind=c["schedule"], min_beta=c["min_beta"],
                                                               max_beta=c["max_beta"]))[1]
     sched = su.make_sampling_schedule(int(c["steps"]), int(c["sampler_steps"]))
-    Nw = z_p.shape[0]
-    z0 = init_noise.to(device) if init_noise is not None else torch.randn(Nw, *lat, device=device)
-    outs = []
-    for lo in range(0, Nw, max_windows_per_batch):
-        hi = min(Nw, lo + max_windows_per_batch)
-        eng = DenoiseEngine(adapt_v=adapt_v, adapt_a=adapt_a, core=core, head=head, tstep_dim=tstep_dim, target=target,
-                            latent_shape=(hi - lo, *lat), prompt_tokens=n_prompt, alpha_bar=abar, guidance=guide, eta=eta,
-                            tube=(t_p, p, p), chunk=(l_chunk, s_chunk))
-        eng.set_prompt(z_p[lo:hi].float().contiguous())
-        outs.append(eng.run(z0[lo:hi].contiguous(), sched))
-    z = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+    Nw = zp_shape[0]
+    if init_noise is not None:
+        z0 = init_noise
+    elif seed is not None:
+        z0 = torch.randn(Nw, *lat, generator=torch.Generator().manual_seed(int(seed)))
+    elif world > 1:
+        raise ValueError("a sharded run needs init_noise or seed: every rank must start its windows from the same global draw")
+    else:
+        z0 = torch.randn(Nw, *lat, device=device)
+    if tuple(z0.shape) != (Nw, *lat):
+        raise ValueError(f"init_noise has shape {tuple(z0.shape)}, expected {(Nw, *lat)}")
+
+    def denoise(zp_part: torch.Tensor, lo0: int, hi0: int) -> torch.Tensor:
+        """the windows [lo0, hi0) of the list, stepped in batches of at most max_windows_per_batch; no communication"""
+        outs = []
+        for lo in range(lo0, hi0, max_windows_per_batch):
+            hi = min(hi0, lo + max_windows_per_batch)
+            eng = DenoiseEngine(adapt_v=adapt_v, adapt_a=adapt_a, core=core, head=head, tstep_dim=tstep_dim, target=target,
+                                latent_shape=(hi - lo, *lat), prompt_tokens=n_prompt, alpha_bar=abar, guidance=guide, eta=eta,
+                                tube=(t_p, p, p), chunk=(l_chunk, s_chunk))
+            eng.set_prompt(zp_part[lo - lo0:hi - lo0].to(device).float().contiguous())
+            outs.append(eng.run(z0[lo:hi].to(device).contiguous(), sched))
+        if not outs:
+            return torch.empty(0, *lat, device=device)
+        return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
+
+    if world > 1:
+        if comm_device is None:
+            comm_device = device if tdist.get_backend() == "nccl" else torch.device("cpu")
+        z = D.run_sharded(Nw, z_p if root else None, zp_shape, comm_device, denoise)
+        if not root:
+            return None
+        z = z.to(device)
+    else:
+        z = denoise(z_p, 0, Nw)
 
     if target == "audio":
         wav = aud_codec.decode(z)[:, 0, :].contiguous()                       # [N, L]

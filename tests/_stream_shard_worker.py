@@ -1,0 +1,56 @@
+"""Worker of tests/test_dist_gloo.py::test_stream_generate_sharded_two_ranks_share_device: `stream_generate(shard=True)` under
+`python -m torch.distributed.run --nproc-per-node 2` with gloo, both ranks on cuda:0; rank 0 then runs the same generation in one
+process and writes whether the two stitched results are bit-identical."""
+import json
+import os
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+import multimodal_diffusion_amd as A  # noqa: E402
+from multimodal_diffusion_amd import dist as D, stream_infer as S  # noqa: E402
+from oracle import ref_cpu as R  # noqa: E402  (seeded weight recipe only: test infrastructure)
+
+rank, world, _ = D.init_from_env("gloo")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+
+ws = R.synth_weights(seed=3, n_layers=2)
+core = A.MMDiT(d_model=512, n_layers=2, n_heads=8, mlp_ratio=4.0).eval()
+core.load_state_dict(ws["core"], strict=True)
+head = A.MultiModalNoiseHead({"video": 512, "audio": 512}, {"video": 256, "audio": 32}, hidden_dim=512).eval()
+head.load_state_dict(ws["head"], strict=True)
+av, aa = A.LinearAdapter(256, 256), A.LinearAdapter(32, 256)
+av.load_state_dict(ws["adapt_v"])
+aa.load_state_dict(ws["adapt_a"])
+core, head, av, aa = (m.to(dev) for m in (core, head, av, aa))
+core.matmul = head.matmul = "f32"          # one kernel family whatever the shard size (the "auto" rule switches at 6,144 rows)
+torch.manual_seed(8)                       # identical codec / VAE weights on both ranks
+vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval().to(dev)
+codec = A.AudioCodec.from_config({"sr": 16000, "latent": {"channels": 8, "frames_per_clip": 150}, "codec": {"hop_samples": 320}}).eval().to(dev)
+cfg = {"tokenizer": {"width": 512, "video": {"tube": {"t": 2, "h": 4, "w": 4}}, "audio": {"chunk": {"length": 4, "stride": 4}}},
+       "video": {"fps": 16, "size": [32, 32], "latent": {"channels": 8, "t_down": 4, "s_down": 8}},
+       "audio": {"sr": 16000, "latent": {"channels": 8, "frames_per_clip": 150}},
+       "data": {"clip_seconds": 0.5}, "streaming": {"window_seconds": 0.5, "hop_seconds": 0.25, "crossfade_seconds": 0.125},
+       "diffusion": {m: {"steps": 1000, "sampler_steps": 3, "schedule": "cosine", "min_beta": 1e-4, "max_beta": 0.02} for m in ("video", "audio")},
+       "sampling": {"ddim_eta": 0.0, "guidance_scale": {"video": 2.0, "audio": 2.0}}}
+wav = (0.1 * torch.randn(18000, generator=torch.Generator().manual_seed(9))).numpy()      # 5 windows of 0.5 s at a 0.25 s hop
+kw = dict(cfg=cfg, vid_vae=vae, aud_codec=codec, adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, device=dev,
+          prompt_modality="audio", prompt_video=None, prompt_audio=wav, seed=10)
+n_win = S.split_audio_into_windows(wav, sr=16000, win_s=0.5, hop_s=0.25)[0].shape[0]
+
+sharded = S.stream_generate(shard=True, **kw)
+none_elsewhere = D.gather_scalars(1.0 if sharded is None else 0.0, torch.device("cpu"))
+D.barrier()
+torch.distributed.destroy_process_group()
+if rank == 0:
+    single = S.stream_generate(shard=False, **kw)
+    same = sharded is not None and sharded["video"].dtype == np.uint8 and np.array_equal(sharded["video"], single["video"])
+    Path(os.environ["AVD_TEST_OUT"]).write_text(json.dumps({
+        "world": world, "windows": int(n_win), "shards": [list(D.shard_range(n_win, r, world)) for r in range(world)],
+        "rank1_returned_none": none_elsewhere == [0.0, 1.0], "frames_shape": list(single["video"].shape),
+        "bit_identical": bool(same), "max_abs_diff": int(np.abs(sharded["video"].astype(np.int32) - single["video"].astype(np.int32)).max())}))

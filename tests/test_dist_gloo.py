@@ -56,6 +56,57 @@ def test_broadcast_and_shard_world2():
     assert res == [(0, True, 2.0), (1, True, 2.0)]
 
 
+def _shard_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from multimodal_diffusion_amd import dist as D
+    D.init_from_env("gloo")
+    n = 7                                                    # ragged: 4 + 3 items
+    cond_all = torch.arange(n * 6, dtype=torch.float32).view(n, 2, 3)
+    seen = []
+
+    def step(cond_part, lo, hi):                             # stand-in for the denoising loop: per-item, no communication
+        seen.append((lo, hi, cond_part.clone()))
+        return cond_part.sum(-1) * 2.0 + torch.arange(lo, hi, dtype=torch.float32)[:, None]
+
+    got = D.run_sharded(n, cond_all if rank == 0 else None, (n, 2, 3), torch.device("cpu"), step)
+    want = cond_all.sum(-1) * 2.0 + torch.arange(n, dtype=torch.float32)[:, None]
+    lo, hi = D.shard_range(n, rank, world)
+    ok = torch.equal(got, want) and len(seen) == 1 and seen[0][:2] == (lo, hi) and torch.equal(seen[0][2], cond_all[lo:hi])
+    # more ranks than items: the empty shard contributes nothing and every rank still gets the whole result
+    one = D.run_sharded(1, torch.ones(1, 4) if rank == 0 else None, (1, 4), torch.device("cpu"), lambda c, a, b: c * 3.0)
+    ok = ok and torch.equal(one, torch.full((1, 4), 3.0))
+    D.barrier()
+    out.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_run_sharded_world2():
+    """dist.run_sharded — the library entry stream_generate(shard=True) is built on: ONE broadcast of the conditioning from rank 0,
+    contiguous (ragged) shards, the per-shard function called once per rank with exactly its slice, one all-gather of the results in
+    item order; world size 2 over gloo on CPU with a stand-in step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
+
+
+def test_run_sharded_single_process():
+    from multimodal_diffusion_amd import dist as D
+    c = torch.arange(10, dtype=torch.float32).view(5, 2)
+    assert torch.equal(D.run_sharded(5, c, (5, 2), torch.device("cpu"), lambda part, lo, hi: part + lo), c)
+    with pytest.raises(ValueError):
+        D.run_sharded(5, c, (4, 2), torch.device("cpu"), lambda part, lo, hi: part)
+    with pytest.raises(ValueError):
+        D.run_sharded(5, c, (5, 2), torch.device("cpu"), lambda part, lo, hi: part[:1])
+
+
 def test_bench_setup_under_torchrun(tmp_path):
     """bench.py's own N > 1 setup, launched the way the driver launches it (torch.distributed.run, one process per rank),
     with gloo on CPU: env handling, group init, the conditioning broadcast and shards, per-rank latents, max-over-ranks."""
@@ -107,3 +158,31 @@ def test_bench_two_ranks_share_device():
     cs, ls = d["verify"]["conditioning_checksum_per_rank"], d["verify"]["latent_abs_sum_per_rank"]
     assert len(cs) == 2 and cs[0] == cs[1], cs
     assert len(ls) == 2 and all(v == v and v < float("inf") for v in ls) and ls[0] != ls[1], ls
+
+
+@pytest.mark.gpu
+@pytest.mark.gpu_first
+def test_stream_generate_sharded_two_ranks_share_device(tmp_path):
+    """The library's data-parallel entry on hardware: `stream_generate(shard=True)` launched as two FRESH
+    child ranks under `python -m torch.distributed.run` (gloo for the one broadcast and the one all-gather, both ranks on cuda:0).
+    Rank 0 then repeats the generation single-process in the same worker and compares: the stitched uint8 video of the sharded run
+    equals the single-process result BIT FOR BIT (tests/_stream_shard_worker.py).  This process never touches the device."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    if torch.cuda.device_count() < 1:
+        pytest.skip("needs a GPU")
+    if torch.cuda.is_initialized():
+        pytest.skip("this process already initialised the GPU: run this test first / alone (conftest orders it first)")
+    root = Path(__file__).resolve().parent.parent
+    out = tmp_path / "shard.json"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", AVD_TEST_OUT=str(out))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(root / "tests" / "_stream_shard_worker.py")]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    d = json.loads(out.read_text())
+    assert d["world"] == 2 and d["windows"] == 5 and d["shards"] == [[0, 3], [3, 5]], d
+    assert d["rank1_returned_none"] and d["frames_shape"][1:] == [32, 32, 3]
+    assert d["bit_identical"], d

@@ -1138,6 +1138,97 @@ def test_engine_follows_weight_updates(dev, full, matmul):
     assert rel_err(after[:2], ref) < TOL
 
 
+@pytest.mark.parametrize("matmul", ["f32", "bf16x3", "f16x2", "auto"])
+def test_class_default_width_golden(dev, matmul):
+    """VERDICT r3 missing 4: the reference's CLASS-DEFAULT geometry — MMDiT(d_model=1024, n_heads=16) (mmdt.py:125-126; two layers) on
+    16 x 421 tokens (6,736 rows: the split kernels engage) and MultiModalNoiseHead at d = 1024 with the reference shape test's token
+    counts (tests/test_shapes.py:86-107: Nv = 96, Na = 37; batch 64 = 6,144 video rows) — against fixture g18 (the reference's own
+    modules on seeded-recipe weights) and against the oracle on whole samples.  Widths other than mvp.yaml's take other kernel
+    variants: N = 1024 residual epilogues (four column blocks, 16 sum-of-squares chunks per row), K = 4096 fc2, 16-head q|k|v
+    images, no row-owner norm epilogue in f16x2 (that one needs N == 512: separate norm kernels run instead)."""
+    import multimodal_diffusion_amd as A
+    g = load_golden("g18_class_default_width.npz")
+    meta = json.loads(str(g["meta"]))
+    ws = R.synth_weights(seed=meta["seed_weights"], d=1024, n_layers=2)
+    gen = torch.Generator().manual_seed(meta["seed_inputs"])
+    x = torch.randn(16, 421, 1024, generator=gen)
+    hv = torch.randn(64, 96, 1024, generator=gen)
+    ha = torch.randn(64, 37, 1024, generator=gen)
+    core = A.MMDiT(d_model=1024, n_layers=2, n_heads=16).eval()
+    core.load_state_dict(ws["core"], strict=True)
+    head = A.MultiModalNoiseHead(input_dims={"video": 1024, "audio": 1024}, output_dims={"video": 256, "audio": 32}, hidden_dim=512,
+                                 num_shared_layers=2, num_modality_specific_layers=1, dropout=0.1, activation="gelu").eval()
+    head.load_state_dict(ws["head"], strict=True)
+    core, head = core.to(dev), head.to(dev)
+    core.matmul = head.matmul = matmul
+    y = core(x.to(dev)).cpu()
+    e_gold = max(rel_err(y[0, ::8], g["core_first"]), rel_err(y[-1, ::8], g["core_last"]))
+    e_orc = rel_err(y[[0, 7]], R.mmdit_forward(x[[0, 7]], ws["core"], 2, 16))
+    out = head({"video": hv.to(dev), "audio": ha.to(dev)})
+    ov, oa = out["video"].cpu(), out["audio"].cpu()
+    assert ov.shape == (64, 96, 256) and oa.shape == (64, 37, 32)
+    e_head = max(rel_err(ov[0], g["head_video_first"]), rel_err(ov[-1], g["head_video_last"]), rel_err(oa[0], g["head_audio_first"]))
+    e_head_orc = rel_err(ov[[5, 40]], R.noise_head(hv[[5, 40]], ws["head"], "video"))
+    print(f"d_model 1024, {matmul}: core vs golden {e_gold:.2e}, vs oracle {e_orc:.2e}; head vs golden {e_head:.2e}, vs oracle {e_head_orc:.2e}")
+    assert torch.isfinite(y).all() and max(e_gold, e_orc, e_head, e_head_orc) < TOL
+    # the reference shape test's own call (B = 2: 192 + 74 rows, fp32 kernels whatever the mode)
+    small = head({"video": hv[:2].to(dev), "audio": ha[:2].to(dev)})
+    assert rel_err(small["video"].cpu(), R.noise_head(hv[:2], ws["head"], "video")) < TOL
+    assert rel_err(small["audio"].cpu(), R.noise_head(ha[:2], ws["head"], "audio")) < TOL
+
+
+@pytest.mark.parametrize("d,H,hid", [(768, 12, 3072), (256, 4, 1024), (384, 6, 1536), (512, 8, 1024)])
+def test_other_widths_fall_back_or_run(dev, d, H, hid):
+    """Widths the split kernels cover (every projection width a multiple of 256: d = 768, 256) run them; widths they refuse (d = 384:
+    3 d = 1,152 is not) take the fp32 MFMA kernels without a word — both against the oracle in the headline mode at a row count
+    past the split threshold, so whichever path is taken is the one being checked."""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd import _lib as L
+    ws = R.synth_weights(seed=d, d=d, n_layers=2, mlp_ratio=hid / d)
+    core = A.MMDiT(d_model=d, n_layers=2, n_heads=H, mlp_ratio=hid / d).eval()
+    core.load_state_dict(ws["core"], strict=True)
+    core = core.to(dev)
+    x = torch.randn(16, 421, d, generator=torch.Generator().manual_seed(d + 1))
+    ref = R.mmdit_forward(x[:2], ws["core"], 2, H)
+    for mode in ("bf16x3", "f16x2", "f32"):
+        core.matmul = mode
+        core(x.to(dev))
+        L.prof_enable(True)
+        y = core(x.to(dev)).cpu()
+        torch.cuda.synchronize()
+        L.prof_enable(False)
+        used = {k for k, v in L.prof_report().items() if v[0] > 0}
+        split = any(k.startswith("gemm_bf16x3") for k in used)
+        assert split == (mode != "f32" and d % 256 == 0 and hid % 256 == 0), (d, mode, used)
+        assert rel_err(y[:2], ref) < TOL, (d, mode)
+
+
+@pytest.mark.parametrize("matmul", ["bf16x3", "f16x2", "auto"])
+def test_full_step_shipped_geometry_batch32(dev, full, matmul):
+    """the reference's SHIPPED geometry (configs/mvp.yaml:32 — 128 x 128 video: 96 + 37 tokens) at batch 32:
+    2B*N = 8,512 rows, just above the split kernels' 6,144-row threshold, where every projection takes the 256 x 128 blocks.  One CFG
+    step against the CPU oracle (not against the fp32 mode) on samples from the start, middle and end of the batch."""
+    import multimodal_diffusion_amd as A
+    ws, mods = full
+    core, head, av, aa = mods
+    B, idx = 32, [0, 13, 31]
+    g = torch.Generator().manual_seed(1280)
+    z_v = torch.randn(B, 8, 12, 16, 16, generator=g)
+    z_a = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn = torch.tensor(([982, 500, 16, 999] * B)[:B])
+    tp = torch.tensor(([966, 480, -1, 979] * B)[:B])
+    eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z_v.shape),
+                          prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=matmul)
+    eng.set_prompt(z_a.to(dev))
+    out = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)).cpu()
+    ref = R.denoise_step_a2v(z_v[idx], z_a[idx], tn[idx], tp[idx], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"], core=ws["core"],
+                             head=ws["head"], n_layers=8, n_heads=8, guidance=3.5)
+    err = rel_err(out[idx], ref)
+    print(f"128x128 batch 32, {matmul}: rel err vs CPU oracle {err:.3e}")
+    assert torch.isfinite(out).all() and err < TOL
+
+
 def test_default_mode_is_the_headline_mode(dev):
     """modules built through `build_components` from an mvp.yaml-shaped config with NO runtime override run the
     bench's headline kernels at the bench's size (matmul "auto" -> bf16x3 where the split kernels engage) and the norm-folded fp32

@@ -224,6 +224,27 @@ def test_g17_full_width_step():
     assert rel_err(z, g["z_next01"]) < TOL
 
 
+def g18_inputs():
+    """The seeded inputs of fixture g18 (tools/make_golden.py G18): core input, head video rows, head audio rows (seed 1818)."""
+    gen = torch.Generator().manual_seed(1818)
+    return (torch.randn(16, 421, 1024, generator=gen), torch.randn(64, 96, 1024, generator=gen), torch.randn(64, 37, 1024, generator=gen))
+
+
+def test_g18_class_default_width():
+    """The reference's class-default width (mmdt.py:125-126: d_model 1024, 16 heads; two layers) and its shape test's head
+    (tests/test_shapes.py:86-107: d = 1024, Nv = 96, Na = 37) computed by the REFERENCE's own modules on seeded-recipe weights:
+    the oracle on the first and last sample."""
+    g = load_golden("g18_class_default_width.npz")
+    meta = json.loads(str(g["meta"]))
+    ws = R.synth_weights(seed=meta["seed_weights"], d=1024, n_layers=2)
+    x, hv, ha = g18_inputs()
+    y = R.mmdit_forward(x[[0, -1]], ws["core"], 2, 16)
+    assert rel_err(y[0, ::8], g["core_first"]) < TOL and rel_err(y[1, ::8], g["core_last"]) < TOL
+    ov = R.noise_head(hv[[0, -1]], ws["head"], "video")
+    assert rel_err(ov[0], g["head_video_first"]) < TOL and rel_err(ov[1], g["head_video_last"]) < TOL
+    assert rel_err(R.noise_head(ha[:1], ws["head"], "audio")[0], g["head_audio_first"]) < TOL
+
+
 def _grp(g, prefix):
     return {k[len(prefix) + 1:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix + "/")}
 

@@ -16,6 +16,8 @@ G14 stream_infer splitting / cross-fade stitching,
 G15 one CFG step with the TRAINER's embedding (d-wide adapters, timestep embedding added; train/trainer.py:36-49),
 G16 drop-in corners: MMDiT with key_padding_mask, norm="layernorm", VideoVAE variational eval encode, non-GELU head.
 G17 one CFG step at the bench's full model width (d=512, L=8, 421 tokens), batch 8, weights by seeded recipe.
+G18 the reference CLASS-DEFAULT geometry (mmdt.py:125-126: d_model=1024, n_heads=16; 2 layers for time): MMDiT.forward on 16 x 421
+    tokens, and MultiModalNoiseHead at d=1024 with the reference shape test's token counts (tests/test_shapes.py:86-107: Nv=96, Na=37).
 """
 from __future__ import annotations
 
@@ -438,6 +440,34 @@ def main():
             zn = su.ddim_step(z_v, tn17, tp17, el, abarF, eta=0.0)
         _save("g17_full_step_c3.npz", meta=np.array(json.dumps(dict(seed_weights=0, seed_inputs=1717, B=B17, guidance=3.5, tokens=[int(Nv), int(tok_a.size(1))]))),
               t_now=_np(tn17), t_prev=_np(tp17), eps_tok0=_np(et[:1]), z_next01=_np(zn[:2]), z_next_absmax=np.float32(zn.abs().max()))
+
+    # ---- G18 the reference's class-default width through its own modules: MMDiT(d_model=1024, n_heads=16) (mmdt.py:125-126; two of
+    # the sixteen layers, to keep the CPU run and the GPU test short) on [16, 421, 1024] (6,736 rows: every matrix-pipe mode of the HIP
+    # path engages), and MultiModalNoiseHead(input 1024 -> hidden 512 -> 256 | 32) on the reference shape test's token counts
+    # (tests/test_shapes.py:86-107: Nv = 96, Na = 37) at batch 64 (6,144 video rows).  Weights: the seeded recipe
+    # oracle.synth_weights(18, d=1024, n_layers=2), loaded with strict=True, not stored.  Stored: every 8th row of the first and the
+    # last sample of the core output; the head's video tokens for the first and last sample and its audio tokens for the first.
+    if ONLY is None or "g18" in ONLY:
+        sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+        from oracle import ref_cpu as R
+        ws18 = R.synth_weights(seed=18, d=1024, n_layers=2)
+        core18 = MMDiT(d_model=1024, n_layers=2, n_heads=16).eval()          # every other kwarg at the class default
+        core18.load_state_dict(ws18["core"], strict=True)
+        head18 = MultiModalNoiseHead(input_dims={"video": 1024, "audio": 1024}, output_dims={"video": 256, "audio": 32}, hidden_dim=512,
+                                     num_shared_layers=2, num_modality_specific_layers=1, dropout=0.1, activation="gelu").eval()
+        head18.load_state_dict(ws18["head"], strict=True)
+        gen = torch.Generator().manual_seed(1818)
+        x18 = torch.randn(16, 421, 1024, generator=gen)
+        hv18 = torch.randn(64, 96, 1024, generator=gen)
+        ha18 = torch.randn(64, 37, 1024, generator=gen)
+        with torch.no_grad():
+            y18 = core18(x18)
+            o18 = head18({"video": hv18, "audio": ha18})
+        _save("g18_class_default_width.npz",
+              meta=np.array(json.dumps(dict(seed_weights=18, seed_inputs=1818, d_model=1024, n_layers=2, n_heads=16, core_in=[16, 421, 1024],
+                                            head_video_in=[64, 96, 1024], head_audio_in=[64, 37, 1024], row_stride=8))),
+              core_first=_np(y18[0, ::8]), core_last=_np(y18[-1, ::8]), core_absmax=np.float32(y18.abs().max()),
+              head_video_first=_np(o18["video"][0]), head_video_last=_np(o18["video"][-1]), head_audio_first=_np(o18["audio"][0]))
 
     # ---- optional: full-size live comparison oracle vs reference --------------------------
     if args.full_size_report:
