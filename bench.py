@@ -105,6 +105,89 @@ def pmc_traffic(kernel_tag: str, matmul: str):
     return None, "no PMC profile committed for this mode"
 
 
+class PowerClockSampler:
+    """Core clock and socket power of THIS GPU while a pass runs, read from sysfs by a sampling thread (no child process: a process
+    that has initialised HIP must not fork + exec on the GPU boxes).  The builder's explanation of every roofline fraction in this
+    file is "the chip holds its clock down under the power cap" (DESIGN.md 4.5-4.8): the driver's record carries the evidence."""
+
+    def __init__(self, device_index: int):
+        self.dir = self._find(device_index)
+        self.samples = []          # (t, sclk_mhz | None, power_w | None)
+        self._stop = False
+        self._thread = None
+
+    @staticmethod
+    def _find(device_index: int):
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = f"{getattr(pr, 'pci_domain_id', 0):04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            d = Path("/sys/bus/pci/devices") / bdf
+            if (d / "pp_dpm_sclk").exists():
+                return d
+        except Exception:
+            pass
+        cards = sorted(Path("/sys/class/drm").glob("card[0-9]*/device/pp_dpm_sclk"))
+        return cards[0].parent if len(cards) == 1 else None      # several cards and no PCI match: do not guess
+
+    def _read(self):
+        mhz = watts = None
+        try:
+            for line in (self.dir / "pp_dpm_sclk").read_text().splitlines():
+                if line.rstrip().endswith("*"):
+                    mhz = float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except (OSError, ValueError, IndexError):
+            pass
+        for name in ("power1_average", "power1_input"):
+            for f in self.dir.glob(f"hwmon/hwmon*/{name}"):
+                try:
+                    watts = float(f.read_text()) / 1e6
+                    break
+                except (OSError, ValueError):
+                    continue
+            if watts is not None:
+                break
+        return mhz, watts
+
+    def cap_watts(self):
+        if self.dir is None:
+            return None
+        for f in self.dir.glob("hwmon/hwmon*/power1_cap"):
+            try:
+                return float(f.read_text()) / 1e6
+            except (OSError, ValueError):
+                pass
+        return None
+
+    def start(self):
+        import threading
+        if self.dir is None:
+            return
+        self._t0 = time.perf_counter()
+
+        def loop():
+            while not self._stop:
+                mhz, watts = self._read()
+                self.samples.append((time.perf_counter() - self._t0, mhz, watts))
+                time.sleep(0.05)
+        self._thread = threading.Thread(target=loop, daemon=True)
+        self._thread.start()
+
+    def stop(self, settle_s: float):
+        """median clock / power over the samples taken after `settle_s` seconds of load"""
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join(timeout=2.0)
+        if self.dir is None:
+            return {"source": None, "reason": "no sysfs node found for this device (pp_dpm_sclk / hwmon power1_average)"}
+        late = [x for x in self.samples if x[0] >= settle_s] or self.samples
+        med = lambda v: (sorted(v)[len(v) // 2] if v else None)
+        return {"source": f"sysfs {self.dir}", "samples": len(late), "settle_s": settle_s,
+                "sclk_mhz_median": med([x[1] for x in late if x[1] is not None]),
+                "socket_power_w_median": med([x[2] for x in late if x[2] is not None]),
+                "socket_power_cap_w": self.cap_watts(),
+                "note": "pp_dpm_sclk reads up to ~10 % above the in-kernel clock of an MFMA-dense loop (MI355X_MICROARCH.md, DVFS give-back 6)"}
+
+
 def step_flops_per_sample(nv: int, na: int, d: int = 512, L: int = 8, hid: int = 2048, tok: int = 256,
                           head_hidden: int = 512, tdim: int = 256) -> float:
     """Algorithmic FLOPs of one CFG step for one sample (head on target rows only)."""
@@ -387,6 +470,20 @@ def main():
         out["roofline"], out["kernels"], single = instrumented(args.matmul, eng)
         if single is not None:
             out["single_stream_steps_per_s"] = single
+
+    # ---- clock and socket power the chip holds on this workload: >= 2.5 s of back-to-back steps of the timed engine, sysfs sampled
+    # every 50 ms, medians over what was read after the first second (outside the timed region)
+    if rank == 0 and not args.no_roofline:
+        smp = PowerClockSampler(dev.index if dev.index is not None else 0)
+        smp.start()
+        p0 = time.perf_counter()
+        n_pc = 0
+        while time.perf_counter() - p0 < 2.5:
+            run_steps(10)
+            torch.cuda.synchronize()
+            n_pc += 10
+        out["power_clock"] = smp.stop(settle_s=1.0)
+        out["power_clock"]["steps_per_s_during_pass"] = n_pc / (time.perf_counter() - p0)
 
     # ---- CPU side (rank 0, N = 1): the oracle's step is the parity reference; the TIMED baseline is the port of the same step on
     # the fused ATen kernels the reference's modules dispatch to (oracle/ref_cpu_fast.py; tools/cpu_port_speed.py holds it to the

@@ -38,7 +38,7 @@ cfg = {"tokenizer": {"width": 512, "video": {"tube": {"t": 2, "h": 4, "w": 4}}, 
        "data": {"clip_seconds": 0.5}, "streaming": {"window_seconds": 0.5, "hop_seconds": 0.25, "crossfade_seconds": 0.125},
        "diffusion": {m: {"steps": 1000, "sampler_steps": 3, "schedule": "cosine", "min_beta": 1e-4, "max_beta": 0.02} for m in ("video", "audio")},
        "sampling": {"ddim_eta": 0.0, "guidance_scale": {"video": 2.0, "audio": 2.0}}}
-wav = (0.1 * torch.randn(18000, generator=torch.Generator().manual_seed(9))).numpy()      # 5 windows of 0.5 s at a 0.25 s hop
+wav = (0.1 * torch.randn(18000, generator=torch.Generator().manual_seed(9))).numpy()      # 4 windows of 0.5 s at a 0.25 s hop
 kw = dict(cfg=cfg, vid_vae=vae, aud_codec=codec, adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, device=dev,
           prompt_modality="audio", prompt_video=None, prompt_audio=wav, seed=10)
 n_win = S.split_audio_into_windows(wav, sr=16000, win_s=0.5, hop_s=0.25)[0].shape[0]
