@@ -15,6 +15,9 @@
 // reads were measured and change nothing: the step runs on the socket power cap.
 #include "avd_common.h"
 
+#include <stdlib.h>
+#include <type_traits>
+
 namespace avd {
 
 constexpr int A3_DH = 64, A3_KT = 64, A3_NW = 4;
@@ -272,6 +275,323 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 4: the same algorithm as ONE software pipeline per wave (attn_bf16x3_pipe_kernel, default; avd_tune_set "attn_pipe" 0 takes the
+// kernel above).  Why: in the kernel above a wave's 96 MFMAs per 64-key tile (3,072 matrix-pipe cycles, six terms) and its ~1,900 cycles
+// of softmax / split VALU work run one after the other, and on a SIMD the two ADD (DESIGN.md 4.8 g): 0.32 of the MFMA peak with the pipe
+// 40 % busy.  A v_mfma_f32_32x32x16 occupies the SIMD's vector issue for 8 of its 32 cycles; the other 24 take up to five single-issue
+// VALU instructions of the SAME wave for free (MI355X_MICROARCH.md, cycle constants) — but only instructions that do not depend on the
+// MFMAs around them.  So the tile loop is skewed by half a tile:
+//   phase A(kt):  S^T(kt+1) = K(kt+1) Q^T   [48 MFMAs, six terms]   beside   p(kt) = exp2(s(kt) - m), row sums, O *= alpha, split of
+//                                                                           the first 16-key group of p(kt)
+//   phase B(kt):  O^T += V(kt)^T P(kt)^T     [48 MFMAs]              beside   split of key groups 1..3 of p(kt), max of s(kt+1)
+// with the VALU work cut into items that are dealt out behind every MFMA pair in program order (a sched_barrier pins each slot).
+// K(kt+2) is fetched while phase B runs, V(kt+1) while phase A runs: the same two LDS tiles and two barriers per tile as before.
+// The O rescale is unconditional here (alpha = 1 when no maximum moved): a wave-uniform branch would cut the schedule in two.
+int g_attn_pipe = getenv("AVD_ATTN_PIPE") ? atoi(getenv("AVD_ATTN_PIPE")) : 1;
+
+template <bool SPLIT_OUT, int TERMS>
+__global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const unsigned char* __restrict__ img, float* __restrict__ out,
+                                                                         int Bt, int N, int Npad, int H, int n_query, int nqb,
+                                                                         float s_inv2, float v_inv, float o_scale) {
+    constexpr int NW = A3_NW, ROWB = QKV3_ROWB;
+    constexpr bool F16 = TERMS == 3;
+    constexpr int NPL = s3_planes(TERMS);
+    constexpr int PPW = 24 / NW;
+    using TT = A3Terms<TERMS>;
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[A3_KT * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[A3_KT * ROWB];
+
+    int qb, h, b;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = id & 7;
+        const int w = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+        qb = w % nqb;
+        h = (w / nqb) % H;
+        b = w / (nqb * H);
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int64_t hstride = (int64_t)Npad * ROWB;
+    const unsigned char* Qb = img + (((int64_t)0 * Bt + b) * H + h) * hstride;
+    const unsigned char* Kb = img + (((int64_t)1 * Bt + b) * H + h) * hstride;
+    const unsigned char* Vb = img + (((int64_t)2 * Bt + b) * H + h) * hstride;
+
+    const int q_row = qb * (NW * 32) + wave * 32 + l31;
+    bf16x8 qf[4][3];
+    {
+        const unsigned char* src = Qb + (int64_t)(q_row < N ? q_row : N - 1) * ROWB + hi * 16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) qf[s][p] = *reinterpret_cast<const bf16x8*>(src + p * 128 + s * 32);
+    }
+    auto dma = [&](const unsigned char* gsrc, unsigned char* ldst, int kt) {
+        const int last_row = N - 1 - kt * A3_KT;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + NW * i;
+            const int off = p * 1024 + lane * 16;
+            int row = off / ROWB;
+            const int within = off - row * ROWB;
+            row = row < last_row ? row : last_row;
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(gsrc + ((int64_t)kt * A3_KT + row) * ROWB + within), AVD_LDS_PTR(ldst + p * 1024), 16,
+                                             0, 0);
+        }
+    };
+    auto sync = [&]() {
+        __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's DMA pieces have landed
+        __syncthreads();
+    };
+
+    const int nkt = (N + A3_KT - 1) / A3_KT;
+    const bool ragged = (N & (A3_KT - 1)) != 0;
+    dma(Kb, Ks, 0);
+    dma(Vb, Vs, 0);
+    sync();
+
+    const bool active = qb * (NW * 32) + wave * 32 < n_query;   // wave-uniform: a wave of padding rows only loads
+    if (!active) {
+        // same barriers and the same DMA duty as the computing waves
+        sync();
+        if (nkt > 1) dma(Kb, Ks, 1);
+        sync();
+        for (int kt = 0; kt < nkt; ++kt) {
+            sync();
+            if (kt + 2 < nkt) dma(Kb, Ks, kt + 2);
+            if (kt + 1 < nkt) {
+                sync();
+                dma(Vb, Vs, kt + 1);
+            }
+        }
+        return;
+    }
+
+    const int ksw = (l31 >> 1) & 7;
+    const int k_rd = l31 * ROWB;
+    const int i16 = lane & 15, cb = (lane >> 4) & 1;
+    const int v_q = i16 >> 2, v_p = i16 & 3;
+#define A3_SB() __builtin_amdgcn_sched_barrier(0)
+
+    f32x16 o0, o1, sc0, sc1, sn0, sn1;        // O^T halves; scores / probabilities of the current tile; scores of the next tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; sc0[r] = 0.f; sc1[r] = 0.f; sn0[r] = 0.f; sn1[r] = 0.f; }
+    float m_run = A3_NEG, l_run = 0.f;
+
+    // the two MFMAs (keys 0..31 and 32..63) of term t of d-step s of S^T = K Q^T, with that d-step's K fragments read in front of term 0
+    bf16x8 ka[3], kb2[3];
+    auto s_slot = [&](f32x16& d0, f32x16& d1, int s, int t) {
+        if (t == 0) {
+            const int ch = ((2 * s + hi) ^ ksw) << 4;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                ka[p] = *reinterpret_cast<const bf16x8*>(Ks + k_rd + p * 128 + ch);
+                kb2[p] = *reinterpret_cast<const bf16x8*>(Ks + k_rd + 32 * ROWB + p * 128 + ch);
+            }
+        }
+        d0 = mma16<F16>(ka[TT::PA[t]], qf[s][TT::PB[t]], d0);
+        d1 = mma16<F16>(kb2[TT::PA[t]], qf[s][TT::PB[t]], d1);
+    };
+    auto mask_tail = [&](f32x16& d0, f32x16& d1, int kt) {      // ragged last tile: keys >= N contribute nothing
+        const int kbase = kt * A3_KT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kbase + mfma32_row(r, hi);
+            if (key >= N) d0[r] = A3_NEG;
+            if (key + 32 >= N) d1[r] = A3_NEG;
+        }
+    };
+    // running maximum over this lane's query column (both lane halves), in the exp2 domain (f16x2: scores still carry the image scale^2)
+    auto tile_max = [&](const f32x16& d0, const f32x16& d1) {
+        float mt = fmaxf(d0[0], d1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mt = fmaxf(mt, fmaxf(d0[r], d1[r]));
+        if constexpr (F16) mt *= s_inv2;
+        return fmaxf(mt, __shfl_xor(mt, 32, 64));
+    };
+
+    // ---- prologue: S(0) with nothing beside it, K(1) on its way while its maximum is taken ----
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < TT::N; ++t) s_slot(sc0, sc1, s, t);
+    if (nkt == 1 && ragged) mask_tail(sc0, sc1, 0);
+    sync();
+    if (nkt > 1) dma(Kb, Ks, 1);
+    float m_new = fmaxf(m_run, tile_max(sc0, sc1));
+    sync();
+
+    u32x4 pf[2][3];               // P fragments (planes) of two consecutive 16-key groups
+    // pair e (two of the eight probabilities) of key group g = (kb, t) of sc0 / sc1, split into planes: dword e of every plane
+    auto split_pair = [&](int g, int e, u32x4 (&dst)[3]) {
+        const float a = (g >> 1) ? sc1[8 * (g & 1) + 2 * e] : sc0[8 * (g & 1) + 2 * e];
+        const float c = (g >> 1) ? sc1[8 * (g & 1) + 2 * e + 1] : sc0[8 * (g & 1) + 2 * e + 1];
+        if constexpr (F16) {
+            const unsigned int hh = pk_f16(a, c);
+            const f32x2 u = unpk_f16(hh);
+            dst[0][e] = hh;
+            dst[1][e] = pk_f16(a - u[0], c - u[1]);
+        } else {
+            const unsigned int hh = pk_bf16(a, c);
+            const float ra = a - bf16_lo(hh), rc = c - bf16_hi(hh);
+            dst[0][e] = hh;
+            if constexpr (NPL > 1) {
+                const unsigned int mm = pk_bf16(ra, rc);
+                dst[1][e] = mm;
+                dst[2][e] = pk_bf16(ra - bf16_lo(mm), rc - bf16_hi(mm));
+            }
+        }
+    };
+    // the MFMAs of (key group g, d block db, term tt) of O^T += V^T P^T, that block's V fragments read in front of term 0
+    bf16x8 vf[3];
+    auto pv_slot = [&](int g, int db, int tt, const u32x4 (&P)[3]) {
+        if (tt == 0) {
+            const int key0 = 16 * g + 4 * hi + v_q;
+            const int sw = ((key0 >> 1) & 1) << 2;
+            const int chunk = 4 * db + 2 * cb + (v_p >> 1);
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)AVD_LDS_PTR(
+                    Vs + key0 * ROWB + p * 128 + ((chunk ^ sw) << 4) + 8 * (v_p & 1)));
+                const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)AVD_LDS_PTR(
+                    Vs + (key0 + 8) * ROWB + p * 128 + ((chunk ^ sw) << 4) + 8 * (v_p & 1)));
+                const u32x2 a = __builtin_bit_cast(u32x2, lo), c2 = __builtin_bit_cast(u32x2, up);
+                const u32x4 w = {a[0], a[1], c2[0], c2[1]};
+                vf[p] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+        if (db == 0) o0 = mma16<F16>(vf[TT::PA[tt]], __builtin_bit_cast(bf16x8, P[TT::PB[tt]]), o0);
+        else o1 = mma16<F16>(vf[TT::PA[tt]], __builtin_bit_cast(bf16x8, P[TT::PB[tt]]), o1);
+    };
+
+    // one tile; MORE (compile time): a tile kt+1 exists.  The last tile is a separate instantiation behind the loop — as the two arms of
+    // one `if (more)` the compiler hoists the VALU items, common to both arms, in front of the branch and the schedule is gone.
+    auto tile = [&](auto more_tag, int kt) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        // ================= phase A: S(kt+1) beside the exponentials of tile kt =================
+        const float m_sub = F16 ? m_new - 15.0f : m_new;        // f16x2: probabilities are kept at scale 2^15 (sum and planes alike)
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+        float ps = 0.f;
+        // VALU items of this phase: 0..15 two exponentials each (register r of both halves), 16..23 four O multiplies each, 24..27 one
+        // pair each of the split of key group 0 — dealt out over the 4 x TT::N MFMA slots
+        constexpr int NSLOT_A = 4 * TT::N, NITEM_A = 28;
+        auto item_a = [&](int w) {
+            if (w < 16) {
+                const float e0 = F16 ? sc0[w] * s_inv2 : sc0[w], e1 = F16 ? sc1[w] * s_inv2 : sc1[w];
+                sc0[w] = __builtin_amdgcn_exp2f(e0 - m_sub);
+                sc1[w] = __builtin_amdgcn_exp2f(e1 - m_sub);
+                ps += sc0[w] + sc1[w];
+            } else if (w < 24) {
+                const int r0 = (w - 16) * 2;
+                o0[r0] *= alpha; o0[r0 + 1] *= alpha;
+                o1[r0] *= alpha; o1[r0 + 1] *= alpha;
+            } else {
+                split_pair(0, w - 24, pf[0]);
+            }
+        };
+        if constexpr (MORE) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sn0[r] = 0.f; sn1[r] = 0.f; }
+#pragma unroll
+            for (int sl = 0; sl < NSLOT_A; ++sl) {
+                A3_SB();
+                s_slot(sn0, sn1, sl / TT::N, sl % TT::N);
+#pragma unroll
+                for (int w = sl * NITEM_A / NSLOT_A; w < (sl + 1) * NITEM_A / NSLOT_A; ++w) item_a(w);
+            }
+            A3_SB();
+            if (kt + 2 == nkt && ragged) mask_tail(sn0, sn1, kt + 1);
+        } else {
+#pragma unroll
+            for (int w = 0; w < NITEM_A; ++w) item_a(w);
+        }
+        l_run = l_run * alpha + ps;
+        // V(kt) has landed (issued a phase ago); every wave is past its reads of K(kt+1)
+        sync();
+        if (kt + 2 < nkt) dma(Kb, Ks, kt + 2);
+
+        // ================= phase B: O += V(kt) P(kt) beside the remaining splits and the maximum of tile kt+1 =================
+        // slots: (g, db, tt) in that order, 2 x TT::N per key group.  Items: the split of group g+1, one pair behind each of the first
+        // slots of group g, and the 16 max pairs of s(kt+1) spread over the last group's slots
+        float mt = A3_NEG;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+#pragma unroll
+            for (int sl = 0; sl < 2 * TT::N; ++sl) {
+                A3_SB();
+                pv_slot(g, sl / TT::N, sl % TT::N, pf[g & 1]);
+                if (g < 3) {        // the split of the next group: its four pairs behind the first slots of this group
+                    constexpr int SPS = 2 * TT::N >= 4 ? 1 : 2;      // pairs per slot (one-term mode: two slots per group)
+#pragma unroll
+                    for (int e = sl * SPS; e < (sl + 1) * SPS && e < 4; ++e) split_pair(g + 1, e, pf[(g + 1) & 1]);
+                }
+                if (MORE && g == 3) {
+#pragma unroll
+                    for (int w = sl * 16 / (2 * TT::N); w < (sl + 1) * 16 / (2 * TT::N); ++w) mt = fmaxf(mt, fmaxf(sn0[w], sn1[w]));
+                }
+            }
+        }
+        A3_SB();
+        if constexpr (MORE) {
+            if constexpr (F16) mt *= s_inv2;
+            mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+            m_new = fmaxf(m_run, mt);
+            sc0 = sn0;
+            sc1 = sn1;
+            // K(kt+2) has landed; every wave is past its reads of V(kt)
+            sync();
+            dma(Vb, Vs, kt + 1);
+        }
+    };
+    {
+        int kt = 0;
+        for (; kt + 1 < nkt; ++kt) tile(std::integral_constant<bool, true>{}, kt);
+        tile(std::integral_constant<bool, false>{}, kt);
+    }
+#undef A3_SB
+
+    // ---- normalise and store: lane (q, hi) holds O[q][8 g + 4 hi + (0..3)] in regs 4g..4g+3 of o0 (d < 32) / o1 ----
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = F16 ? v_inv / l_tot : 1.0f / l_tot;
+    const int d = H * A3_DH;
+    if constexpr (SPLIT_OUT) {
+        float ch[8][4];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ch[g4][e] = o0[4 * g4 + e] * inv;
+                ch[4 + g4][e] = o1[4 * g4 + e] * inv;
+            }
+        unsigned char* o3 = reinterpret_cast<unsigned char*>(out);
+#pragma unroll
+        for (int c = 0; c < 8; c += 2) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float send = hi ? ch[c][e] : ch[c + 1][e];
+                const float recv = __shfl_xor(send, 32, 64);
+                v[e] = hi ? recv : ch[c][e];
+                v[4 + e] = hi ? ch[c + 1][e] : recv;
+            }
+            if (q_row < n_query) {
+                if constexpr (F16) store_split8_h2(o3, (int64_t)b * N + q_row, h * A3_DH + 8 * (c + hi), d, v, o_scale);
+                else store_split8(o3, (int64_t)b * N + q_row, h * A3_DH + 8 * (c + hi), d, v);
+            }
+        }
+    } else if (q_row < n_query) {
+        float* dst = out + ((int64_t)b * N + q_row) * d + h * A3_DH + 4 * hi;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            f32x4 a = {o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv};
+            f32x4 c = {o1[4 * g4] * inv, o1[4 * g4 + 1] * inv, o1[4 * g4 + 2] * inv, o1[4 * g4 + 3] * inv};
+            *reinterpret_cast<f32x4*>(dst + 8 * g4) = a;
+            *reinterpret_cast<f32x4*>(dst + 32 + 8 * g4) = c;
+        }
+    }
+}
+
 int64_t qkv3_bytes(int B, int N, int H) { return (int64_t)3 * B * H * qkv3_npad(N) * QKV3_ROWB; }
 
 // out3 != null: split3 image of the [B*N, H*64] result; otherwise fp32 out [B, N, H*64]
@@ -279,6 +599,15 @@ template <int TERMS>
 static void attn3_launch(const unsigned char* img, float* out, void* out3, int B, int N, int Npad, int H, int n_query, int nqb, hipStream_t st,
                          float img_scale, float out_scale) {
     const float s_inv2 = 1.0f / (img_scale * img_scale), v_inv = 1.0f / img_scale;
+    if (g_attn_pipe) {
+        if (out3)
+            hipLaunchKernelGGL((attn_bf16x3_pipe_kernel<true, TERMS>), dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, static_cast<float*>(out3),
+                               B, N, Npad, H, n_query, nqb, s_inv2, v_inv, out_scale);
+        else
+            hipLaunchKernelGGL((attn_bf16x3_pipe_kernel<false, TERMS>), dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, out, B, N, Npad, H,
+                               n_query, nqb, s_inv2, v_inv, out_scale);
+        return;
+    }
     if (out3)
         hipLaunchKernelGGL((attn_bf16x3_kernel<true, TERMS>), dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, static_cast<float*>(out3), B, N,
                            Npad, H, n_query, nqb, s_inv2, v_inv, out_scale);

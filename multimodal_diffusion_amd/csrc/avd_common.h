@@ -268,6 +268,7 @@ int layernorm_act_split3_f32(const float* x, const float* gamma, const float* be
 bool gemm_bf16x3_supported(int64_t M, int N, int K);
 int attn_f32_split3(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st);
 extern int g_s3_stagger;
+extern int g_attn_pipe;          // 1 (default): the split-operand attention as one software pipeline per wave (avd_tune_set "attn_pipe")
 extern int g_s3_m16;             // 1 (default): bf16x3 GEMMs on v_mfma_f32_16x16x32_bf16, two terms per MFMA; 0: 32x32x16 (avd_tune_set "s3_m16")
 extern int g_s3_w128;            // 1: the 8-wave bf16x3 blocks with an image epilogue run as 4 waves with a 128 x 128 wave tile (avd_tune_set "s3_w128")
 extern int g_s3_rt;              // rows per 8-wave block of the residual + image epilogue: 0 automatic, 7 = 224 rows, 8 = 256 rows (avd_tune_set "s3_rt")

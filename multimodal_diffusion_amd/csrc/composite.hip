@@ -582,6 +582,7 @@ extern "C" int avd_tune_set(const char* key, int64_t value) {
         return AVD_OK;
     }
     if (!strcmp(key, "s3_stagger")) { g_s3_stagger = (int)value; return AVD_OK; }
+    if (!strcmp(key, "attn_pipe")) { g_attn_pipe = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_tile")) { g_gemm_force_tile = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_stages")) { g_gemm_stages = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_min_rows")) { g_s3_min_rows = value; return AVD_OK; }

@@ -136,7 +136,7 @@ def test_core_f16x2_vs_oracle_and_f32(dev, full):
     ws, _ = full
     core2, _, _, _ = _full_modules(dev, ws)
     core32, _, _, _ = _full_modules(dev, ws)
-    core2.matmul = "f16x2"
+    core2.matmul, core32.matmul = "f16x2", "f32"
     x = torch.randn(40, 421, 512, generator=torch.Generator().manual_seed(12))
     y2 = core2(x.to(dev)).cpu()
     y32 = core32(x.to(dev)).cpu()
@@ -319,7 +319,7 @@ def test_f16x2_engine_follows_weight_updates(dev, full):
     ws, _ = full
     core, _, _, _ = _full_modules(dev, ws)
     ref_core, _, _, _ = _full_modules(dev, ws)
-    core.matmul = "f16x2"
+    core.matmul, ref_core.matmul = "f16x2", "f32"
     x = torch.randn(16, 421, 512, generator=torch.Generator().manual_seed(8)).to(dev)
     y0 = core(x)
     for c in (core, ref_core):
@@ -589,6 +589,7 @@ def test_vae_encode_f16x2(dev):
     vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval()
     vae.load_state_dict(split_weights(g)["w"], strict=False)
     vae = vae.to(dev)
+    vae.matmul = "f32"
     z32 = vae.encode(G(g["x"], dev)).cpu()
     vae.matmul = "f16x2"
     z2 = vae.encode(G(g["x"], dev)).cpu()
@@ -610,6 +611,7 @@ def test_vae_decode_f16x2_256(dev):
             if p.dim() == 1:
                 p.add_(0.1 * torch.randn_like(p))
     z = torch.randn(1, 8, 12, 32, 32, generator=torch.Generator().manual_seed(6)).to(dev)
+    vae.matmul = "f32"
     x32 = vae.decode(z)
     vae.matmul = "f16x2"
     x2 = vae.decode(z)
@@ -639,8 +641,8 @@ def test_block_stagger_changes_timing_only(dev, full):
 
 def test_fp8_attention_on_f16x2_images(dev, full):
     """BASELINE C5 as named (512x512, "fp8 MFMA attention"), with f16x2 projections: the e4m3 attention reads the f16x2 q|k|v image
-    and writes its result as an f16x2 image.  Reduced precision — the error against the fp32 oracle is reported and bounded loosely
-    (5e-2 of max|z|), and must be of the size the bf16x3 + fp8 combination has."""
+    and writes its result as an f16x2 image.  Reduced precision — the error against the fp32 oracle is reported and bounded at 2.2x the
+    measured 1.5e-3 of max|z|, and must be of the size the bf16x3 + fp8 combination has."""
     import multimodal_diffusion_amd as A
     ws, mods = full
     core, head, av, aa = mods
@@ -663,7 +665,7 @@ def test_fp8_attention_on_f16x2_images(dev, full):
         errs[(matmul, attn)] = rel_err(out[:1], ref)
     print(f"C5 step: {errs}")
     assert errs[("f16x2", "default")] < TOL
-    assert 1e-5 < errs[("f16x2", "fp8")] < 5e-2
+    assert 1e-5 < errs[("f16x2", "fp8")] < 3.3e-3         # measured 1.5e-3 (round 4)
     assert errs[("f16x2", "fp8")] < 2.0 * errs[("bf16x3", "fp8")]
 
 

@@ -688,7 +688,7 @@ def test_core_bf16x3_vs_oracle_and_f32(dev, full):
     ws, _ = full
     core3, _, _, _ = _full_modules(dev, ws)
     core32, _, _, _ = _full_modules(dev, ws)
-    core3.matmul = "bf16x3"
+    core3.matmul, core32.matmul = "bf16x3", "f32"
     x = torch.randn(40, 421, 512, generator=torch.Generator().manual_seed(12))
     y3 = core3(x.to(dev)).cpu()
     y32 = core32(x.to(dev)).cpu()
@@ -885,6 +885,7 @@ def test_vae_encode_bf16x3(dev):
     vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval()
     vae.load_state_dict(split_weights(g)["w"], strict=False)
     vae = vae.to(dev)
+    vae.matmul = "f32"
     z32 = vae.encode(G(g["x"], dev)).cpu()
     vae.matmul = "bf16x3"
     z3 = vae.encode(G(g["x"], dev)).cpu()
@@ -1650,13 +1651,16 @@ def test_attention_fp8_reported_error(dev, B, N, H):
     ref8 = (pq @ f8(v) / p.sum(-1, keepdim=True)).transpose(1, 2).reshape(B, N, d)
     err8 = rel_err(out.cpu()[:, :nq], ref8[:, :nq])
     print(f"fp8 attention B={B} N={N} H={H}: rel err vs fp64 {err:.3e}, vs fp64 on the e4m3 operands {err8:.3e}")
-    assert err < 0.15 and err8 < 0.04
+    # measured (round 4, GPU box): err 8.2e-2 / 7.7e-2 / 9.5e-2 / 8.9e-2 (operand quantisation on N(0, 1.5^2) data), err8 6.3e-3 / 1.1e-2 /
+    # 2.1e-2 / 1.6e-2 for N = 64 / 133 / 421 / 1573; the bounds sit at 1.3x resp. 2x of that — a wrong operand map inside a lane group is O(1)
+    bound, bound8 = {64: (0.11, 1.3e-2), 133: (0.10, 2.3e-2), 421: (0.125, 4.2e-2), 1573: (0.12, 3.3e-2)}[N]
+    assert err < bound and err8 < bound8
     assert torch.all(out[:, nq:] == 7.0)
 
 
 def test_fp8_attention_step_c5(dev, full):
     """BASELINE C5 geometry (512x512: 1536 + 37 tokens), B=8 per GPU, bf16x3 projections + fp8 attention: one CFG step against the
-    fp32 oracle on sample 0 — reported error, bound 5e-2 of max|z| (the fp32 paths sit at 4e-6)."""
+    fp32 oracle on sample 0 — reported error, bound 3e-3 of max|z| = 2.2x the measured 1.35e-3 (the fp32 paths sit at 2e-6)."""
     ws, mods = full
     import multimodal_diffusion_amd as A
     core, head, av, aa = mods
@@ -1677,7 +1681,7 @@ def test_fp8_attention_step_c5(dev, full):
         outs[attn] = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)).cpu()
     e_def, e_f8 = rel_err(outs["default"][:1], ref), rel_err(outs["fp8"][:1], ref)
     print(f"C5 step: bf16x3 attention rel err {e_def:.3e}, fp8 attention rel err {e_f8:.3e}")
-    assert e_def < TOL and 1e-5 < e_f8 < 5e-2
+    assert e_def < TOL and 1e-5 < e_f8 < 3e-3            # measured 1.35e-3 (round 4); the fp32-level paths sit at 2e-6
     with pytest.raises(ValueError):
         A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z_v.shape),
                         prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul="f32", attn="fp8")
