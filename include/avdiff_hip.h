@@ -51,10 +51,14 @@ int         avd_device_arch(char* buf, int buflen);
  * 256x256, 1 = 4-wave 256x128 blocks of the split-operand GEMMs), "s3_stagger" (first-generation stagger of co-resident 4-wave blocks,
  * x 1024 cycles; -1 automatic), "s3_min_rows" (smallest 2B*N that takes the split-operand kernels), "no_fold" (1 = keep RMSNorm as
  * separate kernels in avd_core_forward_f32, in every mode), "s3_m16" (1 default: bf16x3 GEMMs on v_mfma_f32_16x16x32_bf16 with two product
- * terms per instruction; 0: the 32x32x16 kernel), "s3_rt" (rows per 8-wave block of the bf16x3 residual + image epilogue: 0 automatic,
- * 7 = 224 rows, 8 = 256 rows; results are bit-identical), "s3_w128" (1 default: the bf16x3 residual + image GEMMs run as four waves
- * with a 128 x 128 wave tile and accumulators in AGPRs; 0: eight waves with 128 x 64 tiles; bit-identical), "s3_splitk" (K slices of the fc2 launch when its blocks cover at most half of the
- * CUs — small batches; 0 = never, default 4; partial sums are added in slice order by a reduction kernel, no atomics). */
+ * terms per instruction; 0: the 32x32x16 kernel), "s3_rt" (rows per block of the bf16x3 residual + image epilogue: 0 automatic,
+ * 7 = 224 rows, 8 = 256 rows, 6 = 192 rows (four-wave kernel only); results are bit-identical), "s3_w128" (1 default: the bf16x3 residual + image GEMMs run as four waves
+ * with a 128 x 128 wave tile and accumulators in AGPRs; 0: eight waves with 128 x 64 tiles; bit-identical), "s3_splitk" (largest number of K slices of the fc2 launch when its blocks
+ * fill at most half of the chip's block slots — small and mid-size batches; 0 = never, default and maximum 4; partial sums are added in
+ * slice order by a reduction kernel, no atomics), "attn_pipe" (1 default: the three-plane split-operand attention runs as one software
+ * pipeline per wave — the next tile's score MFMAs beside this tile's softmax; 0: the plain kernel everywhere, 2: the pipeline in every
+ * split mode), "core_trim" (1 default: the last block of avd_core_forward_f32 runs out_proj / fc1 / fc2 / the final norm on the caller's
+ * row window only; 0: on every row; the window's results are bit-identical). */
 int         avd_tune_set(const char* key, int64_t value);
 
 /* ---- a6: RMSNorm — avdiff/models/mmdt.py:33-42 (RMSNorm.forward)
@@ -324,7 +328,9 @@ int avd_attn_fwd_qkv_f16x2_f32(const void* qkv, float* out, void* out2, int B, i
 int64_t avd_core_workspace_bytes(const avd_core_weights* w, int B, int N);
 /* MMDiT.forward(x) -> y, x,y: [B,N,d] (y may alias x).  n_out_rows: number of leading rows per sample whose
  * output is needed (N = reference behaviour; fewer lets the last block skip dead rows when the caller only
- * consumes the first n_out_rows — the engine passes the target-row count). out_row0: first needed row.
+ * consumes the first n_out_rows — the engine passes the target-row count). out_row0: first needed row.  Rows of y outside
+ * [out_row0, out_row0 + n_out_rows) are unspecified: with the window at row 0 the last block's attention, out_proj, fc1, fc2 and the final
+ * norm run on the window's rows only (six-term bf16-plane path).
  * key_padding_mask: NULL or bytes [B,N], see avd_attn_fwd_f32.  A mask, or norm_kind 1 (LayerNorm), keeps the whole forward on the fp32
  * MFMA kernels whatever split_terms says — the split-operand attention takes no mask and the split producers are RMSNorm's; results
  * are the fp32 path's, at its speed.  attn_mode 1 (fp8 attention) with either of them is refused (AVD_EUNSUPPORTED). */

@@ -39,7 +39,7 @@ template <> struct A3Terms<3> { static constexpr int N = 3; static constexpr int
 template <bool SPLIT_OUT, int TERMS>   // SPLIT_OUT: the [B*N, H*64] result is written as a split3 image (A operand of out_proj)
 __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsigned char* __restrict__ img, float* __restrict__ out,
                                                                     int Bt, int N, int Npad, int H, int n_query, int nqb,
-                                                                    float s_inv2, float v_inv, float o_scale) {
+                                                                    float s_inv2, float v_inv, float o_scale, int out_tok) {
     // TERMS == 3 (f16x2 image of scale s): s_inv2 = 1 / s^2 takes the scores back to the exp2 domain, the probabilities are split
     // at scale 2^15 (p <= 1), v_inv = 1 / s undoes V's scale, o_scale is the scale of the image written (SPLIT_OUT)
     constexpr int NW = A3_NW, ROWB = QKV3_ROWB;
@@ -259,12 +259,12 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
                 v[4 + e] = hi ? ch[c + 1][e] : recv;
             }
             if (q_row < n_query) {
-                if constexpr (F16) store_split8_h2(o3, (int64_t)b * N + q_row, h * A3_DH + 8 * (c + hi), d, v, o_scale);
-                else store_split8(o3, (int64_t)b * N + q_row, h * A3_DH + 8 * (c + hi), d, v);
+                if constexpr (F16) store_split8_h2(o3, (int64_t)b * out_tok + q_row, h * A3_DH + 8 * (c + hi), d, v, o_scale);
+                else store_split8(o3, (int64_t)b * out_tok + q_row, h * A3_DH + 8 * (c + hi), d, v);
             }
         }
     } else if (q_row < n_query) {
-        float* dst = out + ((int64_t)b * N + q_row) * d + h * A3_DH + 4 * hi;
+        float* dst = out + ((int64_t)b * out_tok + q_row) * d + h * A3_DH + 4 * hi;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             f32x4 a = {o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv};
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Round 4: the same algorithm as ONE software pipeline per wave (attn_bf16x3_pipe_kernel, default; avd_tune_set "attn_pipe" 0 takes the
-// kernel above).  Why: in the kernel above a wave's 96 MFMAs per 64-key tile (3,072 matrix-pipe cycles, six terms) and its ~1,900 cycles
+// Round 4: the same algorithm as ONE software pipeline per wave (attn_bf16x3_pipe_kernel; default for the three-plane modes, avd_tune_set
+// "attn_pipe" 0 takes the kernel above everywhere, 2 this one everywhere).  Why: in the kernel above a wave's 96 MFMAs per 64-key tile (3,072 matrix-pipe cycles, six terms) and its ~1,900 cycles
 // of softmax / split VALU work run one after the other, and on a SIMD the two ADD (DESIGN.md 4.8 g): 0.32 of the MFMA peak with the pipe
 // 40 % busy.  A v_mfma_f32_32x32x16 occupies the SIMD's vector issue for 8 of its 32 cycles; the other 24 take up to five single-issue
 // VALU instructions of the SAME wave for free (MI355X_MICROARCH.md, cycle constants) — but only instructions that do not depend on the
@@ -293,7 +293,7 @@ int g_attn_pipe = getenv("AVD_ATTN_PIPE") ? atoi(getenv("AVD_ATTN_PIPE")) : 1;
 template <bool SPLIT_OUT, int TERMS>
 __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const unsigned char* __restrict__ img, float* __restrict__ out,
                                                                          int Bt, int N, int Npad, int H, int n_query, int nqb,
-                                                                         float s_inv2, float v_inv, float o_scale) {
+                                                                         float s_inv2, float v_inv, float o_scale, int out_tok) {
     constexpr int NW = A3_NW, ROWB = QKV3_ROWB;
     constexpr bool F16 = TERMS == 3;
     constexpr int NPL = s3_planes(TERMS);
@@ -476,18 +476,25 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
         // VALU items of this phase: 0..15 two exponentials each (register r of both halves), 16..23 four O multiplies each, 24..27 one
         // pair each of the split of key group 0 — dealt out over the 4 x TT::N MFMA slots
         constexpr int NSLOT_A = 4 * TT::N, NITEM_A = 28;
+        // Every item ends in an empty volatile statement that names its results: nothing in this phase consumes them, so without it the
+        // compiler sinks the whole item into the block of its first use (behind the barrier) and the MFMAs run alone again.
         auto item_a = [&](int w) {
             if (w < 16) {
                 const float e0 = F16 ? sc0[w] * s_inv2 : sc0[w], e1 = F16 ? sc1[w] * s_inv2 : sc1[w];
-                sc0[w] = __builtin_amdgcn_exp2f(e0 - m_sub);
-                sc1[w] = __builtin_amdgcn_exp2f(e1 - m_sub);
-                ps += sc0[w] + sc1[w];
+                float p0 = __builtin_amdgcn_exp2f(e0 - m_sub), p1 = __builtin_amdgcn_exp2f(e1 - m_sub);
+                ps += p0 + p1;
+                asm volatile("" : "+v"(p0), "+v"(p1), "+v"(ps));
+                sc0[w] = p0;
+                sc1[w] = p1;
             } else if (w < 24) {
                 const int r0 = (w - 16) * 2;
-                o0[r0] *= alpha; o0[r0 + 1] *= alpha;
-                o1[r0] *= alpha; o1[r0 + 1] *= alpha;
+                float a0 = o0[r0] * alpha, a1 = o0[r0 + 1] * alpha, c0 = o1[r0] * alpha, c1 = o1[r0 + 1] * alpha;
+                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(c0), "+v"(c1));
+                o0[r0] = a0; o0[r0 + 1] = a1;
+                o1[r0] = c0; o1[r0 + 1] = c1;
             } else {
                 split_pair(0, w - 24, pf[0]);
+                asm volatile("" : "+v"(pf[0][0][w - 24]), "+v"(pf[0][1][w - 24]), "+v"(pf[0][2][w - 24]));
             }
         };
         if constexpr (MORE) {
@@ -529,6 +536,7 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
                 if (MORE && g == 3) {
 #pragma unroll
                     for (int w = sl * 16 / (2 * TT::N); w < (sl + 1) * 16 / (2 * TT::N); ++w) mt = fmaxf(mt, fmaxf(sn0[w], sn1[w]));
+                    asm volatile("" : "+v"(mt));      // stays in this slot
                 }
             }
         }
@@ -576,12 +584,12 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
                 v[4 + e] = hi ? ch[c + 1][e] : recv;
             }
             if (q_row < n_query) {
-                if constexpr (F16) store_split8_h2(o3, (int64_t)b * N + q_row, h * A3_DH + 8 * (c + hi), d, v, o_scale);
-                else store_split8(o3, (int64_t)b * N + q_row, h * A3_DH + 8 * (c + hi), d, v);
+                if constexpr (F16) store_split8_h2(o3, (int64_t)b * out_tok + q_row, h * A3_DH + 8 * (c + hi), d, v, o_scale);
+                else store_split8(o3, (int64_t)b * out_tok + q_row, h * A3_DH + 8 * (c + hi), d, v);
             }
         }
     } else if (q_row < n_query) {
-        float* dst = out + ((int64_t)b * N + q_row) * d + h * A3_DH + 4 * hi;
+        float* dst = out + ((int64_t)b * out_tok + q_row) * d + h * A3_DH + 4 * hi;
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
             f32x4 a = {o0[4 * g4] * inv, o0[4 * g4 + 1] * inv, o0[4 * g4 + 2] * inv, o0[4 * g4 + 3] * inv};
@@ -597,27 +605,31 @@ int64_t qkv3_bytes(int B, int N, int H) { return (int64_t)3 * B * H * qkv3_npad(
 // out3 != null: split3 image of the [B*N, H*64] result; otherwise fp32 out [B, N, H*64]
 template <int TERMS>
 static void attn3_launch(const unsigned char* img, float* out, void* out3, int B, int N, int Npad, int H, int n_query, int nqb, hipStream_t st,
-                         float img_scale, float out_scale) {
+                         float img_scale, float out_scale, int out_tok) {
     const float s_inv2 = 1.0f / (img_scale * img_scale), v_inv = 1.0f / img_scale;
-    if (g_attn_pipe) {
+    // the pipelined kernel pays for the exact three-plane modes (C3: 175 -> 170 us per launch, profiles/r04_attn_pipe.txt); with two fp16
+    // planes or one bf16 plane a tile has half / a sixth of the MFMAs to hide the VALU work behind and the plain kernel is as fast or faster
+    if (g_attn_pipe == 2 || (g_attn_pipe == 1 && (TERMS == 6 || TERMS == 9))) {
         if (out3)
             hipLaunchKernelGGL((attn_bf16x3_pipe_kernel<true, TERMS>), dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, static_cast<float*>(out3),
-                               B, N, Npad, H, n_query, nqb, s_inv2, v_inv, out_scale);
+                               B, N, Npad, H, n_query, nqb, s_inv2, v_inv, out_scale, out_tok);
         else
             hipLaunchKernelGGL((attn_bf16x3_pipe_kernel<false, TERMS>), dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, out, B, N, Npad, H,
-                               n_query, nqb, s_inv2, v_inv, out_scale);
+                               n_query, nqb, s_inv2, v_inv, out_scale, out_tok);
         return;
     }
     if (out3)
         hipLaunchKernelGGL((attn_bf16x3_kernel<true, TERMS>), dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, static_cast<float*>(out3), B, N,
-                           Npad, H, n_query, nqb, s_inv2, v_inv, out_scale);
+                           Npad, H, n_query, nqb, s_inv2, v_inv, out_scale, out_tok);
     else
         hipLaunchKernelGGL((attn_bf16x3_kernel<false, TERMS>), dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, out, B, N, Npad, H, n_query, nqb,
-                           s_inv2, v_inv, out_scale);
+                           s_inv2, v_inv, out_scale, out_tok);
 }
 
 int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms, hipStream_t st, float img_scale,
-                float out_scale) {
+                float out_scale, int out_tokens) {
+    const int out_tok = out_tokens > 0 ? out_tokens : N;
+    AVD_REQUIRE(out_tok >= n_query, AVD_EINVAL, "attn_bf16x3: out_tokens=%d < n_query=%d", out_tok, n_query);
     AVD_REQUIRE(terms == 0 || terms == 6 || terms == 9 || terms == 1 || terms == 3, AVD_EINVAL, "attn_bf16x3: terms must be 6, 9, 1 or 3, got %d", terms);
     AVD_REQUIRE(img_scale > 0.f && img_scale < __builtin_inff() && out_scale > 0.f && out_scale < __builtin_inff() &&
                     img_scale * img_scale < __builtin_inff(), AVD_EINVAL, "attn_bf16x3: image scales must be positive and finite");
@@ -633,10 +645,10 @@ int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, i
     ProfScope prof(tag, 4.0 * (double)B * H * (double)n_query * N * A3_DH, st);
     const int Npad = qkv3_npad(N);
     const auto* img = static_cast<const unsigned char*>(qkv3);
-    if (terms == 9) attn3_launch<9>(img, out, out3, B, N, Npad, H, n_query, nqb, st, 1.f, 1.f);
-    else if (terms == 1) attn3_launch<1>(img, out, out3, B, N, Npad, H, n_query, nqb, st, 1.f, 1.f);
-    else if (terms == 3) attn3_launch<3>(img, out, out3, B, N, Npad, H, n_query, nqb, st, img_scale, out_scale);
-    else attn3_launch<6>(img, out, out3, B, N, Npad, H, n_query, nqb, st, 1.f, 1.f);
+    if (terms == 9) attn3_launch<9>(img, out, out3, B, N, Npad, H, n_query, nqb, st, 1.f, 1.f, out_tok);
+    else if (terms == 1) attn3_launch<1>(img, out, out3, B, N, Npad, H, n_query, nqb, st, 1.f, 1.f, out_tok);
+    else if (terms == 3) attn3_launch<3>(img, out, out3, B, N, Npad, H, n_query, nqb, st, img_scale, out_scale, out_tok);
+    else attn3_launch<6>(img, out, out3, B, N, Npad, H, n_query, nqb, st, 1.f, 1.f, out_tok);
     AVD_CHECK_LAUNCH("attn_bf16x3");
     return AVD_OK;
 }

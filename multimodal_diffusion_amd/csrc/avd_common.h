@@ -283,18 +283,21 @@ int64_t attn_fp8_ws_bytes(int B, int N, int H);
 int attn_fp8(const void* qkv3, void* ws, int64_t ws_bytes, float* out, void* out3, int B, int N, int H, int n_query, hipStream_t st,
              int img_terms = 6, float img_scale = 1.f, float out_scale = 1.f);
 // terms == 3: img_scale = scale of the qkv image, out_scale = scale of the image written to out3
+// out_tokens (0 = N): rows per sample of the output — n_query <= out_tokens: the last block writes its target rows compactly
 int attn_bf16x3(const void* qkv3, float* out, void* out3, int B, int N, int H, int n_query, int terms, hipStream_t st,
-                float img_scale = 1.f, float out_scale = 1.f);
+                float img_scale = 1.f, float out_scale = 1.f, int out_tokens = 0);
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
                 int act, int terms, hipStream_t st, float ab_scale = 1.f, float c_scale = 1.f, const float* ss_in = nullptr, float eps = 0.f,
-                float* ss_out = nullptr, const float* gamma = nullptr);
+                float* ss_out = nullptr, const float* gamma = nullptr, int r_seg = 0, int r_stride = 0);
+// r_seg > 0 (fp32 + image residual epilogue of the six-term 16x16x32 kernels): output row m adds R row (m / r_seg) * r_stride + m % r_seg
+bool gemm_bf16x3_resmap_supported(int terms);
 // gamma != null (f16x2 images, N == 512): C = A W^T + bias + R as fp32 AND C3 = image (scale c_scale) of RMSNorm(C; gamma, eps)
 bool gemm_bf16x3_rownorm_supported(int N, int terms);
 // split-K for residual GEMMs that cannot fill the chip (small batches): slices to use (0 = none), workspace, launch
 extern int g_s3_splitk;          // slices tried (0 off; avd_tune_set "s3_splitk")
 int gemm_bf16x3_splitk_slices(int64_t M, int N, int K, int terms);
 int64_t gemm_bf16x3_splitk_ws_floats(int64_t M, int N, int ns);
-constexpr int kS3SplitKMax = 8;  // upper bound of "s3_splitk" (workspaces are sized for it)
+constexpr int kS3SplitKMax = 4;  // upper bound of "s3_splitk" (workspaces are sized for it)
 int64_t gemm_bf16x3_splitk_ws_max_floats(int64_t M, int N, int K);
 int gemm_bf16x3_splitk(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, float* ss, int64_t M, int N,
                        int K, int terms, int ns, float* part, hipStream_t st);

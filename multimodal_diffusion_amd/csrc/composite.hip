@@ -149,6 +149,10 @@ static bool core_use_fold(const avd_core_weights* w) {
     return true;
 }
 
+// last-block dead-row elimination (avd_tune_set "core_trim" 0 switches it off: measurement aid / A-B in tests)
+static bool g_core_trim = getenv("AVD_CORE_TRIM") ? atoi(getenv("AVD_CORE_TRIM")) != 0 : true;
+static int64_t core_trim_floats(const avd_core_weights* w, int B, int N) { return (int64_t)B * N * w->d; }
+
 // the wide scratch of the bf16x3 path holds the qkv3 image, then the fc1 image
 static int64_t core_split_wide_bytes(const avd_core_weights* w, int B, int N) {
     const int64_t qkv3 = qkv3_bytes(B, N, w->n_heads), fc1 = split3_bytes((int64_t)B * N, w->mlp_hidden);
@@ -172,7 +176,8 @@ static int64_t core_ws_bytes(const avd_core_weights* w, int B, int N) {
                          : core_split_rownorm_capable(w) ? align_up(split3_bytes(M, w->d)) : 0;        // the normalised stream's image
     // split-K partial sums of fc2 for batches that cannot fill the chip (folded bf16-plane path only), at the largest slice count
     const int64_t sk_b = core_split_fold_capable(w) ? align_up(gemm_bf16x3_splitk_ws_max_floats(M, w->d, w->mlp_hidden) * 4) : 0;
-    const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d)) + align_up(f8_b) + fold_b + sk_b;
+    const int64_t trim_b = core_split_fold_capable(w) ? align_up(core_trim_floats(w, B, N) * 4) : 0;      // compact stream of the last block
+    const int64_t split_path = align_up(wide_b) + align_up(split3_bytes(M, w->d)) + align_up(f8_b) + fold_b + sk_b + trim_b;
     return split_path > fp32_path ? split_path : fp32_path;
 }
 
@@ -246,12 +251,30 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
             float* ss = cs.take(M * (d / 64));                           // its rows' sums of squares, [M][d / 64]
             const int ns = gemm_bf16x3_splitk_slices(M, d, hid, terms);
             float* part = ns ? cs.take(gemm_bf16x3_splitk_ws_floats(M, d, ns)) : nullptr;
+            // dead-row elimination in the LAST block (sample_clip.py:375,379 consume the target rows only): its attention already
+            // computes only the caller's row window; when that window starts at row 0 the attention writes those rows compactly and
+            // out_proj / fc1 / fc2 / the final norm run on B * n_out_rows rows instead of B * N (C3: 384 of 421)
+            const bool trim = g_core_trim && out_row0 == 0 && n_out_rows < N && w->attn_mode == 0 && gemm_bf16x3_resmap_supported(terms);
+            float* yc = cs.take(core_trim_floats(w, B, N));              // compact fp32 stream of the last block (sized whether or not it is used)
             AVD_REQUIRE(cs.ok, AVD_EWORKSPACE, "core: workspace carve %lld > %lld bytes", (long long)cs.used, (long long)cs.cap);
             if (int rc = split3_rows_f32(cur, rd, hx, M, d, st, 0.f, ss)) return rc;
             for (int l = 0; l < w->n_layers; ++l) {
                 const avd_block_weights& b = w->blocks[l];
                 const bool last = l == w->n_layers - 1;
                 const int nq = (last && out_row0 == 0) ? n_out_rows : N;
+                if (last && trim) {
+                    const int64_t Mc = (int64_t)B * nq;
+                    if (int rc = gemm_bf16x3_qkv3(hx, b.in_proj_weight3n, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, terms, st,
+                                                  1.f, 1.f, ss, w->norm_eps)) return rc;
+                    if (int rc = attn_bf16x3(qkv, nullptr, hs, B, N, H, nq, terms, st, 1.f, 1.f, nq)) return rc;       // rows b * nq + q
+                    if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, yc, hx, Mc, d, d, AVD_ACT_NONE, terms, st, 1.f, 1.f,
+                                             nullptr, 0.f, ss, nullptr, nq, N)) return rc;                                  // residual rows b * N + q
+                    if (int rc = gemm_bf16x3(hx, b.fc1_weight3n, b.fc1_bias, nullptr, nullptr, wide3, Mc, hid, d, AVD_ACT_GELU, terms, st, 1.f, 1.f,
+                                             ss, w->norm_eps)) return rc;
+                    if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, yc, yc, nullptr, Mc, d, hid, AVD_ACT_NONE, terms, st)) return rc;
+                    // final norm from the compact rows into the caller's [B, N, d] layout (rows outside the window stay as they were)
+                    return rmsnorm_f32(yc, rd, w->final_norm_scale, y, RowMap{d, nq, (int64_t)N * d}, Mc, d, w->norm_eps, st);
+                }
                 if (int rc = gemm_bf16x3_qkv3(hx, b.in_proj_weight3n, b.in_proj_bias, qkv, M, N, H, d, scale * 1.4426950408889634f, terms, st,
                                               1.f, 1.f, ss, w->norm_eps)) return rc;
                 if (w->attn_mode == 1) {
@@ -583,6 +606,7 @@ extern "C" int avd_tune_set(const char* key, int64_t value) {
     }
     if (!strcmp(key, "s3_stagger")) { g_s3_stagger = (int)value; return AVD_OK; }
     if (!strcmp(key, "attn_pipe")) { g_attn_pipe = (int)value; return AVD_OK; }
+    if (!strcmp(key, "core_trim")) { g_core_trim = value != 0; return AVD_OK; }
     if (!strcmp(key, "gemm_tile")) { g_gemm_force_tile = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_stages")) { g_gemm_stages = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_min_rows")) { g_s3_min_rows = value; return AVD_OK; }

@@ -199,6 +199,9 @@ struct S3Args {
     float* ss_out;
     float ss_sqrt_d, ss_eps;
     const float* gamma;         // EPI_RES_NORM: the norm's scale vector [N]; ss_sqrt_d = sqrt(N), ss_eps as above
+    // EPI_RES_IMG on the 16x16x32 kernels: residual rows in groups — output row m adds R row (m / r_seg) * r_stride + m % r_seg
+    // (r_seg == 0: R row m).  The last block of the core runs on its target rows only: outputs compact, residual stream not.
+    int r_seg, r_stride;
 #ifdef AVD_S3_STAMPS            // diagnostic build only (tools/micro/s3_stamps.py), never in the product library
     unsigned long long* dbg;
 #endif
@@ -1003,6 +1006,13 @@ __device__ __forceinline__ void s3_epilogue_img16(const S3Args& g, f32x4t (&acc)
             qsw = qkv3_swizzle(nbase / (g.heads * 64), (int)tok);
         }
         [[maybe_unused]] float ssq = 0.f;
+        [[maybe_unused]] int64_t rrow = m;        // EPI_RES_IMG: row of the residual operand
+        if constexpr (EPI == S3_EPI_RES_IMG) {
+            if (g.r_seg > 0 && m < g.M) {
+                const unsigned sgi = (unsigned)m / (unsigned)g.r_seg;
+                rrow = (int64_t)sgi * g.r_stride + ((unsigned)m - sgi * (unsigned)g.r_seg);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float v[8];
@@ -1028,7 +1038,7 @@ __device__ __forceinline__ void s3_epilogue_img16(const S3Args& g, f32x4t (&acc)
                 }
             } else if constexpr (EPI == S3_EPI_RES_IMG) {
                 if (S3_ROW_OK(m)) {
-                    const float* rp = g.R + m * g.N + n;
+                    const float* rp = g.R + rrow * g.N + n;
                     const f32x4 r0 = *reinterpret_cast<const f32x4*>(rp), r1 = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = (v[e] + bv[j][e]) + (e < 4 ? r0[e] : r1[e - 4]);
@@ -1295,7 +1305,7 @@ template <int EPI, int RT>
 __global__ __launch_bounds__(256, 1) void gemm_bf16x3_w128_kernel(S3Args g) {
     constexpr int BM = 32 * RT, BN = 256, WM = 16 * RT, PS = 256 * 32, STAGE = 6 * PS, NST = 3, PPW = 12;
     static_assert(EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG, "register image epilogues only");
-    static_assert(RT == 8 || RT == 7, "row tiles per wave");
+    static_assert(RT == 8 || RT == 7 || RT == 6, "row tiles per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
     [[maybe_unused]] const unsigned long long t_entry = S3_T(), rt_entry = S3_RT();
@@ -1357,7 +1367,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16x3_w128_kernel(S3Args g) {
         }
     }
     const unsigned lane16 = (unsigned)lane * 16u;
+    // (A pieces of the 32-row groups past the block's 32 RT rows are never read: not moved)
     auto issue_piece = [&](int i, int kt, int buf) {
+        const int P = wave * PPW + i;       // wave-uniform
+        if (RT < 8 && P < 24 && (P & 7) >= RT) return;
         __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(rbase[i] + (int64_t)kt * S3_CHUNK + lane16), AVD_LDS_PTR(smem3 + (buf * STAGE + rdst[i])), 16, 0, 0);
     };
 
@@ -1472,13 +1485,14 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16x3_w128_kernel(S3Args g) {
     [[maybe_unused]] const unsigned long long t_end = S3_T();
     int lane_e = lane;
     // the last MFMAs have written their AGPRs before the epilogue reads them: the wait states are one statement with the tiles of the
-    // last two MFMA groups (row tiles 6 and 7: RT = 7 blocks skip tile 7) as read-write operands, so no accumulator read of the
-    // epilogue can be scheduled in front of it (MFMAs retire in order: older tiles are complete once these are)
+    // last two MFMA groups (row tiles RT - 2 and RT - 1) as read-write operands, so no accumulator read of the epilogue can be scheduled
+    // in front of it (MFMAs retire in order: older tiles are complete once these are)
     asm volatile("s_nop 15\n\ts_nop 15"
-                 : "+v"(lane_e), "+a"(acc[0][6][0]), "+a"(acc[0][6][1]), "+a"(acc[0][6][2]), "+a"(acc[0][6][3]), "+a"(acc[1][6][0]),
-                   "+a"(acc[1][6][1]), "+a"(acc[1][6][2]), "+a"(acc[1][6][3]), "+a"(acc[0][7][0]), "+a"(acc[0][7][1]), "+a"(acc[0][7][2]),
-                   "+a"(acc[0][7][3]), "+a"(acc[1][7][0]), "+a"(acc[1][7][1]), "+a"(acc[1][7][2]), "+a"(acc[1][7][3]));
-    // (row tiles 0..5 were last written >= 16 MFMAs = 256 issue cycles before the loop's final sched_barrier, above which nothing of the
+                 : "+v"(lane_e), "+a"(acc[0][RT - 2][0]), "+a"(acc[0][RT - 2][1]), "+a"(acc[0][RT - 2][2]), "+a"(acc[0][RT - 2][3]),
+                   "+a"(acc[1][RT - 2][0]), "+a"(acc[1][RT - 2][1]), "+a"(acc[1][RT - 2][2]), "+a"(acc[1][RT - 2][3]), "+a"(acc[0][RT - 1][0]),
+                   "+a"(acc[0][RT - 1][1]), "+a"(acc[0][RT - 1][2]), "+a"(acc[0][RT - 1][3]), "+a"(acc[1][RT - 1][0]), "+a"(acc[1][RT - 1][1]),
+                   "+a"(acc[1][RT - 1][2]), "+a"(acc[1][RT - 1][3]));
+    // (the other row tiles were last written >= 16 MFMAs = 256 issue cycles before the loop's final sched_barrier, above which nothing of the
     // epilogue can be scheduled: they need no wait states.  Naming all 64 tiles here as well made the register allocator spill.)
     s3_epilogue_img16<EPI, RT>(g, acc[0], (int64_t)bm * BM + wm * WM, bn * BN + wn * 128, lane_e);
     s3_epilogue_img16<EPI, RT>(g, acc[1], (int64_t)bm * BM + wm * WM, bn * BN + wn * 128 + 64, lane_e);
@@ -1733,15 +1747,22 @@ static int launch_s3t(const S3Args& a, hipStream_t st) {
         if (g_s3_m16) {
             if (s3_tile_for(EPI, a.M, a.N)) return launch_s3w16<EPI, 4>(a, st);
             constexpr bool TR = EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG;
-            bool rt7 = false;
+            bool rt7 = false, rt6 = false;
             if constexpr (EPI == S3_EPI_RES_IMG) {
-                // 224-row blocks when they need fewer generations of blocks x rows than 256-row blocks (one block per CU)
+                // 224-row (192-row) blocks when they need fewer generations of blocks x rows than 256-row blocks (one block per CU)
                 const int64_t cu = s3_cu_count() > 0 ? s3_cu_count() : 256, nbn = a.N / 256;
                 const int64_t g8 = ((a.M + 255) / 256 * nbn + cu - 1) / cu * 8, g7 = ((a.M + 223) / 224 * nbn + cu - 1) / cu * 7;
-                rt7 = g_s3_rt == 7 || (g_s3_rt != 8 && g7 < g8);
+                const int64_t g6 = ((a.M + 191) / 192 * nbn + cu - 1) / cu * 6;
+                rt6 = g_s3_w128 && (g_s3_rt == 6 || (g_s3_rt == 0 && g6 < g7 && g6 < g8));       // 192 rows: the four-wave kernel only
+                rt7 = !rt6 && (g_s3_rt == 7 || (g_s3_rt != 8 && g7 < g8));
             }
             if constexpr (TR) {
-                if (g_s3_w128) return rt7 ? launch_s3w128<EPI, 7>(a, st) : launch_s3w128<EPI, 8>(a, st);
+                if (g_s3_w128) {
+                    if constexpr (EPI == S3_EPI_RES_IMG) {
+                        if (rt6) return launch_s3w128<EPI, 6>(a, st);
+                    }
+                    return rt7 ? launch_s3w128<EPI, 7>(a, st) : launch_s3w128<EPI, 8>(a, st);
+                }
             }
             if constexpr (EPI == S3_EPI_RES_IMG) {
                 if (rt7) return launch_s3w16<EPI, 8, 7>(a, st);
@@ -1772,9 +1793,13 @@ static int launch_s3(const S3Args& a, hipStream_t st) {
 // otherwise fp32 row-major into C (act NONE; residual optional, may alias C).
 // Folded RMSNorm (see S3Args): ss_in -> image outputs scale their rows by 1 / (||row of the un-normalised A|| / sqrt(K) + eps);
 // C, C3, R and ss_out all given -> the new residual stream as fp32, as an image and as sums of squares in one epilogue.
+bool gemm_bf16x3_resmap_supported(int terms) { return (terms == 0 || terms == 6) && g_s3_m16 != 0; }
+
 int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* R, float* C, void* C3, int64_t M, int N, int K,
                 int act, int terms, hipStream_t st, float ab_scale, float c_scale, const float* ss_in, float eps, float* ss_out,
-                const float* gamma) {
+                const float* gamma, int r_seg, int r_stride) {
+    AVD_REQUIRE(r_seg == 0 || (r_seg > 0 && r_stride >= r_seg && ss_out && gemm_bf16x3_resmap_supported(terms) && M < (1ll << 31)), AVD_EUNSUPPORTED,
+                "gemm_bf16x3: a residual row map needs the fp32 + image residual epilogue of the six-term 16x16x32 kernels");
     AVD_REQUIRE(A3 && W3 && (C || C3), AVD_EINVAL, "gemm_bf16x3: null pointer");
     AVD_REQUIRE(!gamma || (gemm_bf16x3_rownorm_supported(N, terms) && C && C3 && R && bias && !ss_in && !ss_out && act == AVD_ACT_NONE && aligned16(gamma)),
                 AVD_EUNSUPPORTED, "gemm_bf16x3: the residual + RMSNorm epilogue needs N == 512, f16x2 images, fp32 and image outputs, bias and residual");
@@ -1789,7 +1814,7 @@ int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* 
                 "gemm_bf16x3: pointers must be 16-byte aligned");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, R, C,
              static_cast<unsigned char*>(C3), M, N, K, 0, 0, 0, 0, 0, 0, 0.f, 0, 0, terms, 1.0f / ab_scale, c_scale,
-             ss_in, ss_out, (float)sqrt((double)K), eps, gamma};
+             ss_in, ss_out, (float)sqrt((double)K), eps, gamma, r_seg, r_stride};
     if (gamma) {
         a.ss_sqrt_d = (float)sqrt((double)N);
         return launch_s3<S3_EPI_RES_NORM>(a, st);
@@ -1848,21 +1873,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
 }
 
-// K slices for a residual GEMM of [M][N] over K, 0 = do not split: only when the 256x128 blocks cover at most half of the CUs
-// and a slice keeps >= 32 k-steps.  avd_tune_set "s3_splitk" (AVD_S3_SPLITK): 0 off, else the slice count tried (default 4).
+// K slices for a residual GEMM of [M][N] over K, 0 = do not split.  A launch of 256 x 128 blocks (two resident per CU) that fills at most
+// half of the chip's block slots is cut into the largest power-of-two number of K slices (<= "s3_splitk", default 4) that still fits
+// the slots in ONE generation and leaves a slice >= 32 k-steps: C2 (3,904 rows) fc2 64 blocks -> 4 slices; the reference's shipped
+// 128 x 128 geometry at batch 32 (8,512 rows) 136 blocks -> 2 slices (round 4; the slices run on the 32x32x16 kernel in every bf16-plane
+// mode, the six-term one included).  avd_tune_set "s3_splitk" (AVD_S3_SPLITK): 0 off, else the largest slice count tried.
 int g_s3_splitk = [] { const int v = getenv("AVD_S3_SPLITK") ? atoi(getenv("AVD_S3_SPLITK")) : 4; return v < 0 ? 0 : v > kS3SplitKMax ? kS3SplitKMax : v; }();
+static bool splitk_shape_ok(int64_t M, int N, int K) {
+    if (N % 128 || K % 32 || K / 2 < 512) return false;
+    const int64_t slots = 2 * (int64_t)s3_cu_count();
+    return (M + 255) / 256 * (N / 128) * 2 <= slots;
+}
 int gemm_bf16x3_splitk_slices(int64_t M, int N, int K, int terms) {
-    const int ns = g_s3_splitk;
-    if (ns < 2 || terms == 3 || ((terms == 0 || terms == 6) && g_s3_m16) || N % 128 || K % (16 * ns) || K / ns < 512) return 0;
-    const int cu = s3_cu_count();
-    return (M + 255) / 256 * (N / 128) * 2 <= cu ? ns : 0;
+    if (g_s3_splitk < 2 || terms == 3 || !splitk_shape_ok(M, N, K)) return 0;
+    const int64_t slots = 2 * (int64_t)s3_cu_count(), blocks = (M + 255) / 256 * (N / 128);
+    int ns = 1;
+    while (ns * 2 <= g_s3_splitk && blocks * ns * 2 <= slots && K % (32 * ns) == 0 && K / (ns * 2) >= 512) ns *= 2;
+    return ns >= 2 ? ns : 0;
 }
 int64_t gemm_bf16x3_splitk_ws_floats(int64_t M, int N, int ns) { return (int64_t)ns * M * N; }
-// the most a split-K launch of this shape can ever ask for, whatever the tunables (s3_splitk <= kS3SplitKMax, s3_m16) say: sizing only
+// the most a split-K launch of this shape can ever ask for, whatever the tunables say (s3_splitk <= kS3SplitKMax): sizing only
 int64_t gemm_bf16x3_splitk_ws_max_floats(int64_t M, int N, int K) {
-    if (N % 128 || K % 32 || K / 2 < 512) return 0;
-    const int cu = s3_cu_count();
-    return (M + 255) / 256 * (N / 128) * 2 <= cu ? gemm_bf16x3_splitk_ws_floats(M, N, kS3SplitKMax) : 0;
+    return splitk_shape_ok(M, N, K) ? gemm_bf16x3_splitk_ws_floats(M, N, kS3SplitKMax) : 0;
 }
 
 // C = A W^T + bias + R (fp32), optionally C3 = operand image of C and ss = its rows' sums of squares; bf16-plane images
@@ -1875,7 +1907,7 @@ int gemm_bf16x3_splitk(const void* A3, const void* W3, const float* bias, const 
     AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(C) && aligned16(C3) && aligned16(bias) && aligned16(R) && aligned16(part),
                 AVD_EUNSUPPORTED, "gemm_bf16x3_splitk: pointers must be 16-byte aligned");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), nullptr, nullptr, part, nullptr, M, N, K / ns,
-             0, 0, 0, 0, 0, 0, 0.f, 0, 0, terms, 1.0f, 1.0f, nullptr, nullptr, 1.0f, 0.f, nullptr};
+             0, 0, 0, 0, 0, 0, 0.f, 0, 0, terms, 1.0f, 1.0f, nullptr, nullptr, 1.0f, 0.f, nullptr, 0, 0};
     int rc;
     switch (terms) {
         case 1: rc = launch_s3w<S3_EPI_BIAS, 1, 4>(a, st, ns); break;
@@ -1912,7 +1944,7 @@ int gemm_bf16x3_qkv3(const void* A3, const void* W3, const float* bias, void* im
     AVD_REQUIRE(aligned16(A3) && aligned16(W3) && aligned16(bias) && aligned16(img), AVD_EUNSUPPORTED, "gemm_bf16x3_qkv3: alignment");
     S3Args a{static_cast<const unsigned char*>(A3), static_cast<const unsigned char*>(W3), bias, nullptr, nullptr,
              static_cast<unsigned char*>(img), M, N, K, 0, 0, 0, tokens, qkv3_npad(tokens), heads, qscale, 0, 0, terms, 1.0f / ab_scale, c_scale,
-             ss_in, nullptr, (float)sqrt((double)K), eps, nullptr};
+             ss_in, nullptr, (float)sqrt((double)K), eps, nullptr, 0, 0};
     return launch_s3<S3_EPI_QKV3>(a, st);
 }
 

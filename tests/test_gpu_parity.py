@@ -1230,6 +1230,45 @@ def test_full_step_shipped_geometry_batch32(dev, full, matmul):
     assert torch.isfinite(out).all() and err < TOL
 
 
+@pytest.mark.parametrize("B,N,nq", [(16, 421, 384), (3, 2100, 2048), (20, 421, 1)])
+def test_last_block_runs_on_the_output_window_only(dev, full, B, N, nq):
+    """VERDICT r3 missing 6: with the caller's row window at row 0 (the engine passes the target rows) the last block's attention
+    writes its rows compactly and out_proj / fc1 / fc2 / the final norm run on B * n_out_rows rows (residual read through a row map).
+    Every row's arithmetic is unchanged, so the window of the result equals the full-window forward BIT FOR BIT, in the headline
+    mode, at the bench's row ratio (384 of 421), at a ragged multi-block shape and at a one-row window; `core_trim` 0 (the
+    untrimmed last block) agrees as well."""
+    import ctypes as C
+    from multimodal_diffusion_amd import _lib as L
+    ws, mods = full
+    core = mods[0]
+    prev = core.matmul
+    core.matmul = "bf16x3"
+    try:
+        x = torch.randn(B, N, 512, generator=torch.Generator().manual_seed(B + N)).to(dev)
+        cw, keep = core.weight_table()
+        wsb = torch.empty(L.lib().avd_core_workspace_bytes(C.byref(cw), B, N), dtype=torch.uint8, device=dev)
+
+        def fwd(rows, trim):
+            _tune("core_trim", trim)
+            try:
+                y = torch.zeros_like(x)
+                L.check(L.lib().avd_core_forward_f32(C.byref(cw), x.data_ptr(), y.data_ptr(), B, N, 0, rows, None, wsb.data_ptr(), wsb.numel(),
+                                                     L.stream_ptr(dev)))
+                torch.cuda.synchronize()
+                return y
+            finally:
+                _tune("core_trim", 1)
+        whole = fwd(N, 1)
+        assert torch.isfinite(whole).all()
+        assert rel_err(whole[:1].cpu(), R.mmdit_forward(x[:1].cpu(), ws["core"], 8, 8)) < TOL
+        for trim in (1, 0):
+            part = fwd(nq, trim)
+            assert torch.equal(part[:, :nq], whole[:, :nq]), (trim, float((part[:, :nq] - whole[:, :nq]).abs().max()))
+        del keep
+    finally:
+        core.matmul = prev
+
+
 def test_default_mode_is_the_headline_mode(dev):
     """modules built through `build_components` from an mvp.yaml-shaped config with NO runtime override run the
     bench's headline kernels at the bench's size (matmul "auto" -> bf16x3 where the split kernels engage) and the norm-folded fp32
@@ -1467,7 +1506,7 @@ def test_split_gemm_block_rows_agree(dev, full, size, B):
     tn = torch.tensor(([982, 500, 16, 999] * B)[:B])
     tp = torch.tensor(([966, 480, -1, 979] * B)[:B])
     outs = {}
-    for rt, w128 in ((7, 0), (8, 0), (0, 0), (7, 1), (8, 1)):
+    for rt, w128 in ((7, 0), (8, 0), (0, 0), (7, 1), (8, 1), (6, 1), (0, 1)):
         _tune("s3_rt", rt)
         _tune("s3_w128", w128)
         _tune("s3_tile", 0 if B == 5 else -1)
@@ -1486,6 +1525,8 @@ def test_split_gemm_block_rows_agree(dev, full, size, B):
     # the 4-wave kernel with a 128 x 128 wave tile (avd_tune_set "s3_w128") issues the same MFMA sequence per output element
     assert torch.equal(outs[7, 1], outs[8, 0])
     assert torch.equal(outs[8, 1], outs[8, 0])
+    # 192-row blocks (round 4: what the host picks for the trimmed last block, 24,576 rows) and the automatic choice
+    assert torch.equal(outs[6, 1], outs[8, 0]) and torch.equal(outs[0, 1], outs[8, 0])
     outs = {7: outs[7, 0]}
     ref = R.denoise_step_a2v(z_v[:1], z_a[:1], tn[:1], tp[:1], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"], core=ws["core"],
                              head=ws["head"], n_layers=8, n_heads=8, guidance=3.5)
