@@ -55,7 +55,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
     p = fmaf(p, t, 0.254829592f);
     p *= t;
     const float e = __builtin_amdgcn_exp2f(-a * a * 1.4426950408889634f);
-    const float er = copysignf(1.0f - p * e, z);
+    const float er = copysignf(fmaf(-p, e, 1.0f), z);      // explicit fma: the same rounding in every kernel that inlines this
     return 0.5f * x * (1.0f + er);
 }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
@@ -268,6 +268,10 @@ int layernorm_act_split3_f32(const float* x, const float* gamma, const float* be
 bool gemm_bf16x3_supported(int64_t M, int N, int K);
 int attn_f32_split3(const float* qkv, void* out3, int B, int N, int H, int Dh, float scale, int n_query, hipStream_t st);
 extern int g_s3_stagger;
+extern int g_mlp_fused;          // 1: fc1 -> GELU -> fc2 of the six-term bf16x3 path as one launch (mlp_bf16x3.hip; default 0, avd_tune_set "mlp_fused")
+bool mlp_bf16x3_supported(int d, int hidden, int terms);
+int mlp_bf16x3(const void* X3, const void* W1n3, const float* b1, const void* W23, const float* b2, const float* ss_in, float eps,
+               const float* R, float* C, void* C3, float* ss_out, int64_t M, int d, int hidden, hipStream_t st);
 extern int g_attn_pipe;          // 1 (default): the split-operand attention as one software pipeline per wave (avd_tune_set "attn_pipe")
 extern int g_s3_m16;             // 1 (default): bf16x3 GEMMs on v_mfma_f32_16x16x32_bf16, two terms per MFMA; 0: 32x32x16 (avd_tune_set "s3_m16")
 extern int g_s3_w128;            // 1: the 8-wave bf16x3 blocks with an image epilogue run as 4 waves with a 128 x 128 wave tile (avd_tune_set "s3_w128")

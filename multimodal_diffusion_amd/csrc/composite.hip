@@ -256,6 +256,8 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
             // out_proj / fc1 / fc2 / the final norm run on B * n_out_rows rows instead of B * N (C3: 384 of 421)
             const bool trim = g_core_trim && out_row0 == 0 && n_out_rows < N && w->attn_mode == 0 && gemm_bf16x3_resmap_supported(terms);
             float* yc = cs.take(core_trim_floats(w, B, N));              // compact fp32 stream of the last block (sized whether or not it is used)
+            // fc1 -> GELU -> fc2 as one launch (mlp_bf16x3.hip; off by default: it measures slower)
+            const bool fused = g_mlp_fused && !ns && mlp_bf16x3_supported(d, hid, terms) && gemm_bf16x3_resmap_supported(terms);
             AVD_REQUIRE(cs.ok, AVD_EWORKSPACE, "core: workspace carve %lld > %lld bytes", (long long)cs.used, (long long)cs.cap);
             if (int rc = split3_rows_f32(cur, rd, hx, M, d, st, 0.f, ss)) return rc;
             for (int l = 0; l < w->n_layers; ++l) {
@@ -269,9 +271,19 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
                     if (int rc = attn_bf16x3(qkv, nullptr, hs, B, N, H, nq, terms, st, 1.f, 1.f, nq)) return rc;       // rows b * nq + q
                     if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, yc, hx, Mc, d, d, AVD_ACT_NONE, terms, st, 1.f, 1.f,
                                              nullptr, 0.f, ss, nullptr, nq, N)) return rc;                                  // residual rows b * N + q
-                    if (int rc = gemm_bf16x3(hx, b.fc1_weight3n, b.fc1_bias, nullptr, nullptr, wide3, Mc, hid, d, AVD_ACT_GELU, terms, st, 1.f, 1.f,
-                                             ss, w->norm_eps)) return rc;
-                    if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, yc, yc, nullptr, Mc, d, hid, AVD_ACT_NONE, terms, st)) return rc;
+                    if (fused) {
+                        if (int rc = mlp_bf16x3(hx, b.fc1_weight3n, b.fc1_bias, b.fc2_weight3, b.fc2_bias, ss, w->norm_eps, yc, yc, nullptr, nullptr, Mc,
+                                                d, hid, st)) return rc;
+                    } else {
+                        if (int rc = gemm_bf16x3(hx, b.fc1_weight3n, b.fc1_bias, nullptr, nullptr, wide3, Mc, hid, d, AVD_ACT_GELU, terms, st, 1.f, 1.f,
+                                                 ss, w->norm_eps)) return rc;
+                        if (ns) {       // the same K slices as every other block: the window's rows keep their summation order
+                            if (int rc = gemm_bf16x3_splitk(wide3, b.fc2_weight3, b.fc2_bias, yc, yc, nullptr, nullptr, Mc, d, hid, terms, ns, part,
+                                                            st)) return rc;
+                        } else {
+                            if (int rc = gemm_bf16x3(wide3, b.fc2_weight3, b.fc2_bias, yc, yc, nullptr, Mc, d, hid, AVD_ACT_NONE, terms, st)) return rc;
+                        }
+                    }
                     // final norm from the compact rows into the caller's [B, N, d] layout (rows outside the window stay as they were)
                     return rmsnorm_f32(yc, rd, w->final_norm_scale, y, RowMap{d, nq, (int64_t)N * d}, Mc, d, w->norm_eps, st);
                 }
@@ -285,6 +297,11 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
                 if (int rc = gemm_bf16x3(hs, b.out_proj_weight3, b.out_proj_bias, cur, y, hx, M, d, d, AVD_ACT_NONE, terms, st, 1.f, 1.f, nullptr,
                                          0.f, ss)) return rc;
                 cur = y;
+                if (fused) {
+                    if (int rc = mlp_bf16x3(hx, b.fc1_weight3n, b.fc1_bias, b.fc2_weight3, b.fc2_bias, ss, w->norm_eps, y, y, last ? nullptr : hx,
+                                            last ? nullptr : ss, M, d, hid, st)) return rc;
+                    continue;
+                }
                 if (int rc = gemm_bf16x3(hx, b.fc1_weight3n, b.fc1_bias, nullptr, nullptr, wide3, M, hid, d, AVD_ACT_GELU, terms, st, 1.f, 1.f, ss,
                                          w->norm_eps)) return rc;
                 if (ns) {       // too few blocks for the chip: K slices + a deterministic reduction that writes what the epilogue would
@@ -607,6 +624,7 @@ extern "C" int avd_tune_set(const char* key, int64_t value) {
     if (!strcmp(key, "s3_stagger")) { g_s3_stagger = (int)value; return AVD_OK; }
     if (!strcmp(key, "attn_pipe")) { g_attn_pipe = (int)value; return AVD_OK; }
     if (!strcmp(key, "core_trim")) { g_core_trim = value != 0; return AVD_OK; }
+    if (!strcmp(key, "mlp_fused")) { g_mlp_fused = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_tile")) { g_gemm_force_tile = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_stages")) { g_gemm_stages = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_min_rows")) { g_s3_min_rows = value; return AVD_OK; }

@@ -1269,6 +1269,55 @@ def test_last_block_runs_on_the_output_window_only(dev, full, B, N, nq):
         core.matmul = prev
 
 
+@pytest.mark.parametrize("B", [8, 32])
+def test_fused_mlp_matches_two_launches(dev, full, B):
+    """fc1 -> GELU -> fc2 of a block as ONE launch (csrc/mlp_bf16x3.hip, avd_tune_set "mlp_fused" 1; the hidden
+    chunk stays in LDS, the fc2 accumulators in AGPRs).  Same operands, same six product terms in the same order: a whole CFG step at the
+    bench's geometry agrees with the two-launch path to the last bits of the fp32 stream (measured: one block's output differs by at most
+    1 ulp, 9.5e-7 at |y| <= 5.4) — B = 8 (6,736 rows; without the last-block trim as well, whose fused call writes the fp32 stream
+    only) and the bench's B = 32 — and with the CPU oracle at the parity tolerance, exactly as far from it as the two launches are."""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd import _lib as L
+    ws, mods = full
+    core, head, av, aa = mods
+    g = torch.Generator().manual_seed(900 + B)
+    z_v = torch.randn(B, 8, 12, 32, 32, generator=g)
+    z_a = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn = torch.tensor(([982, 500, 16, 999] * B)[:B])
+    tp = torch.tensor(([966, 480, -1, 979] * B)[:B])
+    outs = {}
+    try:
+        _tune("s3_splitk", 0)                # (split-K of fc2 and the fused launch exclude each other: keep both arms on whole-K sums)
+        for fused, trim in ((0, 1), (1, 1), (1, 0)):
+            _tune("mlp_fused", fused)
+            _tune("core_trim", trim)
+            eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z_v.shape),
+                                  prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul="bf16x3")
+            eng.set_prompt(z_a.to(dev))
+            eng.step(z_v.to(dev), tn.to(dev), tp.to(dev))
+            L.prof_enable(True)
+            outs[fused, trim] = eng.step(z_v.to(dev), tn.to(dev), tp.to(dev)).cpu()
+            torch.cuda.synchronize()
+            L.prof_enable(False)
+            rep = L.prof_report()
+            assert (rep.get("mlp_bf16x3_kernel", (0,))[0] > 0) == bool(fused), rep.keys()
+            if fused:
+                print(f"fused MLP, B={B}, trim={trim}: {1e3 * rep['mlp_bf16x3_kernel'][1] / rep['mlp_bf16x3_kernel'][0]:.1f} us per launch")
+    finally:
+        _tune("mlp_fused", 0)
+        _tune("core_trim", 1)
+        _tune("s3_splitk", 4)
+    assert torch.isfinite(outs[0, 1]).all() and torch.isfinite(outs[1, 1]).all()
+    d1, d0 = rel_err(outs[1, 1], outs[0, 1]), rel_err(outs[1, 0], outs[0, 1])
+    assert torch.equal(outs[1, 0], outs[1, 1])                 # the fused path with and without the trimmed last block: bit-identical
+    ref = R.denoise_step_a2v(z_v[:1], z_a[:1], tn[:1], tp[:1], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"], core=ws["core"],
+                             head=ws["head"], n_layers=8, n_heads=8, guidance=3.5)
+    e1, e0 = rel_err(outs[1, 1][:1], ref), rel_err(outs[0, 1][:1], ref)
+    print(f"fused MLP, B={B}: vs two launches {d1:.2e}; vs CPU oracle {e1:.3e} (two launches: {e0:.3e})")
+    assert d1 < 1e-6 and d0 < 1e-6 and e1 < TOL and e1 < 1.5 * e0 + 1e-7
+
+
 def test_default_mode_is_the_headline_mode(dev):
     """modules built through `build_components` from an mvp.yaml-shaped config with NO runtime override run the
     bench's headline kernels at the bench's size (matmul "auto" -> bf16x3 where the split kernels engage) and the norm-folded fp32
