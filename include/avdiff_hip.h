@@ -47,7 +47,9 @@ const char* avd_last_error(void);
 /* gfx arch name of device 0 as seen by the library ("gfx950"); diagnostic only. */
 int         avd_device_arch(char* buf, int buflen);
 /* Measurement / test hooks, process-wide, never needed for correct results: "gemm_tile" (-1 auto, 0 = 128x128, 1 = 128x64,
- * 2 = 64x64 LDS-DMA tile of avd_gemm_bias_act_f32), "gemm_stages" (0 by size, 2 / 3 LDS stages), "s3_tile" (-1 per epilogue, 0 = 8-wave
+ * 2 = 64x64 LDS-DMA tile of avd_gemm_bias_act_f32), "gemm_stages" (0 by size, 2 / 3 LDS stages), "gemm_splitk" (largest number of K slices of the fp32 fc2 launch of
+ * avd_core_forward_f32 when its 64x64 blocks cover less than half of the CUs — batches of a few hundred rows; 0 = never, default and maximum 4;
+ * partial sums added in slice order, no atomics), "s3_tile" (-1 per epilogue, 0 = 8-wave
  * 256x256, 1 = 4-wave 256x128 blocks of the split-operand GEMMs), "s3_stagger" (first-generation stagger of co-resident 4-wave blocks,
  * x 1024 cycles; -1 automatic), "s3_min_rows" (smallest 2B*N that takes the split-operand kernels), "no_fold" (1 = keep RMSNorm as
  * separate kernels in avd_core_forward_f32, in every mode), "s3_m16" (1 default: bf16x3 GEMMs on v_mfma_f32_16x16x32_bf16 with two product

@@ -247,6 +247,13 @@ int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, 
                   int64_t M, int N, int K, int act, const float* ss_in, int ss_in_cols, float sqrt_d, float eps, float* ss_out,
                   hipStream_t st);
 int rowss_f32(const float* x, float* ss, int64_t rows, int d, hipStream_t st);
+// split-K of the fp32 residual GEMMs for batches of a few hundred rows (gemm_f32.hip): slices to use (0 = none), workspace bound, launch
+constexpr int kGemmSplitKMax = 4;
+extern int g_gemm_splitk;        // largest slice count tried (0 off; avd_tune_set "gemm_splitk")
+int gemm_f32_splitk_slices(int64_t M, int N, int K);
+int64_t gemm_f32_splitk_ws_max_floats(int64_t M, int N, int K);
+int gemm_f32_splitk(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm, float* C, RowMap cm, int64_t M,
+                    int N, int K, int ns, float* part, float* ss_out, hipStream_t st);
 
 int attn_f32(const float* qkv, float* out, int B, int N, int H, int Dh, float scale, int n_query, const unsigned char* key_padding_mask,
              hipStream_t st);

@@ -165,7 +165,8 @@ static int64_t core_split_wide_bytes(const avd_core_weights* w, int B, int N) {
 static int64_t core_ws_bytes(const avd_core_weights* w, int B, int N) {
     const int64_t M = (int64_t)B * N;
     const int wide = 3 * w->d > w->mlp_hidden ? 3 * w->d : w->mlp_hidden;
-    int64_t fp32_path = align_up(M * w->d * 4) + align_up(M * wide * 4) + 2 * align_up(M * (w->d / 32 + 1) * 4);
+    int64_t fp32_path = align_up(M * w->d * 4) + align_up(M * wide * 4) + 2 * align_up(M * (w->d / 32 + 1) * 4) +
+                        align_up(gemm_f32_splitk_ws_max_floats(M, w->d, w->mlp_hidden) * 4);       // split-K partial sums of fc2 (tiny batches)
     if (!core_split_capable(w, M)) return fp32_path;
     // + split3 image of the norm / attention output, and the wide buffer must also hold the split3 image of the MLP hidden
     const int64_t wide_b = core_split_wide_bytes(w, B, N);
@@ -369,6 +370,8 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
         // in_proj / fc1 GEMMs run on the un-normalised stream with scale-carrying weights and multiply their rows by 1/rms
         float* ssA = cv.take(M * (d / 32 + 1));     // sums of squares of the stream entering norm1
         float* ssB = cv.take(M * (d / 32 + 1));     // ... entering norm2
+        const int nsf = gemm_f32_splitk_slices(M, d, hid);         // K slices of fc2 when its blocks cover less than half of the CUs
+        float* partf = nsf ? cv.take((int64_t)nsf * M * d) : nullptr;
         AVD_REQUIRE(cv.ok, AVD_EWORKSPACE, "core: workspace carve %lld > %lld bytes", (long long)cv.used, (long long)cv.cap);
         const float sqrt_d = (float)sqrt((double)d);
         const float* ssA_in = ss_first;                // the front end may already have the rows' sums of squares
@@ -389,8 +392,12 @@ static int core_forward(const avd_core_weights* w, const float* x, float* y, int
             cur = y;
             if (int rc = gemm_f32_fold(y, rd, b.fc1_weight_n, b.fc1_bias, nullptr, rd, wide, rh, M, hid, d, AVD_ACT_GELU, ssB, d / 32,
                                        sqrt_d, w->norm_eps, nullptr, st)) return rc;
-            if (int rc = gemm_f32_fold(wide, rh, b.fc2_weight, b.fc2_bias, y, rd, y, rd, M, d, hid, AVD_ACT_NONE, nullptr, 0, 1.f, 0.f,
-                                       ssA, st)) return rc;
+            if (nsf) {
+                if (int rc = gemm_f32_splitk(wide, rh, b.fc2_weight, b.fc2_bias, y, rd, y, rd, M, d, hid, nsf, partf, ssA, st)) return rc;
+            } else {
+                if (int rc = gemm_f32_fold(wide, rh, b.fc2_weight, b.fc2_bias, y, rd, y, rd, M, d, hid, AVD_ACT_NONE, nullptr, 0, 1.f, 0.f,
+                                           ssA, st)) return rc;
+            }
             colsA = d / 32;
         }
         return rmsnorm_f32(y, rd, w->final_norm_scale, y, rd, M, d, w->norm_eps, st);
@@ -627,6 +634,11 @@ extern "C" int avd_tune_set(const char* key, int64_t value) {
     if (!strcmp(key, "mlp_fused")) { g_mlp_fused = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_tile")) { g_gemm_force_tile = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_stages")) { g_gemm_stages = (int)value; return AVD_OK; }
+    if (!strcmp(key, "gemm_splitk")) {
+        AVD_REQUIRE(value >= 0 && value <= kGemmSplitKMax, AVD_EINVAL, "tune_set: gemm_splitk must be in [0, %d]", kGemmSplitKMax);
+        g_gemm_splitk = (int)value;
+        return AVD_OK;
+    }
     if (!strcmp(key, "s3_min_rows")) { g_s3_min_rows = value; return AVD_OK; }
     if (!strcmp(key, "no_fold")) { g_no_fold = value != 0; return AVD_OK; }
     return set_error(AVD_EINVAL, "tune_set: unknown key '%s'", key);

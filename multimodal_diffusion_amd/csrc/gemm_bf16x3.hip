@@ -1685,15 +1685,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // into the largest power-of-two number of K slices (<= "s3_splitk", default 4) that still leaves at most ONE block per CU and a slice of
 // >= 32 k-steps: C2 (3,904 rows) fc2 64 blocks -> 4 slices; 6,736 rows 108 blocks -> 2.  (Round 4 tried filling the two slots per CU as
 // well — 8,512 rows, 136 blocks x 2 slices = 272 blocks: the 16 CUs that get two blocks set the launch time, 130 + 21 us against 150 us
-// unsplit, profiles/r04_bench_128_splitk.txt — so a CU never gets more than one.)  The slices run on the 32x32x16 kernel in every
-// bf16-plane mode, the six-term one included.  avd_tune_set "s3_splitk" (AVD_S3_SPLITK): 0 off, else the largest slice count tried.
+// unsplit, profiles/r04_bench_128_splitk.txt — so a CU never gets more than one.)  The slices run on the 32x32x16 kernel (one-term and
+// nine-term modes, and the six-term mode when "s3_m16" is 0).  avd_tune_set "s3_splitk" (AVD_S3_SPLITK): 0 off, else the largest slice count tried.
 int g_s3_splitk = [] { const int v = getenv("AVD_S3_SPLITK") ? atoi(getenv("AVD_S3_SPLITK")) : 4; return v < 0 ? 0 : v > kS3SplitKMax ? kS3SplitKMax : v; }();
 static bool splitk_shape_ok(int64_t M, int N, int K) {
     if (N % 128 || K % 32 || K / 2 < 512) return false;
     return (M + 255) / 256 * (N / 128) * 2 <= (int64_t)s3_cu_count();
 }
 int gemm_bf16x3_splitk_slices(int64_t M, int N, int K, int terms) {
-    if (g_s3_splitk < 2 || terms == 3 || !splitk_shape_ok(M, N, K)) return 0;
+    // (six-term mode on the 16x16x32 kernels: no slices — at 6,736 rows two slices did not pay, profiles/r04_bench_128_splitk.txt, and a
+    // plan that changes with the row count would break the bit-identity of the one- and two-stream CFG layouts at the bench's size)
+    if (g_s3_splitk < 2 || terms == 3 || ((terms == 0 || terms == 6) && g_s3_m16) || !splitk_shape_ok(M, N, K)) return 0;
     const int64_t cu = s3_cu_count(), blocks = (M + 255) / 256 * (N / 128);
     int ns = 1;
     while (ns * 2 <= g_s3_splitk && blocks * ns * 2 <= cu && K % (32 * ns) == 0 && K / (ns * 2) >= 512) ns *= 2;

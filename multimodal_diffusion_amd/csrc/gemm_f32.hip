@@ -26,6 +26,7 @@
 #include "avd_common.h"
 
 #include <stdlib.h>
+#include <atomic>
 #include <type_traits>
 
 namespace avd {
@@ -56,6 +57,7 @@ struct GemmArgs {
     float ss_sqrt_d, ss_eps;
     float* ss_out;
     TubeGather tg;          // gemm_f32_reg_kernel<..., GATHER = true> only: A rows are tube tokens of the latent at A
+    int ldw;                // row stride of W in floats (= K, or the whole K of a split-K launch whose K field is one slice's length)
 #ifdef AVD_GEMM_STAMPS      // diagnostic build only (tools/micro/gemm_stamps.py): per-block phase stamps, never in the product library
     unsigned long long* dbg;
 #endif
@@ -117,6 +119,11 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
     const int wg = xcd_remap(blockIdx.x, gridDim.x);
     const int bm = wg / g.nbn, bn = wg % g.nbn;
 
+    // split-K launches (gemm_f32_splitk): blockIdx.y = K slice z; g.K is ONE slice's length, rows keep their full strides (am.ld, ldw),
+    // slice z writes its partial sums to C + z * M * ldc
+    const int64_t koff = (int64_t)blockIdx.y * g.K;
+    if (gridDim.y > 1) g.C += (int64_t)blockIdx.y * g.M * g.cm.ld;
+
     // ---- DMA source addresses: piece p = tile rows 8p..8p+7; lane -> row 8p + lane/8, PHYSICAL chunk lane%8 ----
     const int r8 = lane >> 3, pc = lane & 7;
     const float* a_src[A_PIECES];
@@ -126,14 +133,14 @@ __global__ __launch_bounds__(256, WPS) void gemm_f32_dma_kernel(GemmArgs g) {
         const int trow = (wave + 4 * i) * 8 + r8;
         int64_t row = (int64_t)bm * BM + trow;
         row = row < g.M ? row : g.M - 1;
-        a_src[i] = g.A + g.am.off(row) + ((pc ^ ((trow >> 1) & 7)) << 2);
+        a_src[i] = g.A + g.am.off(row) + koff + ((pc ^ ((trow >> 1) & 7)) << 2);
     }
 #pragma unroll
     for (int i = 0; i < B_PIECES; ++i) {
         const int trow = (wave + 4 * i) * 8 + r8;
         int n = bn * BN + trow;
         n = n < g.N ? n : g.N - 1;
-        b_src[i] = g.W + (int64_t)n * g.K + ((pc ^ ((trow >> 1) & 7)) << 2);
+        b_src[i] = g.W + (int64_t)n * g.ldw + koff + ((pc ^ ((trow >> 1) & 7)) << 2);
     }
     auto stage = [&](int kt, int buf) {
         float* as = smem + buf * STAGE;
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_reg_kernel(GemmArgs g) {
     for (int i = 0; i < B_IT; ++i) {
         int n = bn * BN + lrow + 32 * i;
         n = n < g.N ? n : g.N - 1;
-        b_src[i] = g.W + (int64_t)n * g.K + lkc;
+        b_src[i] = g.W + (int64_t)n * g.ldw + lkc;
     }
     const int st_off = lrow * GEMM_LD + lkc;
 
@@ -495,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_reg_kernel(GemmArgs g) {
 // =====================================================================================================
 
 template <int BM, int BN, int WM, int WN, int EPI, int WPS, int NST>
-static int launch_dma(const GemmArgs& a, hipStream_t st) {
+static int launch_dma(const GemmArgs& a, hipStream_t st, int nz = 1) {
     constexpr int stage_lds = NST * (BM + BN) * GEMM_BK * 4, epi_lds = 4 * WM * (WN + 4) * 4;
     constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
     static LdsAttr attr;
@@ -507,8 +514,8 @@ static int launch_dma(const GemmArgs& a, hipStream_t st) {
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm grid too large");
     // tag = the kernel name exactly as rocprofv3 prints its template arguments (EPI: 0 bias, 1 gelu, 2 residual)
     static const int tag = prof_tag_id("gemm_f32_dma_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, WM, WN, EPI, WPS, NST);
-    ProfScope prof(tag, 2.0 * (double)a.M * a.N * a.K, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(256), lds, st, g);
+    ProfScope prof(tag, 2.0 * (double)a.M * a.N * a.K * nz, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg, (unsigned)nz), dim3(256), lds, st, g);
     AVD_CHECK_LAUNCH("gemm_f32_dma");
     return AVD_OK;
 }
@@ -574,7 +581,7 @@ int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, 
     AVD_REQUIRE(aligned16(A) && aligned16(W), AVD_EUNSUPPORTED, "gemm: A/W must be 16-byte aligned");
     AVD_REQUIRE(act == AVD_ACT_NONE || act == AVD_ACT_GELU || act == AVD_ACT_SILU, AVD_EINVAL, "gemm: bad act %d", act);
     if (M == 0) return AVD_OK;
-    GemmArgs g{A, am, W, bias, R, rm, C, cm, M, N, K, act, 0, ss_in, ss_in_cols, sqrt_d, eps, ss_out, TubeGather{}};
+    GemmArgs g{A, am, W, bias, R, rm, C, cm, M, N, K, act, 0, ss_in, ss_in_cols, sqrt_d, eps, ss_out, TubeGather{}, K};
 #ifdef AVD_GEMM_STAMPS
     g.dbg = g_gemm_dbg;
 #endif
@@ -606,12 +613,93 @@ int gemm_f32_fold(const float* A, RowMap am, const float* W, const float* bias, 
     return launch_reg_k<64, 64, 32, 32>(g, st);
 }
 
+// ---- split-K for residual GEMMs of tiny batches (round 4) ----
+// BASELINE C1 (32x32, batch 4: 344 rows) gives fc2 48 blocks of 64 x 64 that each walk K = 2,048 alone (45 us of a 0.84 ms step, eight
+// times per step).  K is cut into slices (blockIdx.y) whose fp32 partial sums this kernel adds in slice order, then bias and residual as
+// the fused epilogue would, writing the stream and (ss != null) its rows' sums of squares per 32-column chunk — the table a norm-folded
+// GEMM reads.  Deterministic: fixed order, no atomics.  One thread per 4 columns.
+__global__ __launch_bounds__(256) void splitk_reduce_f32_kernel(const float* __restrict__ part, int ns, const float* __restrict__ bias,
+                                                                const float* R, int64_t ldr, float* C, int64_t ldc, float* __restrict__ ss,
+                                                                int64_t M, int N) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int per_row = N >> 2;
+    const int64_t m = i / per_row;
+    const int n = (int)(i % per_row) * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (m < M) {
+        v = *reinterpret_cast<const f32x4*>(part + m * N + n);
+        for (int z = 1; z < ns; ++z) v += *reinterpret_cast<const f32x4*>(part + ((int64_t)z * M + m) * N + n);
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
+        if (R) v += *reinterpret_cast<const f32x4*>(R + m * ldr + n);
+        *reinterpret_cast<f32x4*>(C + m * ldc + n) = v;
+    }
+    if (ss) {       // 8 consecutive threads hold one 32-column chunk of one row (N % 32 == 0)
+        float sq = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        sq += __shfl_xor(sq, 1, 64);
+        sq += __shfl_xor(sq, 2, 64);
+        sq += __shfl_xor(sq, 4, 64);
+        if ((threadIdx.x & 7) == 0 && m < M) ss[m * (N >> 5) + (n >> 5)] = sq;
+    }
+}
+
+int g_gemm_splitk = getenv("AVD_GEMM_SPLITK") ? atoi(getenv("AVD_GEMM_SPLITK")) : 4;     // largest slice count tried (0 off); avd_tune_set "gemm_splitk"
+static int gemm_cu_count() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    int n = dev < 64 ? cache[dev].load(std::memory_order_acquire) : 0;
+    if (!n) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        n = prop.multiProcessorCount;
+        if (dev < 64) cache[dev].store(n, std::memory_order_release);
+    }
+    return n;
+}
+// slices for C[M][N] = A W^T over K with the 64 x 64 tiles: the largest power of two (<= "gemm_splitk") that keeps one block per CU at
+// most and a slice of >= 16 K tiles; 0 = do not split
+int gemm_f32_splitk_slices(int64_t M, int N, int K) {
+    if (g_gemm_splitk < 2 || N % 32 || K % 64) return 0;
+    const int64_t cu = gemm_cu_count(), blocks = (M + 63) / 64 * ((N + 63) / 64);
+    int ns = 1;
+    while (ns * 2 <= g_gemm_splitk && ns * 2 <= kGemmSplitKMax && blocks * ns * 2 <= cu && K % (GEMM_BK * ns * 2) == 0 && K / (ns * 2) >= 16 * GEMM_BK) ns *= 2;
+    return ns >= 2 ? ns : 0;
+}
+int64_t gemm_f32_splitk_ws_max_floats(int64_t M, int N, int K) {
+    if (N % 32 || K % 64 || K / 2 < 16 * GEMM_BK) return 0;
+    return (M + 63) / 64 * ((N + 63) / 64) * 2 <= gemm_cu_count() ? (int64_t)kGemmSplitKMax * M * N : 0;
+}
+
+// C = A W^T + bias + R with K cut into ns slices (partial sums in `part`, ns * M * N floats); ss_out as gemm_f32_fold's
+int gemm_f32_splitk(const float* A, RowMap am, const float* W, const float* bias, const float* R, RowMap rm, float* C, RowMap cm, int64_t M,
+                    int N, int K, int ns, float* part, float* ss_out, hipStream_t st) {
+    AVD_REQUIRE(A && W && C && part && ns >= 2, AVD_EINVAL, "gemm_f32_splitk: null pointer");
+    AVD_REQUIRE(K % (GEMM_BK * ns) == 0 && N % 32 == 0 && am.seg <= 0 && am.ld % 4 == 0 && cm.seg <= 0 && cm.ld % 4 == 0 &&
+                    (R == nullptr || (rm.seg <= 0 && rm.ld % 4 == 0)), AVD_EUNSUPPORTED, "gemm_f32_splitk: shape (M=%lld N=%d K=%d slices=%d)",
+                (long long)M, N, K, ns);
+    AVD_REQUIRE(aligned16(A) && aligned16(W) && aligned16(C) && aligned16(part) && aligned16(bias) && aligned16(R), AVD_EUNSUPPORTED,
+                "gemm_f32_splitk: pointers must be 16-byte aligned");
+    const RowMap pm{N, 0, 0};
+    GemmArgs g{A, am, W, nullptr, nullptr, pm, part, pm, M, N, K / ns, AVD_ACT_NONE, 0, nullptr, 0, 1.f, 0.f, nullptr, TubeGather{}, K};
+#ifdef AVD_GEMM_STAMPS
+    g.dbg = g_gemm_dbg;
+#endif
+    if (int rc = launch_dma<64, 64, 32, 32, EPI_BIAS, 3, 3>(g, st, ns)) return rc;
+    const int64_t threads = M * (N >> 2);
+    static const int tag = prof_tag_id("splitk_reduce_f32_kernel");
+    ProfScope prof(tag, (double)M * N * 4.0 * (ns + 2), st);
+    hipLaunchKernelGGL(splitk_reduce_f32_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, part, ns, bias, R, rm.ld, C, cm.ld,
+                       ss_out, M, N);
+    AVD_CHECK_LAUNCH("splitk_reduce_f32");
+    return AVD_OK;
+}
+
 int gemm_f32_tube(const float* z, const TubeGather& tg, const float* W, const float* bias, float* C, RowMap cm, int64_t M, int N, int K,
                   hipStream_t st) {
     AVD_REQUIRE(z && W && C && M > 0 && N > 0 && K > 0, AVD_EINVAL, "gemm_tube: bad arguments");
     AVD_REQUIRE(tg.w % 4 == 0 && tg.W % 4 == 0 && K % 4 == 0 && aligned16(z) && aligned16(W), AVD_EUNSUPPORTED,
                 "gemm_tube: the gathered A load needs w %% 4 == 0, W %% 4 == 0, K %% 4 == 0 and 16-byte aligned operands");
-    GemmArgs g{z, RowMap{K, 0, 0}, W, bias, nullptr, cm, C, cm, M, N, K, AVD_ACT_NONE, 0, nullptr, 0, 1.f, 0.f, nullptr, tg};
+    GemmArgs g{z, RowMap{K, 0, 0}, W, bias, nullptr, cm, C, cm, M, N, K, AVD_ACT_NONE, 0, nullptr, 0, 1.f, 0.f, nullptr, tg, K};
 #ifdef AVD_GEMM_STAMPS
     g.dbg = g_gemm_dbg;
 #endif

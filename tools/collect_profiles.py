@@ -7,13 +7,13 @@ import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src, dst = ROOT / "gpurun_out" / tag, ROOT / "profiles"
 dst.mkdir(exist_ok=True)
 copied = []
 for f in sorted(src.glob("*")):
     if f.is_file() and f.suffix in (".json", ".txt") and f.stat().st_size > 0 and not f.name.endswith(".err"):
-        if f.name.startswith(("traffic_f32.txt", "traffic_f16x2.txt", "traffic_bf16x3.txt", "bench_n2.out")):
+        if f.name.startswith(("traffic_f32.txt", "traffic_f16x2.txt", "traffic_bf16x3.txt", "traffic_bf16x3_mlpfused.txt", "bench_n2.out", "k.txt")):
             continue
         shutil.copy(f, dst / f"{tag}_{f.name}")
         copied.append(f.name)

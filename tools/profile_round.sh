@@ -1,10 +1,10 @@
 #!/bin/bash
 # Everything the round's measurement record is built from, in one GPU-box call (run from the repo root):
-#   bash tools/profile_round.sh r03
+#   bash tools/profile_round.sh r04
 # Output under gpurun_out/<tag>/; tools/collect_profiles.py copies the judged summaries into profiles/.
 # Every long step appends to a file under gpurun_out/ (gpurun kills a call that writes nothing for 7 minutes).
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -29,6 +29,15 @@ $B $C5 --attn fp8 --no-cpu-baseline > $OUT/bench_c5_bf16x3_fp8attn.json 2>> $OUT
 $B --size 128 --batch 32 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_128.json 2>> $OUT/bench.err || exit 1
 $B --size 32 --batch 4 --steps 200 --warmup 20 --no-alt --cpu-steps 3 --matmul f32 > $OUT/bench_c1_gpu.json 2>> $OUT/bench.err || exit 1
 
+step "round-4 A/B lines (tune keys through the environment)"
+AB="$B --no-alt --no-cpu-baseline --steps 40 --warmup 5"
+AVD_MLP_FUSED=1 $AB > $OUT/bench_ab_mlp_fused.json 2>> $OUT/bench.err || exit 1          # fc1 -> GELU -> fc2 as one launch
+AVD_ATTN_PIPE=0 $AB > $OUT/bench_ab_attn_plain.json 2>> $OUT/bench.err || exit 1         # the round-3 attention kernel
+AVD_CORE_TRIM=0 $AB > $OUT/bench_ab_notrim.json 2>> $OUT/bench.err || exit 1             # last block on every row
+$AB > $OUT/bench_ab_default.json 2>> $OUT/bench.err || exit 1                            # the default, same flags, right after
+AVD_CORE_TRIM=0 $B --size 128 --batch 32 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_ab_128_notrim.json 2>> $OUT/bench.err || exit 1
+AVD_GEMM_SPLITK=0 $B --size 32 --batch 4 --steps 200 --warmup 20 --no-alt --no-cpu-baseline --matmul f32 > $OUT/bench_ab_c1_nosplitk.json 2>> $OUT/bench.err || exit 1
+
 step "rocprofv3 kernel traces"
 prof() { name=$1; shift; (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o run -- python3 "$@" > $OUT/prof_$name.log 2>&1) || exit 1; step "  traced $name"; }
 prof bf16x3 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt                                  # the default command (headline mode)
@@ -42,6 +51,8 @@ prof vae2 $ROOT/tools/vae_bench.py --iters 5 --matmul f16x2
 step "PMC traffic (separate FETCH_SIZE / WRITE_SIZE passes; single-stream launches as in the roofline pass)"
 timeout -k 10 600 python3 tools/pmc_traffic.py --out gpurun_out/$TAG/traffic_bf16x3.json -- --matmul bf16x3 > $OUT/traffic_bf16x3.txt 2>&1 || exit 1
 step "  traffic bf16x3"
+AVD_MLP_FUSED=1 timeout -k 10 600 python3 tools/pmc_traffic.py --out gpurun_out/$TAG/traffic_bf16x3_mlpfused.json -- --matmul bf16x3 > $OUT/traffic_bf16x3_mlpfused.txt 2>&1 || echo "fused traffic failed"
+step "  traffic bf16x3, fused MLP"
 timeout -k 10 600 python3 tools/pmc_traffic.py --out gpurun_out/$TAG/traffic_f16x2.json -- --matmul f16x2 > $OUT/traffic_f16x2.txt 2>&1 || exit 1
 step "  traffic f16x2"
 timeout -k 10 600 python3 tools/pmc_traffic.py --out gpurun_out/$TAG/traffic.json -- --matmul f32 > $OUT/traffic_f32.txt 2>&1 || exit 1
