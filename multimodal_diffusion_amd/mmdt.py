@@ -248,7 +248,7 @@ class MMDiT(nn.Module):
                 setattr(arr[i], k, t.data_ptr())
             if self.matmul not in L.MATMUL_TERMS:
                 raise ValueError(f"matmul must be one of {sorted(L.MATMUL_TERMS)}, got {self.matmul!r}")
-            if self.fold_norms and self.matmul in ("f32", "auto") and not ln:
+            if self.fold_norms and not ln:      # every mode: below the split kernels' row threshold all of them run the folded fp32 path
                 for k, sc in (("in_proj_weight", "norm1_scale"), ("fc1_weight", "norm2_scale")):
                     t = self._folded_weight(f"{i}.{k}", L.dev_f32(ps[k].detach(), k), L.dev_f32(ps[sc].detach(), sc))
                     keep.append(t)
