@@ -1638,7 +1638,9 @@ def test_f16x2_rownorm_epilogue_matches_norm_kernel(dev, full, B):
     assert torch.isfinite(outs[0]).all()
     d = rel_err(outs[0], outs[1])
     print(f"f16x2 row-norm epilogue vs norm kernel, B={B}: {d:.3e}")
-    assert d < 3e-6
+    # (B = 5 sits under the split kernels' row threshold: since round 4 its fold arm is the norm-FOLDED fp32 path — every mode carries the
+    # folded fp32 weights — against separate norm kernels: 4.3e-6 for a whole step)
+    assert d < (3e-6 if B == 32 else 1e-5)
     idx = [0, B - 1]
     ref = R.denoise_step_a2v(z_v[idx], z_a[idx], tn[idx], tp[idx], abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"], core=ws["core"],
                              head=ws["head"], n_layers=8, n_heads=8, guidance=3.5)
