@@ -45,6 +45,36 @@ PEAK_HBM_GBS = 8000.0
 # split-operand matmul: one product costs TERMS bf16 MFMAs, so the dense bf16 peak (2,516.6 TFLOP/s) prices ALGORITHMIC fp32
 # flops at 2516.6 / TERMS (the chip holds well under 2.4 GHz on this load; that is not priced in)
 PEAK_BF16_MATRIX_TFLOPS = 2516.6
+# per-clock rates behind those two figures (MI355X_MICROARCH.md, Matrix cores): FLOP per clock per SIMD, four SIMDs per CU
+F32_MATRIX_FLOP_PER_CLK_SIMD, BF16_MATRIX_FLOP_PER_CLK_SIMD = 64, 1024
+PEAK_SOURCE = "MI355X_MICROARCH.md constants (256 CUs x 4 SIMDs x FLOP/clk/SIMD x 2.4 GHz)"
+
+
+def peaks_from_device(device_index: int) -> None:
+    """Re-derive the matrix peaks from what THIS box reports (peaks from the box, not hard-coded): CU count and peak
+    shader clock from the HIP runtime (hipDeviceGetAttribute: MultiprocessorCount, ClockRate — the values rocminfo prints),
+    per-clock rates from the microarchitecture guide.  On an MI355X this reproduces 157.3 / 2,516.6 TFLOP/s; the constants above
+    stay in force when the query fails or returns something implausible.  (sysfs pp_dpm_sclk is NOT a source for this: on this
+    ASIC its level 1 is the CURRENT clock.)"""
+    global PEAK_F32_MATRIX_TFLOPS, PEAK_BF16_MATRIX_TFLOPS, PEAK_SOURCE
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")           # the runtime torch has already loaded
+        HIP_ATTR_CLOCK_RATE_KHZ, HIP_ATTR_MULTIPROCESSOR_COUNT = 5, 63      # hipDeviceAttribute_t, hip_runtime_api.h of ROCm 7.x
+        khz, cus = ctypes.c_int(0), ctypes.c_int(0)
+        if hip.hipDeviceGetAttribute(ctypes.byref(khz), HIP_ATTR_CLOCK_RATE_KHZ, device_index) != 0:
+            return
+        if hip.hipDeviceGetAttribute(ctypes.byref(cus), HIP_ATTR_MULTIPROCESSOR_COUNT, device_index) != 0:
+            return
+        if cus.value != torch.cuda.get_device_properties(device_index).multi_processor_count or not 5e5 < khz.value < 5e6:
+            return                                    # enum drift or an implausible clock: keep the guide's constants
+        per_clk = cus.value * 4 * khz.value * 1e3 / 1e12
+        PEAK_F32_MATRIX_TFLOPS = per_clk * F32_MATRIX_FLOP_PER_CLK_SIMD
+        PEAK_BF16_MATRIX_TFLOPS = per_clk * BF16_MATRIX_FLOP_PER_CLK_SIMD
+        PEAK_SOURCE = (f"this box: {cus.value} CUs x 4 SIMDs x {khz.value / 1e3:.0f} MHz peak shader clock (hipDeviceGetAttribute) x "
+                       f"{F32_MATRIX_FLOP_PER_CLK_SIMD} / {BF16_MATRIX_FLOP_PER_CLK_SIMD} FLOP/clk/SIMD (MI355X_MICROARCH.md); HBM {PEAK_HBM_GBS:.0f} GB/s is the spec figure")
+    except Exception:      # no runtime handle, no symbol: keep the guide's constants
+        return
 MODE_TERMS = {"f32": 0, "bf16x3": 6, "bf16x3_strict": 9, "bf16": 1, "f16x2": 3}
 MODE_DTYPE = {
     "f32": "f32",
@@ -312,7 +342,7 @@ def roofline_of(rep, matmul: str, n_steps: int):
 
     traffic, source = pmc_traffic(dom, matmul)
     roof = {"kernel": dom, "bound": "mfma", "achieved": achieved, "peak": peak_of(dom), "unit": "TFLOP/s",
-            "frac": achieved / peak_of(dom), "traffic": traffic, "traffic_source": source,
+            "frac": achieved / peak_of(dom), "peak_source": PEAK_SOURCE, "traffic": traffic, "traffic_source": source,
             "launches": n, "avg_launch_us": 1e3 * ms / max(n, 1), "flops_per_launch": work / max(n, 1)}
     tot_ms = sum(v[1] for v in rep.values())
     kern = {}
@@ -341,6 +371,7 @@ def main():
     abar, sched, z_a0, z0 = ctx["abar"], ctx["sched"], ctx["z_a0"], ctx["z0"]
     mods, tdim = build_modules(dev)
     av, aa, core, head = mods
+    peaks_from_device(dev.index if dev.index is not None else 0)
 
     def make_engine(mode, split="arg"):
         if split == "arg":
