@@ -61,8 +61,8 @@ int         avd_device_arch(char* buf, int buflen);
  * pipeline per wave — the next tile's score MFMAs beside this tile's softmax; 0: the plain kernel everywhere, 2: the pipeline in every
  * split mode), "core_trim" (1 default: the last block of avd_core_forward_f32 runs out_proj / fc1 / fc2 / the final norm on the caller's
  * row window only; 0: on every row; the window's results are bit-identical), "mlp_fused" (0 default; 1: fc1 -> GELU -> fc2 of the six-term
- * bf16x3 path as ONE launch whose hidden activations stay on the CU — d = 512 only; agrees with the two launches to 1 ulp of the stream,
- * and measures 1.5x slower: DESIGN.md 4.9). */
+ * bf16x3 path as ONE launch whose hidden activations stay on the CU — d = 512 only; bit-identical to the two launches, and measures
+ * 1.5x slower: DESIGN.md 4.9). */
 int         avd_tune_set(const char* key, int64_t value);
 
 /* ---- a6: RMSNorm — avdiff/models/mmdt.py:33-42 (RMSNorm.forward)

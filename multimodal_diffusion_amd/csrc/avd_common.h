@@ -125,8 +125,13 @@ __device__ __forceinline__ float bf16_hi(unsigned int p) { return __uint_as_floa
 // Edge of the range (rare, so behind one wave-uniform test): a finite |x| > 0x1.fep127 would round to a bf16 infinity —
 // h keeps the largest finite bf16 instead and the remainder moves to m, the sum is still exact; x = +-inf gives
 // (inf, 0, 0) rather than (inf, NaN, NaN).  NaN stays NaN in every plane.
+// No contraction in here: hipcc's default -ffp-contract=fast fuses across inlined statements, and `a - h` behind a caller's
+// `a = p * q` became fma(p, q, -h) in SOME instantiations (the fused MLP's GELU epilogue, not the fc1 kernel's) — the planes then
+// summed to the unrounded product's leading bits instead of to the fp32 value a, and two kernels running the same arithmetic
+// disagreed in the last bit of a step.  With the pragma the three planes sum to v[e] exactly, in every kernel.
 template <bool RANGE_CHECK = true>     // false: the caller guarantees |v| far below the top of the range (softmax probabilities)
 __device__ __forceinline__ void split8(const float* v, u32x4& H, u32x4& Mi, u32x4& Lo) {
+#pragma clang fp contract(off)
     bool edge = false;
     if constexpr (RANGE_CHECK) {
         float amax = fabsf(v[0]);

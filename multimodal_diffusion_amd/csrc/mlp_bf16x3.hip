@@ -5,8 +5,8 @@
 // RMSNorm of gemm_bf16x3.hip), splits it into planes and parks it in LDS as four 16-k operand tiles; phase 2 multiplies those tiles
 // into the block's 128 x 512 fc2 accumulators (four waves side by side, 128 x 128 each, 256 AGPRs per lane as in gemm_bf16x3_w128_kernel)
 // — and ends in the residual + image + sums-of-squares epilogue of the two-launch path.  Same operands and the same six product terms
-// in the same order as fc1 (gemm_bf16x3_m16_kernel<3, 4, 8>) followed by fc2 (gemm_bf16x3_w128_kernel<6, RT>): the fp32 stream agrees
-// with the two launches to its last bit or two (measured: <= 1 ulp, 9.5e-7 at |y| <= 5.4; tests/test_gpu_parity.py).
+// in the same order as fc1 (gemm_bf16x3_m16_kernel<3, 4, 8>) followed by fc2 (gemm_bf16x3_w128_kernel<6, RT>): the fp32 stream is
+// bit-identical to the two launches' (tests/test_gpu_parity.py::test_fused_mlp_matches_two_launches).
 //
 // Why it is OFF by default (avd_tune_set "mlp_fused" 1 turns it on; DESIGN.md 4.9 has the numbers): the operand image of 128 rows of X
 // is 393 KB — it does not fit the 160 KB LDS beside anything, so X is streamed again for EVERY hidden chunk (32 times for hidden = 2,048)
