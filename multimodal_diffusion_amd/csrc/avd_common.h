@@ -287,6 +287,8 @@ int mlp_bf16x3(const void* X3, const void* W1n3, const float* b1, const void* W2
 extern int g_attn_pipe;          // 1 (default): the split-operand attention as one software pipeline per wave (avd_tune_set "attn_pipe")
 extern int g_s3_m16;             // 1 (default): bf16x3 GEMMs on v_mfma_f32_16x16x32_bf16, two terms per MFMA; 0: 32x32x16 (avd_tune_set "s3_m16")
 extern int g_s3_w128;            // 1: the 8-wave bf16x3 blocks with an image epilogue run as 4 waves with a 128 x 128 wave tile (avd_tune_set "s3_w128")
+extern int g_s3_rt4;             // row tiles per wave of the 4-wave image-epilogue blocks: 0 automatic, 5 .. 8 = 160 .. 256-row blocks (avd_tune_set "s3_rt4")
+extern int g_s3_deep4;           // 1: residual + image launches whose 4-wave blocks fit the CUs once run one block per CU on a four-stage ring (avd_tune_set "s3_deep4")
 extern int g_s3_rt;              // rows per 8-wave block of the residual + image epilogue: 0 automatic, 7 = 224 rows, 8 = 256 rows (avd_tune_set "s3_rt")
 extern int g_s3_tile;            // -1 = per epilogue; 0 / 1 = 8-wave 256x256 / 4-wave 256x128 blocks (avd_tune_set "s3_tile")
 extern thread_local bool t_s3_two_streams;

@@ -622,6 +622,12 @@ extern "C" int avd_tune_set(const char* key, int64_t value) {
     if (!strcmp(key, "s3_tile")) { g_s3_tile = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_m16")) { g_s3_m16 = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_rt")) { g_s3_rt = (int)value; return AVD_OK; }
+    if (!strcmp(key, "s3_rt4")) {
+        AVD_REQUIRE(value == 0 || (value >= 5 && value <= 8), AVD_EINVAL, "tune_set: s3_rt4 must be 0 (automatic) or 5 .. 8");
+        g_s3_rt4 = (int)value;
+        return AVD_OK;
+    }
+    if (!strcmp(key, "s3_deep4")) { g_s3_deep4 = value != 0; return AVD_OK; }
     if (!strcmp(key, "s3_w128")) { g_s3_w128 = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_splitk")) {
         AVD_REQUIRE(value >= 0 && value <= kS3SplitKMax, AVD_EINVAL, "tune_set: s3_splitk must be in [0, %d]", kS3SplitKMax);

@@ -876,19 +876,35 @@ __device__ __forceinline__ void s3_epilogue16(const S3Args& g, f32x4t (&acc)[8][
     }
 }
 
-// RT (8-wave blocks with an image epilogue only): row tiles per wave.  8 = 256-row blocks; 7 = 224-row blocks, chosen by the host when
-// it puts every block into ONE generation on the device's CUs (C3: 26,944 rows x 512 columns = 212 blocks of 256 x 256 on 256 CUs, 83 %
-// of the chip for the whole launch; 242 blocks of 224 x 256 use 95 % of it and each is 7/8 of the work).
-template <int EPI, int WAVES, int RT = 8>
+// RT (blocks with an image epilogue only): row tiles per wave = 32 RT rows per block.  8 waves: 8 = 256-row blocks; 7 = 224-row blocks,
+// chosen by the host when it puts every block into ONE generation on the device's CUs (C3: 26,944 rows x 512 columns = 212 blocks of
+// 256 x 256 on 256 CUs, 83 % of the chip for the whole launch; 242 blocks of 224 x 256 use 95 % of it and each is 7/8 of the work).
+// 4 waves (round 4): 5, 6, 7 — mid-size batches, where 256-row blocks leave CUs idle or give a few CUs one block more than the rest
+// (the shipped 128 x 128 geometry at batch 32, 8,512 rows: fc2 is 136 blocks of 256 x 128 on 256 CUs, 216 blocks of 160 x 128 put
+// the launch on 216 CUs with 5/8 of the work each; the host picks RT per launch, launch_s3t).
+// NSTK (4 waves): LDS stages of the ring; 0 = the configuration's two (two blocks per CU, each hiding the other's DMA round trip).
+// 4 = 144 KiB, ONE block per CU, for launches whose blocks fit the CUs once: a lone block on a two-stage ring waits out the whole DMA
+// round trip of tile kt + 1 every step (issued during step kt, needed at its end); with four stages three tiles are in flight.
+template <int EPI, int WAVES, int RT = 8, int NSTK = 0>
 __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g) {
     using Cf = S3Cfg<6, WAVES>;
-    constexpr int BM = WAVES == 8 ? 32 * RT : Cf::BM, BN = Cf::BN, WM = 16 * RT, WN = 64;
-    constexpr int RCH = Cf::RCH, STAGE = Cf::STAGE, PPW = Cf::PPW, NST = Cf::NST;
+    constexpr bool GEN4 = WAVES == 4 && RT < 8;      // 4 waves, block rows start at any multiple of 32: A staged as the 8-wave blocks stage it
+    constexpr bool GENA = WAVES == 8 || GEN4;
+    constexpr int BM = GENA ? 32 * RT : Cf::BM, BN = Cf::BN, WM = 16 * RT, WN = 64;
+    constexpr int RCH = Cf::RCH, STAGE = Cf::STAGE, NST = NSTK ? NSTK : Cf::NST;
+    static_assert(NSTK == 0 || (WAVES == 4 && NSTK * STAGE <= 160 * 1024), "deeper ring: the 4-wave blocks");
+    // DMA pieces per wave and stage.  GEN4: only the 3 RT live A pieces and the 12 of W are moved, dealt out evenly.  The last wave may be
+    // short of pieces: in a two-stage ring every wait is vmcnt(0) and it simply issues fewer; deeper rings count, so there its surplus
+    // slots repeat the last piece (same bytes to the same place)
+    constexpr int NPIECE = 3 * RT + 12;
+    constexpr int PPW = GEN4 ? (NPIECE + 3) / 4 : Cf::PPW;
     constexpr bool TR = EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG;
-    static_assert(RT == 8 || (RT == 7 && WAVES == 8 && TR), "224-row blocks: 8 waves, register image epilogue");
-    // LDS stage.  4 waves: [region A0 A1 W0][plane][128 rows][32 B] as in the 32x32 kernel.  8 waves: [A | W][plane][256 rows][32 B] —
-    // plane-major over the block's 256 staged rows, so a wave's row tiles are 512 bytes apart wherever its first row falls
-    constexpr int PS = WAVES == 8 ? 256 * 32 : S3_PLANE;              // plane stride in the stage
+    static_assert(RT == 8 || (RT == 7 && WAVES == 8 && TR) || (WAVES == 4 && RT >= 5 && RT <= 7 && TR), "short blocks: register image epilogue");
+    // LDS stage.  4 waves, RT = 8: [region A0 A1 W0][plane][128 rows][32 B] as in the 32x32 kernel.  8 waves: [A | W][plane][256 rows][32 B]
+    // — plane-major over the block's 256 staged rows, so a wave's row tiles are 512 bytes apart wherever its first row falls.
+    // 4 waves, RT < 8: A as the 8 waves have it (24 KiB), W as one region (12 KiB): the same 36 KiB
+    constexpr int PSA = GENA ? 256 * 32 : S3_PLANE;                   // plane strides of the A and W parts of the stage
+    constexpr int PSB = WAVES == 8 ? 256 * 32 : S3_PLANE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
 
     [[maybe_unused]] const unsigned long long t_entry = S3_T(), rt_entry = S3_RT();
@@ -932,16 +948,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
     // the wave's first row tile is odd in the block when RT is odd and wm = 1: its even / odd bases trade places
     const bool flip_a = ((wm * RT) & 1) != 0;
     const int abase_e = flip_a ? base_o : base_e, abase_o = flip_a ? base_e : base_o;
-    const int p1 = hiq * PS;                                         // [h|m]: p1;  [h|l]: 2 p1;  [m|h]: PS - p1;  [l|h]: 2 PS - 2 p1
-    const int a_uni = WAVES == 8 ? wm * (RT * 512) : wm * RCH;
-    const int b_uni = WAVES == 8 ? 3 * PS + wn * WN * 32 : (2 + (wn * WN) / 128) * RCH + ((wn * WN) & 127) * 32;
+    const int p1a = hiq * PSA, p1b = hiq * PSB;                      // [h|m]: p1;  [h|l]: 2 p1;  [m|h]: PS - p1;  [l|h]: 2 PS - 2 p1
+    const int a_uni = GENA ? wm * (RT * 512) : wm * RCH;
+    const int b_uni = WAVES == 8 ? 3 * PSA + wn * WN * 32 : (2 + (wn * WN) / 128) * RCH + ((wn * WN) & 127) * 32;      // (2 RCH == 3 PSA for GEN4)
     enum { T_HM = 0, T_HL = 1, T_MH = 2, T_LH = 3 };
-    auto plane_of = [&](int type) { return type == T_HM ? p1 : type == T_HL ? 2 * p1 : type == T_MH ? PS - p1 : 2 * PS - 2 * p1; };
+    auto plane_of_a = [&](int type) { return type == T_HM ? p1a : type == T_HL ? 2 * p1a : type == T_MH ? PSA - p1a : 2 * PSA - 2 * p1a; };
+    auto plane_of_b = [&](int type) { return type == T_HM ? p1b : type == T_HL ? 2 * p1b : type == T_MH ? PSB - p1b : 2 * PSB - 2 * p1b; };
     auto lda = [&](bf16x8 (&dst)[8], const unsigned char* st, int type, int i0 = 0, int i1 = 8) {
 #ifdef AVD_LAB_NOLDS       // diagnostic build: fragments stay whatever the registers hold (results are wrong by design)
         if (type >= 0) { asm volatile("" : "+v"(dst[0])); return; }
 #endif
-        const int pl = plane_of(type);
+        const int pl = plane_of_a(type);
 #pragma unroll
         for (int i = i0; i < i1; ++i)
             if (i < RT) dst[i] = *reinterpret_cast<const bf16x8*>(st + a_uni + ((i & 1) ? abase_o : abase_e) + pl + i * 512);
@@ -950,7 +967,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
 #ifdef AVD_LAB_NOLDS
         if (type >= 0) { asm volatile("" : "+v"(dst[0])); return; }
 #endif
-        const int pl = plane_of(type);
+        const int pl = plane_of_b(type);
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(st + b_uni + ((j & 1) ? base_o : base_e) + pl + j * 512);
     };
@@ -959,13 +976,28 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
     // three regions.  8 waves: piece P = 6 wave + i of 48 — P < 24: plane P / 8, rows 32 (P % 8) .. +31 of the block's A rows, which
     // start at ANY multiple of 32 (the image keeps 128-row groups: group and 32-row quarter are taken from the global row; rows past
     // the last group re-read it — their results are never stored); P >= 24: the same over the block's 256 W rows.
-    constexpr int NRW = WAVES == 4 ? 3 : PPW;
+    // GEN4: live piece n = PPW wave + i of NPIECE — n < 3 RT: plane n / RT, 32-row quarter n % RT of the block's A rows; then the 12 of W.
+    constexpr int NRW = WAVES == 4 && !GEN4 ? 3 : PPW;
     constexpr int PRW = PPW / NRW;
     const unsigned char* rbase[NRW];
     int rdst[NRW];
 #pragma unroll
     for (int r = 0; r < NRW; ++r) {
-        if constexpr (WAVES == 4) {
+        if constexpr (GEN4) {
+            int n = wave * PPW + r;
+            n = n < NPIECE ? n : NPIECE - 1;               // (a surplus slot: never issued, or a repeat of the last piece — issue_piece)
+            const bool isw = n >= 3 * RT;
+            const int pq = isw ? n - 3 * RT : n, pl = isw ? pq >> 2 : pq / RT, q = isw ? pq & 3 : pq % RT;
+            rdst[r] = isw ? 3 * PSA + pl * S3_PLANE + q * 1024 : pl * PSA + q * 1024;
+            if (!isw) {
+                const int64_t grow = (int64_t)bm * BM + 32 * q;
+                int64_t grp = grow >> 7;
+                grp = grp < nrtA ? grp : nrtA - 1;
+                rbase[r] = g.A + grp * nk * S3_CHUNK + pl * S3_PLANE + (int)((grow >> 5) & 3) * 1024;
+            } else {
+                rbase[r] = g.W + (int64_t)bn * nk * S3_CHUNK + pl * S3_PLANE + q * 1024;
+            }
+        } else if constexpr (WAVES == 4) {
             const int within = wave * PRW * 1024;
             rdst[r] = r * RCH + within;
             if (r < 2) {
@@ -977,7 +1009,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
             }
         } else {
             const int P = wave * PPW + r, isw = P >= 24, pq = isw ? P - 24 : P, pl = pq >> 3, q = pq & 7;
-            rdst[r] = (isw ? 3 * PS : 0) + pl * PS + q * 1024;
+            rdst[r] = (isw ? 3 * PSA : 0) + pl * PSA + q * 1024;
             if (!isw) {
                 const int64_t grow = (int64_t)bm * BM + 32 * q;
                 int64_t grp = grow >> 7;
@@ -990,6 +1022,9 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
     }
     const unsigned lane16 = (unsigned)lane * 16u;
     auto issue_piece = [&](int i, int kt, int buf) {
+        if constexpr (GEN4 && (NPIECE & 3) != 0 && NST == 2) {
+            if (wave * PPW + i >= NPIECE) return;           // wave-uniform
+        }
         const int r = i / PRW, k = (i % PRW) * 1024;
         __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(rbase[r] + ((int64_t)kt * S3_CHUNK + k) + lane16),
                                          AVD_LDS_PTR(smem3 + (buf * STAGE + rdst[r] + k)), 16, 0, 0);
@@ -1205,13 +1240,21 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16x3_w128_kernel(S3Args g) {
             for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc[h][i][j]));
     asm volatile("s_nop 4");
     // transposed accumulators (W fragment as the MFMA's first operand): the image epilogues want one output row per lane
-    auto mm = [&](const bf16x8 (&A_)[8], const bf16x8 (&B_)[8], int i0, int i1) {
+    // FENCE (the last MFMA group of a TAIL step): the wait states that let the MFMAs' AGPR writes land ride in the SAME asm
+    // statement as the group's last MFMA — whatever the register allocator puts at the loop's exit (it moves accumulator tiles between
+    // registers there when it likes, and pads nothing: the MFMAs are opaque to its hazard recogniser) comes behind them
+    // (a plain bool, folded after inlining: asm operands inside a GENERIC lambda do not capture — clang)
+    auto mm = [&](const bf16x8 (&A_)[8], const bf16x8 (&B_)[8], int i0, int i1, const bool FENCE) {
 #pragma unroll
         for (int i = i0; i < i1; ++i)
             if (i < RT) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j >> 2][i][j & 3]) : "v"(B_[j]), "v"(A_[i]));
+                for (int j = 0; j < 8; ++j) {
+                    if (FENCE && i == RT - 1 && j == 7)
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 15" : "+a"(acc[j >> 2][i][j & 3]) : "v"(B_[j]), "v"(A_[i]));
+                    else
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[j >> 2][i][j & 3]) : "v"(B_[j]), "v"(A_[i]));
+                }
             }
     };
 
@@ -1244,32 +1287,32 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16x3_w128_kernel(S3Args g) {
         };
         S3_SB();
         // hl + lh on fragments read during the previous step; meanwhile [m|h] of W and [h|m] of A arrive
-        mm(ahl, bp, 0, 1); slot(0); ldb(bq, st, T_MH, 0, 4); lda(ahm, st, T_HM, 0, 1); S3_SB();
-        mm(ahl, bp, 1, 2); slot(1); ldb(bq, st, T_MH, 4, 8); lda(ahm, st, T_HM, 1, 2); S3_SB();
-        mm(ahl, bp, 2, 3); slot(2); lda(ahm, st, T_HM, 2, 4); S3_SB();
-        mm(ahl, bp, 3, 4); slot(3); lda(ahm, st, T_HM, 4, 5); S3_SB();
-        mm(ahl, bp, 4, 5); slot(4); lda(ahm, st, T_HM, 5, 6); S3_SB();
-        mm(ahl, bp, 5, 6); slot(5); lda(ahm, st, T_HM, 6, 7); S3_SB();
-        mm(ahl, bp, 6, 7); slot(6); lda(ahm, st, T_HM, 7, 8); S3_SB();
-        mm(ahl, bp, 7, 8); slot(7); S3_SB();
+        mm(ahl, bp, 0, 1, false); slot(0); ldb(bq, st, T_MH, 0, 4); lda(ahm, st, T_HM, 0, 1); S3_SB();
+        mm(ahl, bp, 1, 2, false); slot(1); ldb(bq, st, T_MH, 4, 8); lda(ahm, st, T_HM, 1, 2); S3_SB();
+        mm(ahl, bp, 2, 3, false); slot(2); lda(ahm, st, T_HM, 2, 4); S3_SB();
+        mm(ahl, bp, 3, 4, false); slot(3); lda(ahm, st, T_HM, 4, 5); S3_SB();
+        mm(ahl, bp, 4, 5, false); slot(4); lda(ahm, st, T_HM, 5, 6); S3_SB();
+        mm(ahl, bp, 5, 6, false); slot(5); lda(ahm, st, T_HM, 6, 7); S3_SB();
+        mm(ahl, bp, 6, 7, false); slot(6); lda(ahm, st, T_HM, 7, 8); S3_SB();
+        mm(ahl, bp, 7, 8, false); slot(7); S3_SB();
         // hm + mh; [h|m] of W goes into the dead [l|h] registers, the next tile's [h|l] of A into the dead [h|l] registers
-        mm(ahm, bq, 0, 1); slot(8); ldb(bp, st, T_HM, 0, 4); S3_SB();
-        mm(ahm, bq, 1, 2); slot(9); ldb(bp, st, T_HM, 4, 8); S3_SB();
-        mm(ahm, bq, 2, 3); slot(10); lda(ahl, stn, T_HL, 0, 2); S3_SB();
-        mm(ahm, bq, 3, 4); slot(11); lda(ahl, stn, T_HL, 2, 4); S3_SB();
-        mm(ahm, bq, 4, 5); lda(ahl, stn, T_HL, 4, 6); S3_SB();
-        mm(ahm, bq, 5, 6); lda(ahl, stn, T_HL, 6, 8); S3_SB();
-        mm(ahm, bq, 6, 7); S3_SB();
-        mm(ahm, bq, 7, 8); S3_SB();
+        mm(ahm, bq, 0, 1, false); slot(8); ldb(bp, st, T_HM, 0, 4); S3_SB();
+        mm(ahm, bq, 1, 2, false); slot(9); ldb(bp, st, T_HM, 4, 8); S3_SB();
+        mm(ahm, bq, 2, 3, false); slot(10); lda(ahl, stn, T_HL, 0, 2); S3_SB();
+        mm(ahm, bq, 3, 4, false); slot(11); lda(ahl, stn, T_HL, 2, 4); S3_SB();
+        mm(ahm, bq, 4, 5, false); lda(ahl, stn, T_HL, 4, 6); S3_SB();
+        mm(ahm, bq, 5, 6, false); lda(ahl, stn, T_HL, 6, 8); S3_SB();
+        mm(ahm, bq, 6, 7, false); S3_SB();
+        mm(ahm, bq, 7, 8, false); S3_SB();
         // hh + mm; the next tile's [l|h] of W into the dead [m|h] registers
-        mm(ahm, bp, 0, 1); ldb(bq, stn, T_LH, 0, 4); S3_SB();
-        mm(ahm, bp, 1, 2); ldb(bq, stn, T_LH, 4, 8); S3_SB();
-        mm(ahm, bp, 2, 3); S3_SB();
-        mm(ahm, bp, 3, 4); S3_SB();
-        mm(ahm, bp, 4, 5); S3_SB();
-        mm(ahm, bp, 5, 6); S3_SB();
-        mm(ahm, bp, 6, 7); S3_SB();
-        mm(ahm, bp, 7, 8); S3_SB();
+        mm(ahm, bp, 0, 1, false); ldb(bq, stn, T_LH, 0, 4); S3_SB();
+        mm(ahm, bp, 1, 2, false); ldb(bq, stn, T_LH, 4, 8); S3_SB();
+        mm(ahm, bp, 2, 3, !MAIN); S3_SB();
+        mm(ahm, bp, 3, 4, !MAIN); S3_SB();
+        mm(ahm, bp, 4, 5, !MAIN); S3_SB();
+        mm(ahm, bp, 5, 6, !MAIN); S3_SB();
+        mm(ahm, bp, 6, 7, !MAIN); S3_SB();
+        mm(ahm, bp, 7, 8, !MAIN); S3_SB();
     };
     [[maybe_unused]] const unsigned long long t_loop = S3_T();
     {
@@ -1487,14 +1530,15 @@ int g_s3_m16 = getenv("AVD_S3_M16") ? atoi(getenv("AVD_S3_M16")) : 1;
 // rows per 8-wave block of the residual + image epilogue: 0 = automatic (224 when that saves a generation of blocks), 7 / 8 forced
 // (avd_tune_set "s3_rt", AVD_S3_RT)
 int g_s3_rt = getenv("AVD_S3_RT") ? atoi(getenv("AVD_S3_RT")) : 0;
-template <int EPI, int WAVES, int RT = 8>
+template <int EPI, int WAVES, int RT = 8, int NSTK = 0>
 static int launch_s3w16(S3Args g, hipStream_t st) {
     using Cf = S3Cfg<6, WAVES>;
     constexpr bool tile = WAVES == 4;
-    constexpr int BM = WAVES == 8 ? 32 * RT : Cf::BM;
+    constexpr int BM = WAVES == 8 || RT < 8 ? 32 * RT : Cf::BM;
+    constexpr int LDS = NSTK ? NSTK * Cf::STAGE : Cf::LDS;
     static LdsAttr attr;
-    auto kern = gemm_bf16x3_m16_kernel<EPI, WAVES, RT>;
-    if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), Cf::LDS, "gemm_bf16x3 (16x16x32)")) return rc;
+    auto kern = gemm_bf16x3_m16_kernel<EPI, WAVES, RT, NSTK>;
+    if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), LDS, "gemm_bf16x3 (16x16x32)")) return rc;
 #ifdef AVD_S3_STAMPS
     g.dbg = g_s3_dbg;
 #endif
@@ -1512,9 +1556,10 @@ static int launch_s3w16(S3Args g, hipStream_t st) {
     g.first_gen = 2 * s3_cu_count();
     if (tile && g.first_gen > 0 && nbm * g.nbn >= 2 * g.first_gen)
         g.stagger = g_s3_stagger >= 0 ? g_s3_stagger : t_s3_two_streams ? 0 : 48 * (g.K >= 1024 ? 2 : 1);
-    static const int tag = RT == 8 ? prof_tag_id("gemm_bf16x3_m16_kernel<%d, %d, 8>", EPI, WAVES) : prof_tag_id("gemm_bf16x3_m16_kernel<%d, %d, %d>", EPI, WAVES, RT);
+    // tag = the kernel name as rocprofv3 prints it (a defaulted NSTK = 0 is printed too)
+    static const int tag = prof_tag_id("gemm_bf16x3_m16_kernel<%d, %d, %d, %d>", EPI, WAVES, RT, NSTK);
     ProfScope prof(tag, 2.0 * (double)g.M * g.N * g.K, st);
-    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WAVES * 64), Cf::LDS, st, g);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nwg), dim3(WAVES * 64), LDS, st, g);
     AVD_CHECK_LAUNCH("gemm_bf16x3 (16x16x32)");
     return AVD_OK;
 }
@@ -1549,11 +1594,58 @@ static int launch_s3w128(S3Args g, hipStream_t st) {
     return AVD_OK;
 }
 
+// Rows per 4-wave block (32 RT) of the image epilogues: 0 = automatic, 5 .. 8 forced (avd_tune_set "s3_rt4", AVD_S3_RT4).
+// Automatic: the CU with the most blocks sets the launch's time, ceil(blocks / CUs) blocks of RT row tiles each, and a block carries
+// about two row tiles' worth of work that does not shrink with it (W tile DMA, barriers, the W fragment reads): RT minimises
+// ceil(blocks / CUs) x (RT + 2), and 8 stays unless a shorter block models at least 6 % better — many generations of blocks
+// (C3: 26,944 rows) keep 256-row blocks, whose W traffic and fragment reads per MFMA are the lowest.
+int g_s3_rt4 = getenv("AVD_S3_RT4") ? atoi(getenv("AVD_S3_RT4")) : 0;
+static int s3_rt4_for(int64_t M, int N) {
+    if (g_s3_rt4 >= 5 && g_s3_rt4 <= 8) return g_s3_rt4;
+    const int64_t cu = s3_cu_count() > 0 ? s3_cu_count() : 256, nbn = N / 128;
+    int best = 8;
+    int64_t cost8 = 0, cbest = 0;
+    for (int rt = 8; rt >= 5; --rt) {
+        const int64_t blocks = (M + 32 * rt - 1) / (32 * rt) * nbn, cost = (blocks + cu - 1) / cu * (rt + 2);
+        if (rt == 8) cost8 = cbest = cost;
+        else if (cost < cbest) { cbest = cost; best = rt; }
+    }
+    return cbest * 100 <= cost8 * 94 ? best : 8;
+}
+// The four-stage ring (one block per CU) of the residual + image launches: 1 (default) when the launch's blocks fit the CUs once,
+// 0 never (avd_tune_set "s3_deep4", AVD_S3_DEEP4)
+int g_s3_deep4 = getenv("AVD_S3_DEEP4") ? atoi(getenv("AVD_S3_DEEP4")) : 1;
+static bool s3_deep4_for(int64_t M, int N, int rt) {
+    const int64_t cu = s3_cu_count() > 0 ? s3_cu_count() : 256;
+    return g_s3_deep4 != 0 && (M + 32 * rt - 1) / (32 * rt) * (N / 128) <= cu;
+}
+
 template <int EPI, int TERMS>
 static int launch_s3t(const S3Args& a, hipStream_t st) {
     if constexpr (TERMS == 6 && EPI != S3_EPI_RES_NORM) {
         if (g_s3_m16) {
-            if (s3_tile_for(EPI, a.M, a.N)) return launch_s3w16<EPI, 4>(a, st);
+            if (s3_tile_for(EPI, a.M, a.N)) {
+                if constexpr (EPI == S3_EPI_RES_IMG) {
+                    const int rt = s3_rt4_for(a.M, a.N);
+                    if (s3_deep4_for(a.M, a.N, rt)) {
+                        switch (rt) {
+                            case 5: return launch_s3w16<EPI, 4, 5, 4>(a, st);
+                            case 6: return launch_s3w16<EPI, 4, 6, 4>(a, st);
+                            case 7: return launch_s3w16<EPI, 4, 7, 4>(a, st);
+                            default: return launch_s3w16<EPI, 4, 8, 4>(a, st);
+                        }
+                    }
+                }
+                if constexpr (EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG) {
+                    switch (s3_rt4_for(a.M, a.N)) {
+                        case 5: return launch_s3w16<EPI, 4, 5>(a, st);
+                        case 6: return launch_s3w16<EPI, 4, 6>(a, st);
+                        case 7: return launch_s3w16<EPI, 4, 7>(a, st);
+                        default: break;
+                    }
+                }
+                return launch_s3w16<EPI, 4>(a, st);
+            }
             constexpr bool TR = EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG;
             bool rt7 = false, rt6 = false;
             if constexpr (EPI == S3_EPI_RES_IMG) {
@@ -1637,7 +1729,13 @@ int gemm_bf16x3(const void* A3, const void* W3, const float* bias, const float* 
         return act == AVD_ACT_GELU ? launch_s3<S3_EPI_GELU_SPLIT>(a, st) : launch_s3<S3_EPI_SPLIT>(a, st);
     }
     AVD_REQUIRE(act == AVD_ACT_NONE, AVD_EUNSUPPORTED, "gemm_bf16x3: fp32 output supports act NONE only");
-    if (R) return launch_s3<S3_EPI_RES>(a, st);
+    if (R) {
+        // six-term 16x16x32 kernels: the residual + image epilogue with no image and no sums of squares to write IS the fp32 residual
+        // epilogue ((acc + bias) + R, straight from the accumulator registers) — and it has the short-block / deep-ring variants the
+        // slab epilogue lacks (the trimmed last fc2 at the shipped 128 x 128 geometry: 6,144 rows, 96 blocks of 256 x 128)
+        if ((terms == 0 || terms == 6) && g_s3_m16 && bias) return launch_s3<S3_EPI_RES_IMG>(a, st);
+        return launch_s3<S3_EPI_RES>(a, st);
+    }
     return launch_s3<S3_EPI_BIAS>(a, st);
 }
 

@@ -118,13 +118,22 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(MlpArgs g) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) asm volatile("" : "+a"(acc2[h][i][j]));
     asm volatile("s_nop 4");
-    auto mm2 = [&](const bf16x8 (&A_)[8], const bf16x8 (&B_)[8]) {
+    // FENCE (the last MFMA group of a chunk's phase 2): the wait states that let the AGPR writes land ride in the same asm
+    // statement as the last MFMA.  The register allocator moves accumulator tiles between registers at the phase boundaries and at the
+    // loop's exit when it likes, and pads nothing — the MFMAs are opaque to its hazard recogniser; whatever it puts there comes behind them
+    // (a plain bool, folded after inlining: asm operands inside a GENERIC lambda do not capture — clang)
+    auto mm2 = [&](const bf16x8 (&A_)[8], const bf16x8 (&B_)[8], const bool FENCE) {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
-                asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc2[j >> 2][i][j & 3]) : "v"(B_[j]), "v"(A_[i]));
+            for (int j = 0; j < 8; ++j) {
+                if (FENCE && i == 7 && j == 7)
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\ts_nop 15\n\ts_nop 15" : "+a"(acc2[j >> 2][i][j & 3]) : "v"(B_[j]), "v"(A_[i]));
+                else
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc2[j >> 2][i][j & 3]) : "v"(B_[j]), "v"(A_[i]));
+            }
     };
+
 #define ML_SB() __builtin_amdgcn_sched_barrier(0)
 #define ML_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(MlpArgs g) {
             }
         }
         // ================= phase 2: acc2 += H chunk x W2[:, chunk]^T, four 16-k steps =================
-        for (int kt = 0; kt < 4; ++kt) {
+        auto phase2_step = [&](const bool last, int kt) {
             wait_vm<0>();                                // this wave's pieces of W2 tile kt have landed
             ML_BARRIER();                                // ... every wave's, the H tiles are written, W2 tile kt - 1 is no longer read
             if (kt + 1 < 4) issue2(c * 4 + kt + 1, (kt + 1) & 1);
@@ -220,11 +229,13 @@ __global__ __launch_bounds__(256, 1) void mlp_bf16x3_kernel(MlpArgs g) {
             ML_SB();
             lda(ahl, T_HL); ldb(bx, T_LH); ML_SB();
             lda(ahm, T_HM); ldb(by, T_MH); ML_SB();
-            mm2(ahl, bx); ML_SB();                       // hl + lh
+            mm2(ahl, bx, false); ML_SB();            // hl + lh
             ldb(bx, T_HM); ML_SB();                      // [h|m] of W2 into the dead [l|h] registers
-            mm2(ahm, by); ML_SB();                       // hm + mh
-            mm2(ahm, bx); ML_SB();                       // hh + mm
-        }
+            mm2(ahm, by, false); ML_SB();            // hm + mh
+            mm2(ahm, bx, last); ML_SB();             // hh + mm
+        };
+        for (int kt = 0; kt < 3; ++kt) phase2_step(false, kt);
+        phase2_step(true, 3);
     }
 #undef ML_SB
 #undef ML_BARRIER
