@@ -51,12 +51,12 @@ int         avd_device_arch(char* buf, int buflen);
  * avd_core_forward_f32 when its 64x64 blocks cover less than half of the CUs — batches of a few hundred rows; 0 = never, default and maximum 4;
  * partial sums added in slice order, no atomics), "s3_tile" (-1 per epilogue, 0 = 8-wave
  * 256x256, 1 = 4-wave 256x128 blocks of the split-operand GEMMs), "s3_stagger" (first-generation stagger of co-resident 4-wave blocks,
- * x 1024 cycles; -1 automatic), "s3_min_rows" (smallest 2B*N that takes the split-operand kernels), "no_fold" (1 = keep RMSNorm as
+ * x 1024 cycles; -1 automatic), "s3_min_rows" (smallest 2B*N that takes the split-operand kernels: -1 default = 2,048 rows for the core in the six-term bf16x3 mode, 6,144 otherwise; >= 0 = that many in every mode), "no_fold" (1 = keep RMSNorm as
  * separate kernels in avd_core_forward_f32, in every mode), "s3_m16" (1 default: bf16x3 GEMMs on v_mfma_f32_16x16x32_bf16 with two product
  * terms per instruction; 0: the 32x32x16 kernel), "s3_rt" (rows per block of the bf16x3 residual + image epilogue: 0 automatic,
  * 7 = 224 rows, 8 = 256 rows, 6 = 192 rows (four-wave kernel only); results are bit-identical), "s3_rt4" (rows per 256x128-class four-wave
  * block of the bf16x3 in_proj / fc1 / out_proj / fc2 launches, in units of 32: 0 = the host picks per launch what leaves the fewest CUs idle —
- * mid-size batches — 5 .. 8 forced; bit-identical), "s3_deep4" (1 default: an out_proj / fc2 launch whose four-wave blocks fit the CUs once runs
+ * mid-size and small batches — 2 .. 8 forced (in_proj / fc1: at least 5); bit-identical), "s3_deep4" (1 default: an out_proj / fc2 launch whose four-wave blocks fit the CUs once runs
  * one block per CU on a four-stage LDS ring instead of a two-stage one; 0: never; bit-identical), "s3_w128" (1 default: the bf16x3 residual + image GEMMs run as four waves
  * with a 128 x 128 wave tile and accumulators in AGPRs; 0: eight waves with 128 x 64 tiles; bit-identical), "s3_splitk" (largest number of K slices of the fc2 launch when its blocks
  * fill at most half of the chip's block slots — small and mid-size batches; 0 = never, default and maximum 4; partial sums are added in

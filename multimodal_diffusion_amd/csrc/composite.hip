@@ -100,10 +100,17 @@ struct Carver {
 // ---------------------------------------------------------------- MMDiT.forward
 // bf16x3 matmul path (gemm_bf16x3.hip, attn_bf16x3.hip): taken when every block carries split3 weight images and the batch has
 // enough rows for the 256-row tiles
-constexpr int64_t kSplitMinRows = 6144;    // 128x128 geometry at B=32 (8,512 rows) gains 1.34x; 64x64 (3,904 rows) does not fill the tiles
-static int64_t g_s3_min_rows = [] { const char* e = getenv("AVD_S3_MIN_ROWS"); return e ? (int64_t)atoll(e) : kSplitMinRows; }();
+constexpr int64_t kSplitMinRows = 6144;    // 128x128 geometry at B=32 (8,512 rows) gains 1.34x; 64x64 (3,904 rows) does not fill the 256-row tiles
+// the six-term mode on the 16x16x32 kernels has 64 .. 224-row blocks for its residual launches (round 4): it passes the fp32 MFMA path
+// between 1,684 rows (606 against 680 steps/s) and 2,128 rows (631 against 516); 3,904 rows (C2): 549 against 462
+constexpr int64_t kSplitMinRowsM16 = 2048;
+static int64_t g_s3_min_rows = [] { const char* e = getenv("AVD_S3_MIN_ROWS"); return e ? (int64_t)atoll(e) : (int64_t)-1; }();
 static bool g_no_fold = getenv("AVD_NO_FOLD") != nullptr;
-static int64_t split_min_rows() { return g_s3_min_rows; }      // avd_tune_set "s3_min_rows": measurement aid
+// avd_tune_set "s3_min_rows" (measurement aid): -1 = the per-mode defaults above, >= 0 = that many rows in every mode
+static int64_t split_min_rows(int terms = 3) {
+    if (g_s3_min_rows >= 0) return g_s3_min_rows;
+    return (terms == 0 || terms == 6) && g_s3_m16 ? kSplitMinRowsM16 : kSplitMinRows;
+}
 // what the weights and shapes allow, whatever the process-wide tunables say (workspace sizing: core_ws_bytes)
 static bool core_split_capable(const avd_core_weights* w, int64_t M) {
     if (w->norm_kind != 0) return false;
@@ -118,7 +125,7 @@ static bool core_split_capable(const avd_core_weights* w, int64_t M) {
 }
 static bool core_use_split(const avd_core_weights* w, int64_t M) {
     // (the reduced-precision one-term mode is an explicit request, not a speed heuristic: it takes the split kernels at any size)
-    if (M < split_min_rows() && w->split_terms != 1 && w->attn_mode != 1) return false;
+    if (M < split_min_rows(w->split_terms) && w->split_terms != 1 && w->attn_mode != 1) return false;
     return core_split_capable(w, M);
 }
 
@@ -623,7 +630,7 @@ extern "C" int avd_tune_set(const char* key, int64_t value) {
     if (!strcmp(key, "s3_m16")) { g_s3_m16 = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_rt")) { g_s3_rt = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_rt4")) {
-        AVD_REQUIRE(value == 0 || (value >= 5 && value <= 8), AVD_EINVAL, "tune_set: s3_rt4 must be 0 (automatic) or 5 .. 8");
+        AVD_REQUIRE(value == 0 || (value >= 2 && value <= 8), AVD_EINVAL, "tune_set: s3_rt4 must be 0 (automatic) or 2 .. 8");
         g_s3_rt4 = (int)value;
         return AVD_OK;
     }

@@ -879,7 +879,7 @@ __device__ __forceinline__ void s3_epilogue16(const S3Args& g, f32x4t (&acc)[8][
 // RT (blocks with an image epilogue only): row tiles per wave = 32 RT rows per block.  8 waves: 8 = 256-row blocks; 7 = 224-row blocks,
 // chosen by the host when it puts every block into ONE generation on the device's CUs (C3: 26,944 rows x 512 columns = 212 blocks of
 // 256 x 256 on 256 CUs, 83 % of the chip for the whole launch; 242 blocks of 224 x 256 use 95 % of it and each is 7/8 of the work).
-// 4 waves (round 4): 5, 6, 7 — mid-size batches, where 256-row blocks leave CUs idle or give a few CUs one block more than the rest
+// 4 waves (round 4): 2 .. 7 (2 .. 4 for the residual launches only) — mid-size and small batches, where 256-row blocks leave CUs idle or give a few CUs one block more than the rest
 // (the shipped 128 x 128 geometry at batch 32, 8,512 rows: fc2 is 136 blocks of 256 x 128 on 256 CUs, 216 blocks of 160 x 128 put
 // the launch on 216 CUs with 5/8 of the work each; the host picks RT per launch, launch_s3t).
 // NSTK (4 waves): LDS stages of the ring; 0 = the configuration's two (two blocks per CU, each hiding the other's DMA round trip).
@@ -899,7 +899,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
     constexpr int NPIECE = 3 * RT + 12;
     constexpr int PPW = GEN4 ? (NPIECE + 3) / 4 : Cf::PPW;
     constexpr bool TR = EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG;
-    static_assert(RT == 8 || (RT == 7 && WAVES == 8 && TR) || (WAVES == 4 && RT >= 5 && RT <= 7 && TR), "short blocks: register image epilogue");
+    static_assert(RT == 8 || (RT == 7 && WAVES == 8 && TR) || (WAVES == 4 && RT >= 2 && RT <= 7 && TR), "short blocks: register image epilogue");
     // LDS stage.  4 waves, RT = 8: [region A0 A1 W0][plane][128 rows][32 B] as in the 32x32 kernel.  8 waves: [A | W][plane][256 rows][32 B]
     // — plane-major over the block's 256 staged rows, so a wave's row tiles are 512 bytes apart wherever its first row falls.
     // 4 waves, RT < 8: A as the 8 waves have it (24 KiB), W as one region (12 KiB): the same 36 KiB
@@ -1594,19 +1594,21 @@ static int launch_s3w128(S3Args g, hipStream_t st) {
     return AVD_OK;
 }
 
-// Rows per 4-wave block (32 RT) of the image epilogues: 0 = automatic, 5 .. 8 forced (avd_tune_set "s3_rt4", AVD_S3_RT4).
+// Rows per 4-wave block (32 RT) of the image epilogues: 0 = automatic, 2 .. 8 forced (avd_tune_set "s3_rt4", AVD_S3_RT4; in_proj / fc1
+// have no blocks shorter than 5 row tiles and take 5 for less).
 // Automatic: the CU with the most blocks sets the launch's time, ceil(blocks / CUs) blocks of RT row tiles each, and a block carries
-// about two row tiles' worth of work that does not shrink with it (W tile DMA, barriers, the W fragment reads): RT minimises
-// ceil(blocks / CUs) x (RT + 2), and 8 stays unless a shorter block models at least 6 % better — many generations of blocks
+// about three row tiles' worth of work that does not shrink with it (W tile DMA, barriers, the W fragment reads; fitted to the
+// residual launches at 3,904 rows: 71.4 / 60.8 / 56.7 / 45.1 us for RT = 5 / 4 / 3 / 2): RT minimises ceil(blocks / CUs) x (RT + 3),
+// and 8 stays unless a shorter block models at least 6 % better — many generations of blocks
 // (C3: 26,944 rows) keep 256-row blocks, whose W traffic and fragment reads per MFMA are the lowest.
 int g_s3_rt4 = getenv("AVD_S3_RT4") ? atoi(getenv("AVD_S3_RT4")) : 0;
-static int s3_rt4_for(int64_t M, int N) {
-    if (g_s3_rt4 >= 5 && g_s3_rt4 <= 8) return g_s3_rt4;
+static int s3_rt4_for(int64_t M, int N, int rt_min) {
+    if (g_s3_rt4 >= 2 && g_s3_rt4 <= 8) return g_s3_rt4 > rt_min ? g_s3_rt4 : rt_min;
     const int64_t cu = s3_cu_count() > 0 ? s3_cu_count() : 256, nbn = N / 128;
     int best = 8;
     int64_t cost8 = 0, cbest = 0;
-    for (int rt = 8; rt >= 5; --rt) {
-        const int64_t blocks = (M + 32 * rt - 1) / (32 * rt) * nbn, cost = (blocks + cu - 1) / cu * (rt + 2);
+    for (int rt = 8; rt >= rt_min; --rt) {
+        const int64_t blocks = (M + 32 * rt - 1) / (32 * rt) * nbn, cost = (blocks + cu - 1) / cu * (rt + 3);
         if (rt == 8) cost8 = cbest = cost;
         else if (cost < cbest) { cbest = cost; best = rt; }
     }
@@ -1626,9 +1628,12 @@ static int launch_s3t(const S3Args& a, hipStream_t st) {
         if (g_s3_m16) {
             if (s3_tile_for(EPI, a.M, a.N)) {
                 if constexpr (EPI == S3_EPI_RES_IMG) {
-                    const int rt = s3_rt4_for(a.M, a.N);
+                    const int rt = s3_rt4_for(a.M, a.N, 2);
                     if (s3_deep4_for(a.M, a.N, rt)) {
                         switch (rt) {
+                            case 2: return launch_s3w16<EPI, 4, 2, 4>(a, st);
+                            case 3: return launch_s3w16<EPI, 4, 3, 4>(a, st);
+                            case 4: return launch_s3w16<EPI, 4, 4, 4>(a, st);
                             case 5: return launch_s3w16<EPI, 4, 5, 4>(a, st);
                             case 6: return launch_s3w16<EPI, 4, 6, 4>(a, st);
                             case 7: return launch_s3w16<EPI, 4, 7, 4>(a, st);
@@ -1636,8 +1641,16 @@ static int launch_s3t(const S3Args& a, hipStream_t st) {
                         }
                     }
                 }
+                if constexpr (EPI == S3_EPI_RES_IMG) {
+                    switch (s3_rt4_for(a.M, a.N, 2)) {
+                        case 2: return launch_s3w16<EPI, 4, 2>(a, st);
+                        case 3: return launch_s3w16<EPI, 4, 3>(a, st);
+                        case 4: return launch_s3w16<EPI, 4, 4>(a, st);
+                        default: break;
+                    }
+                }
                 if constexpr (EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG) {
-                    switch (s3_rt4_for(a.M, a.N)) {
+                    switch (s3_rt4_for(a.M, a.N, 5)) {
                         case 5: return launch_s3w16<EPI, 4, 5>(a, st);
                         case 6: return launch_s3w16<EPI, 4, 6>(a, st);
                         case 7: return launch_s3w16<EPI, 4, 7>(a, st);
