@@ -1641,6 +1641,8 @@ static int launch_s3t(const S3Args& a, hipStream_t st) {
                         }
                     }
                 }
+                // (in_proj / fc1 on the four-stage ring when their blocks fit the CUs once: measured, no gain — K = 512 is 32 steps, and at
+                // 3,904 rows in_proj's 252 blocks run 62 us two to a CU and 79 us one to a CU; they keep the two-stage ring)
                 if constexpr (EPI == S3_EPI_RES_IMG) {
                     switch (s3_rt4_for(a.M, a.N, 2)) {
                         case 2: return launch_s3w16<EPI, 4, 2>(a, st);

@@ -26,7 +26,11 @@ $B $C5 --cpu-steps 1 > $OUT/bench_c5_bf16x3.json 2>> $OUT/bench.err || exit 1
 $B $C5 --matmul f16x2 --no-cpu-baseline > $OUT/bench_c5_f16x2.json 2>> $OUT/bench.err || exit 1
 $B $C5 --matmul f16x2 --attn fp8 --cpu-steps 1 > $OUT/bench_c5_f16x2_fp8attn.json 2>> $OUT/bench.err || exit 1
 $B $C5 --attn fp8 --no-cpu-baseline > $OUT/bench_c5_bf16x3_fp8attn.json 2>> $OUT/bench.err || exit 1
+$B $C2 --no-cpu-baseline > $OUT/bench_c2.json 2>> $OUT/bench.err || exit 1                             # C2 in the default (six-term bf16x3) mode
 $B --size 128 --batch 32 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_128.json 2>> $OUT/bench.err || exit 1
+$B --size 128 --batch 16 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_128_b16.json 2>> $OUT/bench.err || exit 1
+$B --size 128 --batch 8 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_128_b8.json 2>> $OUT/bench.err || exit 1
+$B --batch 8 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_c3_b8.json 2>> $OUT/bench.err || exit 1
 $B --size 32 --batch 4 --steps 200 --warmup 20 --no-alt --cpu-steps 3 --matmul f32 > $OUT/bench_c1_gpu.json 2>> $OUT/bench.err || exit 1
 
 step "round-4 A/B lines (tune keys through the environment)"
@@ -36,6 +40,11 @@ AVD_ATTN_PIPE=0 $AB > $OUT/bench_ab_attn_plain.json 2>> $OUT/bench.err || exit 1
 AVD_CORE_TRIM=0 $AB > $OUT/bench_ab_notrim.json 2>> $OUT/bench.err || exit 1             # last block on every row
 $AB > $OUT/bench_ab_default.json 2>> $OUT/bench.err || exit 1                            # the default, same flags, right after
 AVD_CORE_TRIM=0 $B --size 128 --batch 32 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_ab_128_notrim.json 2>> $OUT/bench.err || exit 1
+# mid-size batches: 256-row blocks on the two-stage ring everywhere (round 3), and the round-3 row threshold of the split path
+AVD_S3_RT4=8 AVD_S3_DEEP4=0 $B --size 128 --batch 32 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_ab_128_rt8.json 2>> $OUT/bench.err || exit 1
+AVD_S3_DEEP4=0 $B --size 128 --batch 32 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_ab_128_nodeep.json 2>> $OUT/bench.err || exit 1
+AVD_S3_MIN_ROWS=6144 $B $C2 --no-cpu-baseline > $OUT/bench_ab_c2_minrows6144.json 2>> $OUT/bench.err || exit 1
+AVD_S3_MIN_ROWS=6144 $B --size 128 --batch 8 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_ab_128_b8_minrows6144.json 2>> $OUT/bench.err || exit 1
 AVD_GEMM_SPLITK=0 $B --size 32 --batch 4 --steps 200 --warmup 20 --no-alt --no-cpu-baseline --matmul f32 > $OUT/bench_ab_c1_nosplitk.json 2>> $OUT/bench.err || exit 1
 
 step "rocprofv3 kernel traces"
