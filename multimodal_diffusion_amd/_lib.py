@@ -206,7 +206,7 @@ def stream_ptr(device: torch.device) -> int:
 
 # matrix-pipe modes of the MMDiT core / engine -> product terms of the split-operand kernels (avd_core_weights.split_terms)
 # "auto" (the modules' default): the exact three-plane bf16x3 kernels wherever the library's own rule engages them (RMSNorm, no
-# key-padding mask, >= 6,144 rows, widths the 256-column tiles cover) and the fp32 MFMA kernels — with the norms folded into their
+# key-padding mask, >= 2,048 rows 2BN — 6,144 for the head and in the other split modes —, widths the 256-column tiles cover) and the fp32 MFMA kernels — with the norms folded into their
 # neighbours — everywhere else; same fp32-level results either way
 MATMUL_TERMS = {"auto": 6, "f32": 0, "bf16x3": 6, "bf16x3_strict": 9, "bf16": 1, "f16x2": 3}
 

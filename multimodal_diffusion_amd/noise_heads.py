@@ -72,7 +72,7 @@ class MultiModalNoiseHead(nn.Module):
         self.apply(_init_linear)
         self._ws: Optional[torch.Tensor] = None
         # matrix-pipe mode of the Linears, as MMDiT.matmul ("auto" | "f32" | "bf16x3" | "bf16x3_strict" | "bf16" | "f16x2"); shapes the
-        # split kernels do not cover (d_out % 256, fewer than 6144 rows) stay on the fp32 MFMA kernels
+        # split kernels do not cover (d_out % 256, fewer than 6,144 rows) stay on the fp32 MFMA kernels
         self.matmul = "auto"
         self._images: dict = {}
 

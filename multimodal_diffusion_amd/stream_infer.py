@@ -124,7 +124,7 @@ def stream_generate(*, cfg: Dict, vid_vae, aud_codec, adapt_v, adapt_a, core, he
     backend, the CPU for gloo) hands them to all ranks, rank r steps windows ``dist.shard_range(N_windows, r, world)``, one
     all-gather collects the finished latents, and rank 0 decodes, stitches and returns the result — the other ranks return None.
     Windows never interact inside the loop, so the stitched output equals the single-process one bit for bit as long as both runs
-    take the same kernels (the matrix-pipe mode "auto" switches kernels at 6,144 rows: fix ``core.matmul`` to compare across sizes).
+    take the same kernels (the matrix-pipe mode "auto" switches kernels at 2,048 / 6,144 rows: fix ``core.matmul`` to compare across sizes).
     """
     st = cfg.get("streaming", {})
     win_s, hop_s = float(st.get("window_seconds", 3.0)), float(st.get("hop_seconds", 1.0))

@@ -28,7 +28,7 @@ av, aa = A.LinearAdapter(256, 256), A.LinearAdapter(32, 256)
 av.load_state_dict(ws["adapt_v"])
 aa.load_state_dict(ws["adapt_a"])
 core, head, av, aa = (m.to(dev) for m in (core, head, av, aa))
-core.matmul = head.matmul = "f32"          # one kernel family whatever the shard size (the "auto" rule switches at 6,144 rows)
+core.matmul = head.matmul = "f32"          # one kernel family whatever the shard size (the "auto" rule switches at 2,048 / 6,144 rows)
 torch.manual_seed(8)                       # identical codec / VAE weights on both ranks
 vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval().to(dev)
 codec = A.AudioCodec.from_config({"sr": 16000, "latent": {"channels": 8, "frames_per_clip": 150}, "codec": {"hop_samples": 320}}).eval().to(dev)
