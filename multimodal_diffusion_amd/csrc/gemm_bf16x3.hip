@@ -898,7 +898,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
     // slots repeat the last piece (same bytes to the same place)
     constexpr int NPIECE = 3 * RT + 12;
     constexpr int PPW = GEN4 ? (NPIECE + 3) / 4 : Cf::PPW;
-    constexpr bool TR = EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG;
+    constexpr bool TR = EPI == S3_EPI_GELU_SPLIT || EPI == S3_EPI_SPLIT || EPI == S3_EPI_QKV3 || EPI == S3_EPI_RES_IMG || EPI == S3_EPI_BIAS_REG;
     static_assert(RT == 8 || (RT == 7 && WAVES == 8 && TR) || (WAVES == 4 && RT >= 2 && RT <= 7 && TR), "short blocks: register image epilogue");
     // LDS stage.  4 waves, RT = 8: [region A0 A1 W0][plane][128 rows][32 B] as in the 32x32 kernel.  8 waves: [A | W][plane][256 rows][32 B]
     // — plane-major over the block's 256 staged rows, so a wave's row tiles are 512 bytes apart wherever its first row falls.
@@ -1627,6 +1627,23 @@ static int launch_s3t(const S3Args& a, hipStream_t st) {
     if constexpr (TERMS == 6 && EPI != S3_EPI_RES_NORM) {
         if (g_s3_m16) {
             if (s3_tile_for(EPI, a.M, a.N)) {
+                // the noise head's launches (fp32 out with a bias: shared Linears, out_proj; image out: input_proj) when their blocks fit the
+                // CUs once — short blocks, one per CU, on the four-stage ring; EPI_BIAS then runs from the registers (S3_EPI_BIAS_REG)
+                if constexpr (EPI == S3_EPI_BIAS || EPI == S3_EPI_SPLIT) {
+                    constexpr int E2 = EPI == S3_EPI_BIAS ? (int)S3_EPI_BIAS_REG : (int)S3_EPI_SPLIT;
+                    const int rt = s3_rt4_for(a.M, a.N, 2);
+                    if (a.bias && a.N % 128 == 0 && s3_deep4_for(a.M, a.N, rt)) {
+                        switch (rt) {
+                            case 2: return launch_s3w16<E2, 4, 2, 4>(a, st);
+                            case 3: return launch_s3w16<E2, 4, 3, 4>(a, st);
+                            case 4: return launch_s3w16<E2, 4, 4, 4>(a, st);
+                            case 5: return launch_s3w16<E2, 4, 5, 4>(a, st);
+                            case 6: return launch_s3w16<E2, 4, 6, 4>(a, st);
+                            case 7: return launch_s3w16<E2, 4, 7, 4>(a, st);
+                            default: return launch_s3w16<E2, 4, 8, 4>(a, st);
+                        }
+                    }
+                }
                 if constexpr (EPI == S3_EPI_RES_IMG) {
                     const int rt = s3_rt4_for(a.M, a.N, 2);
                     if (s3_deep4_for(a.M, a.N, rt)) {

@@ -13,7 +13,8 @@ namespace avd {
 // 7: bias + residual, fp32 out AND the operand image of RMSNorm(out) — the block owns whole rows (128 x 512 block, N == 512), so the
 // norm that follows the residual add (mmdt.py:97-98 -> 39-42) is finished inside the epilogue; f16x2 images (a normalised row has the
 // bound its image scale needs, the un-normalised stream has none)
-enum { S3_EPI_BIAS = 0, S3_EPI_RES = 2, S3_EPI_GELU_SPLIT = 3, S3_EPI_QKV3 = 4, S3_EPI_SPLIT = 5, S3_EPI_RES_IMG = 6, S3_EPI_RES_NORM = 7 };
+enum { S3_EPI_BIAS = 0, S3_EPI_RES = 2, S3_EPI_GELU_SPLIT = 3, S3_EPI_QKV3 = 4, S3_EPI_SPLIT = 5, S3_EPI_RES_IMG = 6, S3_EPI_RES_NORM = 7,
+       S3_EPI_BIAS_REG = 8 };   // EPI_BIAS (fp32 out = acc + bias) run from the accumulator registers: the 16x16x32 kernels' short-block variants
 
 struct S3Args {
     const unsigned char* A;   // split3 image of [M][K]
@@ -80,7 +81,7 @@ __device__ __forceinline__ void s3_epilogue_img16(const S3Args& g, f32x4t (&acc)
     const int l15 = lane & 15, kq = lane >> 4;
     // range test over the valid rows (lane (l15, kq) of row tile i holds output row 16 i + l15 before the exchange)
     bool big = EPI == S3_EPI_RES_IMG;
-    if constexpr (EPI != S3_EPI_RES_IMG) {
+    if constexpr (EPI != S3_EPI_RES_IMG && EPI != S3_EPI_BIAS_REG) {
         float amax = 0.f;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -120,7 +121,7 @@ __device__ __forceinline__ void s3_epilogue_img16(const S3Args& g, f32x4t (&acc)
         const int tile = 2 * ip + (kq & 1);
         const int64_t m = (RT == 8 || tile < RT) ? mwave0 + 16 * tile + l15 : g.M;      // a dead tile's rows fail every m < M test below
         float rinv = 1.0f;
-        if (EPI != S3_EPI_RES_IMG && g.ss_in != nullptr && m < g.M) {
+        if (EPI != S3_EPI_RES_IMG && EPI != S3_EPI_BIAS_REG && g.ss_in != nullptr && m < g.M) {
             const int nc = g.K >> 6;
             const float* sp = g.ss_in + m * nc;
             float ssum = 0.f;
@@ -170,6 +171,14 @@ __device__ __forceinline__ void s3_epilogue_img16(const S3Args& g, f32x4t (&acc)
                     *reinterpret_cast<u32x4*>(dst) = Hh;
                     *reinterpret_cast<u32x4*>(dst + 128) = Mi;
                     *reinterpret_cast<u32x4*>(dst + 256) = Lo;
+                }
+            } else if constexpr (EPI == S3_EPI_BIAS_REG) {
+                if (S3_ROW_OK(m)) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += bv[j][e];
+                    float* cp = g.C + m * g.N + n;
+                    *reinterpret_cast<f32x4*>(cp) = f32x4{v[0], v[1], v[2], v[3]};
+                    *reinterpret_cast<f32x4*>(cp + 4) = f32x4{v[4], v[5], v[6], v[7]};
                 }
             } else if constexpr (EPI == S3_EPI_RES_IMG) {
                 if (S3_ROW_OK(m)) {
