@@ -1391,6 +1391,46 @@ def test_default_mode_is_the_headline_mode(dev):
     assert torch.isfinite(out_small).all()
 
 
+@pytest.mark.parametrize("N,K", [(512, 512), (256, 64), (512, 2048)])
+def test_split_gemm_short_blocks_ragged_rows(dev, N, K):
+    """The short-block / four-stage-ring variants of the four-wave split GEMM at the C ABI (avd_gemm_bf16x3_f32), at row counts that do
+    not fit anything: 1 row, one row either side of a 32-row piece and of a 160-row block, a prime, a 128-row group plus one — fewer rows
+    than one block, last blocks that start in the image's last 128-row group, blocks whose upper waves own no valid row.  For every
+    epilogue the C ABI reaches (fp32 out with bias: the register bias epilogue; + residual: the residual epilogue without an image;
+    GELU -> operand image) every block size (avd_tune_set "s3_rt4" 2 .. 8) on either ring ("s3_deep4") returns the bits of the 256-row
+    blocks, and those are within the fp32 FMA chain's bound of the fp64 product."""
+    from multimodal_diffusion_amd import functional as Fn, _lib as L
+    g = torch.Generator().manual_seed(N + K)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    w3 = Fn.split3(w.to(dev))
+    for M in (1, 31, 33, 159, 161, 257, 1009, 2049):
+        x = torch.randn(M, K, generator=g)
+        r = torch.randn(M, N, generator=g)
+        x3 = Fn.split3(x.to(dev))
+        ref = x.double() @ w.double().t() + b.double()
+        outs = {}
+        try:
+            for rt, deep in ((8, 0), (8, 1), (7, 1), (6, 0), (5, 1), (4, 0), (3, 1), (2, 0), (2, 1), (0, 1)):
+                _tune("s3_rt4", rt)
+                _tune("s3_deep4", deep)
+                _tune("s3_tile", 1)
+                outs[rt, deep] = (Fn.linear_bf16x3(x3, M, w3, N, K, bias=b.to(dev)).cpu(),
+                                  Fn.linear_bf16x3(x3, M, w3, N, K, bias=b.to(dev), residual=r.to(dev)).cpu(),
+                                  Fn.linear_bf16x3(x3, M, w3, N, K, bias=b.to(dev), act=L.ACT_GELU, out_split3=True).cpu())
+        finally:
+            _tune("s3_rt4", 0)
+            _tune("s3_deep4", 1)
+            _tune("s3_tile", -1)
+        base = outs[8, 0]
+        bound = 2.0 * K * 2.0 ** -24 * (x.double().abs() @ w.double().abs().t() + b.double().abs()) + 1e-30
+        assert ((base[0].double() - ref).abs() <= bound).all(), (M, float(((base[0].double() - ref).abs() / bound).max()))
+        assert ((base[1].double() - ref - r.double()).abs() <= bound + 2.0 ** -23 * (ref + r.double()).abs()).all(), M
+        for key, o in outs.items():
+            for which in range(3):
+                assert torch.equal(o[which], base[which]), (M, key, which)
+
+
 # ------------------------------------------------------------------------------------------------- bf16x3 adversarial suite
 def _bf16x3_vs_f32(dev, x, w, b=None, strict=False):
     """(bf16x3 result, fp32-MFMA result, fp64 reference, sum_k |x_k w_k|) for y = x w^T (+ b)."""
