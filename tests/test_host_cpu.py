@@ -214,3 +214,24 @@ def test_checkpoint_interop(tmp_path, small_model):
     CK.load_trainer_checkpoint(p2, mods, use_ema=True)
     assert torch.equal(mods["core"].state_dict()["final_norm.scale"], ema["final_norm.scale"])
     assert CK.load_trainer_checkpoint(tr, fresh(64) | {"adapt_v": None, "adapt_a": None})["temb_mode"] is None
+
+
+def test_agpr_hazard_lint_on_synthetic_listings(tmp_path):
+    """tools/check_agpr_hazards.py (run by build() on the two kernels whose MFMAs are asm statements): an AGPR read one slot behind the
+    asm-statement MFMA that wrote it fails the lint; the same read behind the kernels' `s_nop 15` pair passes; an MFMA the compiler
+    emitted itself (outside ASMSTART / ASMEND: its hazard recogniser pads it) is not counted."""
+    import subprocess
+    import sys
+    tool = str(ROOT / "tools" / "check_agpr_hazards.py")
+    head = "_ZN3avd4testEv:\n"
+    mfma = "\t;;#ASMSTART\n\tv_mfma_f32_16x16x32_bf16 a[4:7], v[0:3], v[4:7], a[4:7]\n\t;;#ASMEND\n"
+    bad = head + mfma + "\tv_accvgpr_read_b32 v9, a5\n"
+    good = head + mfma.replace("a[4:7]\n\t;;#ASMEND", "a[4:7]\n\ts_nop 15\n\ts_nop 15\n\t;;#ASMEND") + "\tv_accvgpr_read_b32 v9, a5\n"
+    own = head + "\tv_mfma_f32_16x16x32_bf16 a[4:7], v[0:3], v[4:7], a[4:7]\n\tv_accvgpr_read_b32 v9, a5\n"
+    other = head + mfma + "\tv_accvgpr_read_b32 v9, a9\n"          # a different register: no dependence
+    for name, text, rc, word in (("bad", bad, 1, "FAIL"), ("good", good, 0, "ok"), ("own", own, 0, ""), ("other", other, 0, "")):
+        f = tmp_path / f"{name}.s"
+        f.write_text(text)
+        r = subprocess.run([sys.executable, tool, str(f)], capture_output=True, text=True)
+        assert r.returncode == rc, (name, r.stdout, r.stderr)
+        assert word in r.stdout, (name, r.stdout)
