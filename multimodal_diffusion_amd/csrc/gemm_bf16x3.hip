@@ -937,6 +937,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
     }
     const int nk = g.K >> 4;
     const int nrtA = (int)((g.M + 127) >> 7);
+#ifdef AVD_LAB_ALIAS       // diagnostic build (tools/micro/s3_phase.py): bit 0 — every block stages row block 0 of A, bit 1 — column block 0 of W:
+    // the same instruction stream and L2 -> LDS bytes with (almost) every piece an L2 hit; results are wrong by design
+    const int bm_s = (AVD_LAB_ALIAS & 1) ? 0 : bm, bn_s = (AVD_LAB_ALIAS & 2) ? 0 : bn;
+#else
+    const int bm_s = bm, bn_s = bn;
+#endif
 
     // fragment addressing (see the header of this section): per-lane base for even row tiles, odd tiles flip the k-half slot;
     // the plane a lane reads depends on its k-group pair (kq >> 1) and on the fragment's pair type
@@ -990,33 +996,33 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
             const int pq = isw ? n - 3 * RT : n, pl = isw ? pq >> 2 : pq / RT, q = isw ? pq & 3 : pq % RT;
             rdst[r] = isw ? 3 * PSA + pl * S3_PLANE + q * 1024 : pl * PSA + q * 1024;
             if (!isw) {
-                const int64_t grow = (int64_t)bm * BM + 32 * q;
+                const int64_t grow = (int64_t)bm_s * BM + 32 * q;
                 int64_t grp = grow >> 7;
                 grp = grp < nrtA ? grp : nrtA - 1;
                 rbase[r] = g.A + grp * nk * S3_CHUNK + pl * S3_PLANE + (int)((grow >> 5) & 3) * 1024;
             } else {
-                rbase[r] = g.W + (int64_t)bn * nk * S3_CHUNK + pl * S3_PLANE + q * 1024;
+                rbase[r] = g.W + (int64_t)bn_s * nk * S3_CHUNK + pl * S3_PLANE + q * 1024;
             }
         } else if constexpr (WAVES == 4) {
             const int within = wave * PRW * 1024;
             rdst[r] = r * RCH + within;
             if (r < 2) {
-                int rt = bm * 2 + r;
+                int rt = bm_s * 2 + r;
                 rt = rt < nrtA ? rt : nrtA - 1;
                 rbase[r] = g.A + (int64_t)rt * nk * S3_CHUNK + within;
             } else {
-                rbase[r] = g.W + (int64_t)bn * nk * S3_CHUNK + within;
+                rbase[r] = g.W + (int64_t)bn_s * nk * S3_CHUNK + within;
             }
         } else {
             const int P = wave * PPW + r, isw = P >= 24, pq = isw ? P - 24 : P, pl = pq >> 3, q = pq & 7;
             rdst[r] = (isw ? 3 * PSA : 0) + pl * PSA + q * 1024;
             if (!isw) {
-                const int64_t grow = (int64_t)bm * BM + 32 * q;
+                const int64_t grow = (int64_t)bm_s * BM + 32 * q;
                 int64_t grp = grow >> 7;
                 grp = grp < nrtA ? grp : nrtA - 1;
                 rbase[r] = g.A + grp * nk * S3_CHUNK + pl * S3_PLANE + (int)((grow >> 5) & 3) * 1024;
             } else {
-                rbase[r] = g.W + (int64_t)(bn * 2 + (q >> 2)) * nk * S3_CHUNK + pl * S3_PLANE + (q & 3) * 1024;
+                rbase[r] = g.W + (int64_t)(bn_s * 2 + (q >> 2)) * nk * S3_CHUNK + pl * S3_PLANE + (q & 3) * 1024;
             }
         }
     }
@@ -1130,6 +1136,13 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
     S3_DBG(4, t_issued);
     S3_DBG(0, t_entry); S3_DBG(1, t_loop); S3_DBG(2, t_end); S3_DBG(3, S3_T());
     S3_DBG(8, (unsigned long long)nk); S3_DBG(9, S3_RT()); S3_DBG(10, rt_entry);
+    {   // which XCD and CU ran the block, and which tile it was (tools/micro/s3_phase.py replays the stage traffic through an L2 model)
+        unsigned xcc, hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        S3_DBG(11, (unsigned long long)(xcc & 15u) | ((unsigned long long)hwid << 8));
+        S3_DBG(12, (unsigned long long)(unsigned)bm | ((unsigned long long)(unsigned)bn << 32));
+    }
 #endif
 }
 
@@ -1485,6 +1498,26 @@ static int s3_cu_count() {                 // CUs of the current device (looked 
     return n;
 }
 
+// Super-tiles: the blocks an XCD runs together (consecutive ids after the XCD remap) form sm x sn blocks that share sm A panels and sn W
+// panels.  256x128 tiles (tile = true, two blocks per CU): whole block rows per super-tile when the launch has at most 16 column blocks, so
+// the 12-16 column blocks that share an A panel run together and the panel is fetched into the XCD's L2 once (in_proj at C3: 2.02 -> 1.84
+// ms per step); 32 blocks per super-tile, 16 for the one-block-per-CU tiles.
+// AVD_S3_SN / AVD_S3_SUPER4 / AVD_S3_SUPER8: measurement aids (super-tile width in blocks / blocks per super-tile of the two-per-CU and
+// one-per-CU kernels); profiles/r05_fetch_ab.txt holds the FETCH_SIZE of fc1 / in_proj across them.
+static void s3_supertile(bool tile, int nbn, int& sn_out, int& sm_out) {
+    int sn = 8;
+    while (nbn % sn) sn >>= 1;
+    if (tile && nbn <= 16) sn = nbn;
+    int total = tile ? 32 : 16;
+    static const int e_sn = getenv("AVD_S3_SN") ? atoi(getenv("AVD_S3_SN")) : 0;
+    static const int e_tot4 = getenv("AVD_S3_SUPER4") ? atoi(getenv("AVD_S3_SUPER4")) : 0;
+    static const int e_tot8 = getenv("AVD_S3_SUPER8") ? atoi(getenv("AVD_S3_SUPER8")) : 0;
+    if (e_sn > 0) { sn = e_sn < nbn ? e_sn : nbn; while (nbn % sn) --sn; }
+    if ((tile ? e_tot4 : e_tot8) > 0) total = tile ? e_tot4 : e_tot8;
+    sn_out = sn;
+    sm_out = total / sn > 0 ? total / sn : 1;
+}
+
 template <int EPI, int TERMS, int WAVES>
 static int launch_s3w(S3Args g, hipStream_t st, int nz = 1) {
     using Cf = S3Cfg<TERMS, WAVES, EPI == S3_EPI_RES_NORM>;
@@ -1496,20 +1529,7 @@ static int launch_s3w(S3Args g, hipStream_t st, int nz = 1) {
     g.dbg = g_s3_dbg;
 #endif
     g.nbn = g.N / Cf::BN;
-    int sn = 8;
-    while (g.nbn % sn) sn >>= 1;
-    // 256x128 tiles: whole block rows per super-tile, so the 12-16 column blocks that share an A panel run together and the panel
-    // is fetched into the XCD's L2 once (in_proj at C3: 2.02 -> 1.84 ms per step)
-    if (tile && g.nbn <= 16) sn = g.nbn;
-    int total = tile ? 32 : 16;
-    {   // AVD_S3_SN / AVD_S3_SUPER4 / AVD_S3_SUPER8: measurement aids (super-tile width in blocks / blocks per super-tile)
-        static const int e_sn = getenv("AVD_S3_SN") ? atoi(getenv("AVD_S3_SN")) : 0;
-        static const int e_tot = getenv(tile ? "AVD_S3_SUPER4" : "AVD_S3_SUPER8") ? atoi(getenv(tile ? "AVD_S3_SUPER4" : "AVD_S3_SUPER8")) : 0;
-        if (e_sn > 0) { sn = e_sn < g.nbn ? e_sn : g.nbn; while (g.nbn % sn) --sn; }
-        if (e_tot > 0) total = e_tot;
-    }
-    g.sn = sn;
-    g.sm = total / sn > 0 ? total / sn : 1;
+    s3_supertile(tile, g.nbn, g.sn, g.sm);
     const int64_t nbm = (g.M + Cf::BM - 1) / Cf::BM;
     const int64_t nwg = (nbm + g.sm - 1) / g.sm * g.sm * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
@@ -1543,12 +1563,7 @@ static int launch_s3w16(S3Args g, hipStream_t st) {
     g.dbg = g_s3_dbg;
 #endif
     g.nbn = g.N / Cf::BN;
-    int sn = 8;
-    while (g.nbn % sn) sn >>= 1;
-    if (tile && g.nbn <= 16) sn = g.nbn;
-    const int total = tile ? 32 : 16;
-    g.sn = sn;
-    g.sm = total / sn > 0 ? total / sn : 1;
+    s3_supertile(tile, g.nbn, g.sn, g.sm);
     const int64_t nbm = (g.M + BM - 1) / BM;
     const int64_t nwg = (nbm + g.sm - 1) / g.sm * g.sm * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
@@ -1578,10 +1593,7 @@ static int launch_s3w128(S3Args g, hipStream_t st) {
     g.dbg = g_s3_dbg;
 #endif
     g.nbn = g.N / 256;
-    int sn = 8;
-    while (g.nbn % sn) sn >>= 1;
-    g.sn = sn;
-    g.sm = 16 / sn > 0 ? 16 / sn : 1;
+    s3_supertile(false, g.nbn, g.sn, g.sm);
     const int64_t nbm = (g.M + BM - 1) / BM;
     const int64_t nwg = (nbm + g.sm - 1) / g.sm * g.sm * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
