@@ -40,20 +40,37 @@ def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def broadcast_conditioning(cond: Optional[torch.Tensor], shape: Tuple[int, ...], device: torch.device,
-                           src: int = 0) -> torch.Tensor:
-    """Root holds ``cond`` [B_global, ...]; every rank returns the full tensor after ONE broadcast."""
+                           src: int = 0, error: Optional[BaseException] = None) -> torch.Tensor:
+    """Root holds ``cond`` [B_global, ...]; every rank returns the full tensor after ONE broadcast.
+
+    The broadcast buffer carries one status word behind the payload.  ``error`` (source rank only): something went wrong while the
+    conditioning was being prepared (a failed encode, a shape the config does not imply).  The source then still enters the
+    broadcast — with the status word cleared — and raises ``error`` afterwards; every other rank raises a ``RuntimeError`` instead of
+    waiting for a broadcast that never comes."""
     world = dist.get_world_size() if dist.is_initialized() else 1
     if world == 1:
+        if error is not None:
+            raise error
         if cond is None:
             raise ValueError("single-process run needs the conditioning tensor")
         return cond.to(device)
     rank = dist.get_rank()
-    buf = cond.to(device=device, dtype=torch.float32).contiguous() if rank == src else \
-        torch.empty(shape, dtype=torch.float32, device=device)
-    if tuple(buf.shape) != tuple(shape):
-        raise ValueError("conditioning shape mismatch on the source rank")
+    n = 1
+    for s_ in shape:
+        n *= int(s_)
+    buf = torch.zeros(n + 1, dtype=torch.float32, device=device)
+    if rank == src:
+        if error is None and (cond is None or tuple(cond.shape) != tuple(shape)):
+            error = ValueError("conditioning shape mismatch on the source rank")
+        if error is None:
+            buf[:n] = cond.to(device=device, dtype=torch.float32).reshape(-1)
+            buf[n] = 1.0
     dist.broadcast(buf, src=src)
-    return buf
+    if rank == src and error is not None:
+        raise error
+    if float(buf[n].item()) != 1.0:
+        raise RuntimeError(f"rank {src} failed while preparing the conditioning (its own log has the error); nothing was broadcast")
+    return buf[:n].view(tuple(shape))
 
 
 def local_conditioning(cond_global: torch.Tensor, rank: int, world: int) -> torch.Tensor:
@@ -61,9 +78,11 @@ def local_conditioning(cond_global: torch.Tensor, rank: int, world: int) -> torc
     return cond_global[lo:hi].contiguous()
 
 
-def gather_batch(local: torch.Tensor, global_batch: int) -> torch.Tensor:
-    """Optional epilogue of the sharded loop: every rank returns the finished latents of the WHOLE batch,
-    [global_batch, ...], shards in rank order (one all-gather; shard sizes may differ by one sample)."""
+def gather_batch(local: torch.Tensor, global_batch: int, dst: Optional[int] = None) -> Optional[torch.Tensor]:
+    """Optional epilogue of the sharded loop: the finished items of the WHOLE batch, [global_batch, ...], shards in rank
+    order (shard sizes may differ by one item; any dtype).  ``dst=None``: one all-gather, every rank returns the batch.  ``dst=r``: one
+    gather to rank r — the others return None and receive nothing (decoded frames are 9.4 MB per 256 x 256 window: an all-gather
+    would push every rank's frames over every xGMI link for a result only the stitching rank reads)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local
     world, rank = dist.get_world_size(), dist.get_rank()
@@ -73,23 +92,34 @@ def gather_batch(local: torch.Tensor, global_batch: int) -> torch.Tensor:
     pad = max(hi - lo for lo, hi in sizes)
     buf = local.new_zeros((pad,) + tuple(local.shape[1:]))
     buf[:local.shape[0]] = local
-    parts = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(parts, buf.contiguous())
+    buf = buf.contiguous()
+    if dst is None:
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+    else:
+        parts = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
+        dist.gather(buf, parts, dst=dst)
+        if rank != dst:
+            return None
     return torch.cat([p[:hi - lo] for p, (lo, hi) in zip(parts, sizes)], dim=0)
 
 
 def run_sharded(n_items: int, cond: Optional[torch.Tensor], cond_shape: Tuple[int, ...], comm_device: torch.device, fn,
-                src: int = 0) -> torch.Tensor:
+                src: int = 0, result: str = "all", error: Optional[BaseException] = None) -> Optional[torch.Tensor]:
     """The data-parallel layout of SURVEY 8e as one call: ``cond`` [n_items, ...] (held by rank ``src``; the others pass None) is
     broadcast ONCE, rank r runs ``fn(cond[lo:hi], lo, hi)`` on its contiguous shard ``[lo, hi) = shard_range(n_items, r, world)``
-    — ``fn`` returns a tensor whose first dimension is ``hi - lo`` — and every rank gets the results of the WHOLE batch back in
-    item order (one all-gather, ragged shards allowed).  No communication inside ``fn``.  Single process: ``fn(cond, 0, n_items)``.
-    A rank whose shard is empty (more ranks than items) calls ``fn`` with an empty slice and must return an empty tensor."""
+    — ``fn`` returns a tensor whose first dimension is ``hi - lo`` (any dtype: latents, or what the rank DECODED from them) — and the
+    results come back in item order: ``result="all"`` on every rank (one all-gather), ``result="root"`` on rank ``src`` only (one
+    gather; the other ranks return None).  Ragged shards allowed.  No communication inside ``fn``.  Single process:
+    ``fn(cond, 0, n_items)``.  A rank whose shard is empty (more ranks than items) calls ``fn`` with an empty slice and must return an
+    empty tensor with the same trailing shape.  ``error``: see ``broadcast_conditioning``."""
     if tuple(cond_shape)[:1] != (n_items,):
         raise ValueError("cond_shape must start with n_items")
+    if result not in ("all", "root"):
+        raise ValueError("result must be 'all' or 'root'")
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    full = broadcast_conditioning(cond, tuple(cond_shape), comm_device, src=src)
+    full = broadcast_conditioning(cond, tuple(cond_shape), comm_device, src=src, error=error)
     lo, hi = shard_range(n_items, rank, world)
     out = fn(full[lo:hi], lo, hi)
     if out.shape[0] != hi - lo:
@@ -97,7 +127,8 @@ def run_sharded(n_items: int, cond: Optional[torch.Tensor], cond_shape: Tuple[in
     if world == 1:
         return out
     back = out.device
-    return gather_batch(out.to(comm_device).contiguous(), n_items).to(back)
+    got = gather_batch(out.to(comm_device).contiguous(), n_items, dst=None if result == "all" else src)
+    return None if got is None else got.to(back)
 
 
 def max_over_ranks(value: float, device: torch.device) -> float:

@@ -5,8 +5,9 @@ The reference splits the prompt into windows (3 s window / 1 s hop), calls ``sam
 batch: the prompt windows are encoded together, ``DenoiseEngine`` steps all windows at once (they are the natural
 large-batch feed for the data-parallel path), the outputs are decoded together and stitched by a HIP kernel.
 With ``shard=True`` under ``torch.distributed`` the windows are the units of the data-parallel layout: rank 0 encodes the
-prompt windows, ONE broadcast hands them to every rank, each rank steps its contiguous share of the windows with no further
-communication, one all-gather returns the finished latents and rank 0 decodes and stitches.
+prompt windows, ONE broadcast hands them to every rank, each rank steps AND DECODES its contiguous share of the windows with no
+further communication (the reference ends every window's call with its own decode, sample_clip.py:392 via stream_infer.py:182-188,
+207-213), one gather brings the decoded windows — uint8 frames or waveforms — to rank 0, which only stitches.
 
 ``split_*`` are host-side slicing (as in the reference); the fade tables are built on the host with the reference's
 fp32 numpy expressions and uploaded; ``crossfade_*`` keep the reference's numpy-in / numpy-out signatures.
@@ -121,10 +122,14 @@ def stream_generate(*, cfg: Dict, vid_vae, aud_codec, adapt_v, adapt_a, core, he
 
     ``shard=True`` (every rank of the default process group calls this with the same arguments; one process per GPU): rank 0 encodes
     the prompt windows, ONE broadcast (``dist.broadcast_conditioning``; over ``comm_device``, default: ``device`` for the nccl = RCCL
-    backend, the CPU for gloo) hands them to all ranks, rank r steps windows ``dist.shard_range(N_windows, r, world)``, one
-    all-gather collects the finished latents, and rank 0 decodes, stitches and returns the result — the other ranks return None.
-    Windows never interact inside the loop, so the stitched output equals the single-process one bit for bit as long as both runs
-    take the same kernels (the matrix-pipe mode "auto" switches kernels at 2,048 / 6,144 rows: fix ``core.matmul`` to compare across sizes).
+    backend, the CPU for gloo) hands them to all ranks, rank r steps windows ``dist.shard_range(N_windows, r, world)`` and decodes them
+    (``vid_vae.decode`` -> uint8 frames / ``aud_codec.decode`` -> waveform: per rank N_windows / world loops AND decodes — the decode is
+    8 ms per 256 x 256 window against 14 ms for its 50-step loop, so leaving it on one rank would cap an 8-rank run near 2x), one
+    gather brings the decoded windows to rank 0, which stitches and returns the result — the other ranks return None.
+    If rank 0 fails before the broadcast (encode error, a prompt shape the config does not imply), every rank raises.
+    Windows never interact inside the loop or the decode, so the stitched output equals the single-process one bit for bit as long as
+    both runs take the same kernels (the matrix-pipe mode "auto" switches kernels at 2,048 / 6,144 rows: fix ``core.matmul`` to
+    compare across sizes).
     """
     st = cfg.get("streaming", {})
     win_s, hop_s = float(st.get("window_seconds", 3.0)), float(st.get("hop_seconds", 1.0))
@@ -162,15 +167,27 @@ def stream_generate(*, cfg: Dict, vid_vae, aud_codec, adapt_v, adapt_a, core, he
         guide = float(cfg["sampling"]["guidance_scale"].get("video", 3.0))
     else:
         raise ValueError("prompt_modality must be 'video' or 'audio'")
-    z_p = None
+    z_p, root_error = None, None
     if root:
-        if prompt_modality == "video":
-            frames = torch.from_numpy(np.ascontiguousarray(chunks)).to(device).float() / 255.0      # [N,T,H,W,3]
-            z_p = vid_vae.encode(frames.permute(0, 4, 1, 2, 3).contiguous())
-        else:
-            z_p = aud_codec.encode(torch.from_numpy(np.ascontiguousarray(chunks, dtype=np.float32)).to(device)[:, None, :])
-        if tuple(z_p.shape) != zp_shape:
-            raise L.AvdError(f"encoded prompt windows have shape {tuple(z_p.shape)}, the config implies {zp_shape}")
+        try:
+            if prompt_modality == "video":
+                frames = torch.from_numpy(np.ascontiguousarray(chunks)).to(device).float() / 255.0      # [N,T,H,W,3]
+                z_p = vid_vae.encode(frames.permute(0, 4, 1, 2, 3).contiguous())
+            else:
+                z_p = aud_codec.encode(torch.from_numpy(np.ascontiguousarray(chunks, dtype=np.float32)).to(device)[:, None, :])
+            if tuple(z_p.shape) != zp_shape:
+                if world > 1:       # the other ranks sized their buffers from the config
+                    raise L.AvdError(f"encoded prompt windows have shape {tuple(z_p.shape)}, the config implies {zp_shape}")
+                # single process (e.g. a caller-supplied encoder): the encoder's own output decides, as in the reference
+                zp_shape = tuple(z_p.shape)
+                if prompt_modality == "video":
+                    n_prompt = (zp_shape[2] // t_p) * (zp_shape[3] // p) * (zp_shape[4] // p)
+                else:
+                    n_prompt = (zp_shape[-1] - l_chunk) // s_chunk + 1
+        except Exception as exc:            # noqa: BLE001 — re-raised below; a sharded run first tells the other ranks
+            if world == 1:
+                raise
+            root_error = exc
 
     c = cfg["diffusion"][target]
     abar = su.alphas_cumprod_from_betas(su.make_beta_schedule(int(c["steps"]), kind=c["schedule"], min_beta=c["min_beta"],
@@ -202,21 +219,31 @@ def stream_generate(*, cfg: Dict, vid_vae, aud_codec, adapt_v, adapt_a, core, he
             return torch.empty(0, *lat, device=device)
         return torch.cat(outs, 0) if len(outs) > 1 else outs[0]
 
+    def decode_windows(z: torch.Tensor) -> torch.Tensor:
+        """finished latents of some windows -> what the stitcher takes: waveforms [n, L] float32 or frames [n, T, H, W, 3] uint8"""
+        if target == "audio":
+            if z.shape[0] == 0:
+                hop_a = int(getattr(aud_codec, "hop", 0)) or int(round(sr * float(cfg["data"]["clip_seconds"]))) // Fa
+                return torch.empty(0, Fa * hop_a, device=device)
+            return aud_codec.decode(z)[:, 0, :].contiguous()
+        if z.shape[0] == 0:
+            return torch.empty(0, lat[1] * t_down, lat[2] * s_down, lat[3] * s_down, 3, dtype=torch.uint8, device=device)
+        x = vid_vae.decode(z).clamp(0, 1)                                         # [n,3,T,H,W]
+        return (x.permute(0, 2, 3, 4, 1) * 255.0).to(torch.uint8).contiguous()    # as the reference's astype(np.uint8)
+
     if world > 1:
         if comm_device is None:
             comm_device = device if tdist.get_backend() == "nccl" else torch.device("cpu")
-        z = D.run_sharded(Nw, z_p if root else None, zp_shape, comm_device, denoise)
+        out = D.run_sharded(Nw, z_p if root else None, zp_shape, comm_device, lambda part, lo, hi: decode_windows(denoise(part, lo, hi)),
+                            result="root", error=root_error)
         if not root:
             return None
-        z = z.to(device)
+        out = out.to(device)
     else:
-        z = denoise(z_p, 0, Nw)
+        out = decode_windows(denoise(z_p, 0, Nw))
 
     if target == "audio":
-        wav = aud_codec.decode(z)[:, 0, :].contiguous()                       # [N, L]
-        w = torch.from_numpy(audio_fade_window(wav.shape[1], int(round(sr * xfade_s))))
-        return {"audio": crossfade_tensor(wav, w, int(round(sr * hop_s))).cpu().numpy(), "sr": sr}
-    x = vid_vae.decode(z).clamp(0, 1)                                         # [N,3,T,H,W]
-    frames_u8 = (x.permute(0, 2, 3, 4, 1) * 255.0).to(torch.uint8).contiguous()   # as the reference's astype(np.uint8)
-    w = torch.from_numpy(video_fade_window(frames_u8.shape[1], int(round(xfade_s * fps))))
-    return {"video": crossfade_tensor(frames_u8, w, int(round(fps * hop_s))).cpu().numpy(), "fps": fps}
+        w = torch.from_numpy(audio_fade_window(out.shape[1], int(round(sr * xfade_s))))
+        return {"audio": crossfade_tensor(out, w, int(round(sr * hop_s))).cpu().numpy(), "sr": sr}
+    w = torch.from_numpy(video_fade_window(out.shape[1], int(round(xfade_s * fps))))
+    return {"video": crossfade_tensor(out, w, int(round(fps * hop_s))).cpu().numpy(), "fps": fps}

@@ -1,6 +1,7 @@
 """Worker of tests/test_dist_gloo.py::test_stream_generate_sharded_two_ranks_share_device: `stream_generate(shard=True)` under
-`python -m torch.distributed.run --nproc-per-node 2` with gloo, both ranks on cuda:0; rank 0 then runs the same generation in one
-process and writes whether the two stitched results are bit-identical."""
+`python -m torch.distributed.run --nproc-per-node 2` with gloo, both ranks on cuda:0 — each rank steps AND decodes its own windows,
+one gather of the decoded windows to rank 0 — in both directions (audio prompt -> uint8 video, video prompt -> waveform); rank 0 then
+runs the same generations in one process and writes whether the stitched results are bit-identical."""
 import json
 import os
 import sys
@@ -44,13 +45,22 @@ kw = dict(cfg=cfg, vid_vae=vae, aud_codec=codec, adapt_v=av, adapt_a=aa, core=co
 n_win = S.split_audio_into_windows(wav, sr=16000, win_s=0.5, hop_s=0.25)[0].shape[0]
 
 sharded = S.stream_generate(shard=True, **kw)
-none_elsewhere = D.gather_scalars(1.0 if sharded is None else 0.0, torch.device("cpu"))
+# the V -> A twin: 12 frames at 16 fps = 0.75 s -> windows of 8 frames at a hop of 4: two windows (one per rank), audio out
+vid = torch.randint(0, 256, (12, 32, 32, 3), generator=torch.Generator().manual_seed(11), dtype=torch.uint8).numpy()
+kw_a = dict(kw, prompt_modality="video", prompt_video=vid, prompt_audio=None, seed=12)
+n_win_a = S.split_frames_into_windows(vid, fps=16, win_s=0.5, hop_s=0.25)[0].shape[0]
+sharded_a = S.stream_generate(shard=True, **kw_a)
+none_elsewhere = D.gather_scalars(1.0 if (sharded is None and sharded_a is None) else 0.0, torch.device("cpu"))
 D.barrier()
 torch.distributed.destroy_process_group()
 if rank == 0:
     single = S.stream_generate(shard=False, **kw)
+    single_a = S.stream_generate(shard=False, **kw_a)
     same = sharded is not None and sharded["video"].dtype == np.uint8 and np.array_equal(sharded["video"], single["video"])
+    same_a = sharded_a is not None and sharded_a["audio"].dtype == np.float32 and np.array_equal(sharded_a["audio"], single_a["audio"])
     Path(os.environ["AVD_TEST_OUT"]).write_text(json.dumps({
         "world": world, "windows": int(n_win), "shards": [list(D.shard_range(n_win, r, world)) for r in range(world)],
         "rank1_returned_none": none_elsewhere == [0.0, 1.0], "frames_shape": list(single["video"].shape),
-        "bit_identical": bool(same), "max_abs_diff": int(np.abs(sharded["video"].astype(np.int32) - single["video"].astype(np.int32)).max())}))
+        "bit_identical": bool(same), "max_abs_diff": int(np.abs(sharded["video"].astype(np.int32) - single["video"].astype(np.int32)).max()),
+        "audio_windows": int(n_win_a), "audio_len": int(single_a["audio"].shape[0]), "audio_bit_identical": bool(same_a),
+        "audio_finite_nonzero": bool(np.isfinite(single_a["audio"]).all() and np.abs(single_a["audio"]).max() > 0)}))

@@ -75,6 +75,33 @@ def _shard_worker(rank, world, port, out):
     # more ranks than items: the empty shard contributes nothing and every rank still gets the whole result
     one = D.run_sharded(1, torch.ones(1, 4) if rank == 0 else None, (1, 4), torch.device("cpu"), lambda c, a, b: c * 3.0)
     ok = ok and torch.equal(one, torch.full((1, 4), 3.0))
+    # result="root" — what stream_generate(shard=True) uses since round 5: every rank DECODES its own items (here: a uint8 stand-in of
+    # another trailing shape than the conditioning) and ONE gather brings them to rank 0 only; ragged shards; the other ranks get None
+    def decode(cond_part, lo, hi):
+        return (cond_part.sum((1, 2)).to(torch.int64)[:, None, None] + torch.arange(lo, hi)[:, None, None] + torch.arange(10).view(1, 2, 5)).to(torch.uint8)
+    frames = D.run_sharded(n, cond_all if rank == 0 else None, (n, 2, 3), torch.device("cpu"), decode, result="root")
+    want_f = (cond_all.sum((1, 2)).to(torch.int64)[:, None, None] + torch.arange(n)[:, None, None] + torch.arange(10).view(1, 2, 5)).to(torch.uint8)
+    ok = ok and ((frames is None) if rank else (frames.dtype == torch.uint8 and torch.equal(frames, want_f)))
+    # more ranks than items with result="root": rank 1's shard is empty, it returns an empty tensor of the right trailing shape
+    one_r = D.run_sharded(1, torch.ones(1, 4) if rank == 0 else None, (1, 4), torch.device("cpu"),
+                          lambda c, a, b: (c[:, :2] * 5.0).to(torch.uint8), result="root")
+    ok = ok and ((one_r is None) if rank else torch.equal(one_r, torch.full((1, 2), 5, dtype=torch.uint8)))
+    # rank 0 fails while preparing the conditioning: every rank raises instead of waiting for a broadcast that never comes
+    try:
+        D.run_sharded(n, None, (n, 2, 3), torch.device("cpu"), step, error=KeyError("encode failed") if rank == 0 else None)
+        raised = None
+    except KeyError as e:
+        raised = "src:" + str(e)
+    except RuntimeError as e:
+        raised = "peer:" + str(e)[:6]
+    ok = ok and raised == ("src:'encode failed'" if rank == 0 else "peer:rank 0")
+    # ... and a conditioning whose shape the other ranks did not expect is reported the same way
+    try:
+        D.run_sharded(n, cond_all[:, :1] if rank == 0 else None, (n, 2, 3), torch.device("cpu"), step)
+        raised = None
+    except (ValueError, RuntimeError) as e:
+        raised = type(e).__name__
+    ok = ok and raised == ("ValueError" if rank == 0 else "RuntimeError")
     D.barrier()
     out.put((rank, bool(ok)))
     dist.destroy_process_group()
@@ -83,7 +110,9 @@ def _shard_worker(rank, world, port, out):
 def test_run_sharded_world2():
     """dist.run_sharded — the library entry stream_generate(shard=True) is built on: ONE broadcast of the conditioning from rank 0,
     contiguous (ragged) shards, the per-shard function called once per rank with exactly its slice, one all-gather of the results in
-    item order; world size 2 over gloo on CPU with a stand-in step."""
+    item order — or, result="root" (every rank decodes its own windows), one gather of the decoded uint8
+    items to rank 0 only; more ranks than items; a rank-0 failure before the broadcast raises on EVERY rank.
+    World size 2 over gloo on CPU with a stand-in step."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -105,6 +134,11 @@ def test_run_sharded_single_process():
         D.run_sharded(5, c, (4, 2), torch.device("cpu"), lambda part, lo, hi: part)
     with pytest.raises(ValueError):
         D.run_sharded(5, c, (5, 2), torch.device("cpu"), lambda part, lo, hi: part[:1])
+    assert torch.equal(D.run_sharded(5, c, (5, 2), torch.device("cpu"), lambda part, lo, hi: part * 2, result="root"), c * 2)
+    with pytest.raises(ValueError):
+        D.run_sharded(5, c, (5, 2), torch.device("cpu"), lambda part, lo, hi: part, result="some")
+    with pytest.raises(KeyError):
+        D.run_sharded(5, c, (5, 2), torch.device("cpu"), lambda part, lo, hi: part, error=KeyError("x"))
 
 
 def test_bench_setup_under_torchrun(tmp_path):
@@ -164,9 +198,11 @@ def test_bench_two_ranks_share_device():
 @pytest.mark.gpu_first
 def test_stream_generate_sharded_two_ranks_share_device(tmp_path):
     """The library's data-parallel entry on hardware: `stream_generate(shard=True)` launched as two FRESH
-    child ranks under `python -m torch.distributed.run` (gloo for the one broadcast and the one all-gather, both ranks on cuda:0).
-    Rank 0 then repeats the generation single-process in the same worker and compares: the stitched uint8 video of the sharded run
-    equals the single-process result BIT FOR BIT (tests/_stream_shard_worker.py).  This process never touches the device."""
+    child ranks under `python -m torch.distributed.run` (gloo for the one broadcast and the one gather, both ranks on cuda:0).  Since
+    round 5 every rank also DECODES its own windows (VideoVAE / AudioCodec on each rank) and the gather carries
+    decoded uint8 frames / waveforms to rank 0, which only stitches.  Rank 0 then repeats the generation single-process in the same
+    worker and compares: the stitched uint8 video (audio prompt) and the stitched waveform (video prompt, the V -> A twin) of the
+    sharded runs equal the single-process results BIT FOR BIT (tests/_stream_shard_worker.py).  This process never touches the device."""
     import json
     import subprocess
     import sys
@@ -186,3 +222,5 @@ def test_stream_generate_sharded_two_ranks_share_device(tmp_path):
     assert d["world"] == 2 and d["windows"] == 4 and d["shards"] == [[0, 2], [2, 4]], d
     assert d["rank1_returned_none"] and d["frames_shape"][1:] == [32, 32, 3]
     assert d["bit_identical"], d
+    assert d["rank1_returned_none"], d
+    assert d["audio_windows"] == 2 and d["audio_len"] == 52000 and d["audio_finite_nonzero"] and d["audio_bit_identical"], d
