@@ -1502,18 +1502,18 @@ static int s3_cu_count() {                 // CUs of the current device (looked 
 // panels.  256x128 tiles (tile = true, two blocks per CU): whole block rows per super-tile when the launch has at most 16 column blocks, so
 // the 12-16 column blocks that share an A panel run together and the panel is fetched into the XCD's L2 once (in_proj at C3: 2.02 -> 1.84
 // ms per step); 32 blocks per super-tile, 16 for the one-block-per-CU tiles.
-// AVD_S3_SN / AVD_S3_SUPER4 / AVD_S3_SUPER8: measurement aids (super-tile width in blocks / blocks per super-tile of the two-per-CU and
-// one-per-CU kernels); profiles/r05_fetch_ab.txt holds the FETCH_SIZE of fc1 / in_proj across them.
+// AVD_S3_SN / AVD_S3_SUPER4 / AVD_S3_SUPER8 (avd_tune_set "s3_sn" / "s3_super4" / "s3_super8"): measurement aids — super-tile width in blocks /
+// blocks per super-tile of the two-per-CU and one-per-CU kernels; profiles/r05_fetch_ab.txt holds the FETCH_SIZE of fc1 / in_proj across them.
+int g_s3_sn = getenv("AVD_S3_SN") ? atoi(getenv("AVD_S3_SN")) : 0;                  // avd_tune_set "s3_sn": 0 = the rule below
+int g_s3_super4 = getenv("AVD_S3_SUPER4") ? atoi(getenv("AVD_S3_SUPER4")) : 0;      // avd_tune_set "s3_super4" / "s3_super8": 0 = 32 / 16 blocks
+int g_s3_super8 = getenv("AVD_S3_SUPER8") ? atoi(getenv("AVD_S3_SUPER8")) : 0;
 static void s3_supertile(bool tile, int nbn, int& sn_out, int& sm_out) {
     int sn = 8;
     while (nbn % sn) sn >>= 1;
     if (tile && nbn <= 16) sn = nbn;
     int total = tile ? 32 : 16;
-    static const int e_sn = getenv("AVD_S3_SN") ? atoi(getenv("AVD_S3_SN")) : 0;
-    static const int e_tot4 = getenv("AVD_S3_SUPER4") ? atoi(getenv("AVD_S3_SUPER4")) : 0;
-    static const int e_tot8 = getenv("AVD_S3_SUPER8") ? atoi(getenv("AVD_S3_SUPER8")) : 0;
-    if (e_sn > 0) { sn = e_sn < nbn ? e_sn : nbn; while (nbn % sn) --sn; }
-    if ((tile ? e_tot4 : e_tot8) > 0) total = tile ? e_tot4 : e_tot8;
+    if (g_s3_sn > 0) { sn = g_s3_sn < nbn ? g_s3_sn : nbn; while (nbn % sn) --sn; }
+    if ((tile ? g_s3_super4 : g_s3_super8) > 0) total = tile ? g_s3_super4 : g_s3_super8;
     sn_out = sn;
     sm_out = total / sn > 0 ? total / sn : 1;
 }
