@@ -218,6 +218,22 @@ class PowerClockSampler:
                 "note": "pp_dpm_sclk reads up to ~10 % above the in-kernel clock of an MFMA-dense loop (MI355X_MICROARCH.md, DVFS give-back 6)"}
 
 
+def workload_name(size: int, B: int) -> str:
+    """Which BASELINE.json configuration (SURVEY 8d's mapping) a geometry is: the default line is C3; the other geometries are
+    parity / record runs and must not carry C3's name."""
+    if size == 256:
+        return "C3" if B == 32 else f"C3 geometry at batch {B}"
+    if size == 32:
+        return "C1" if B == 4 else f"C1 geometry at batch {B}"
+    if size == 64:
+        return "C2" if B == 32 else f"C2 geometry at batch {B}"
+    if size == 512:
+        return "C5 per-GPU shard" if B == 8 else f"C5 geometry at batch {B}"
+    if size == 128:
+        return f"shipped mvp.yaml geometry (not a BASELINE config) at batch {B}"
+    return f"{size}x{size} at batch {B} (not a BASELINE config)"
+
+
 def step_flops_per_sample(nv: int, na: int, d: int = 512, L: int = 8, hid: int = 2048, tok: int = 256,
                           head_hidden: int = 512, tdim: int = 256) -> float:
     """Algorithmic FLOPs of one CFG step for one sample (head on target rows only)."""
@@ -448,7 +464,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": MODE_DTYPE[args.matmul] + ("; attention in fp8 e4m3 (reduced precision)" if args.attn == "fp8" else ""),
             "data": "synthetic",
-            "config": {"workload": f"C3: {size}x{size} audio->video CFG denoising step (cond+null MMDiT d512 L8 H8 + noise head + "
+            "config": {"workload": f"{workload_name(size, B)}: {size}x{size} audio->video CFG denoising step (cond+null MMDiT d512 L8 H8 + noise head + "
                                    f"DDIM), {nv}+{na} tokens, batch {B} per GPU, DDIM {S} steps, guidance {args.guidance}",
                        "global_batch": B * world, "tokens": nv + na, "sampler_steps": S,
                        "parallelism": f"dp{world}", "launch": "hipgraph" if args.graph else "eager", "matmul": args.matmul, "attn": args.attn,

@@ -494,7 +494,11 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
                 o1[r0] = c0; o1[r0 + 1] = c1;
             } else {
                 split_pair(0, w - 24, pf[0]);
-                asm volatile("" : "+v"(pf[0][0][w - 24]), "+v"(pf[0][1][w - 24]), "+v"(pf[0][2][w - 24]));
+                // (name only the planes this mode writes: an unwritten plane as a read-write operand would read an uninitialised register
+                // and pin it for nothing — ADVICE r4)
+                if constexpr (NPL == 3) asm volatile("" : "+v"(pf[0][0][w - 24]), "+v"(pf[0][1][w - 24]), "+v"(pf[0][2][w - 24]));
+                else if constexpr (NPL == 2) asm volatile("" : "+v"(pf[0][0][w - 24]), "+v"(pf[0][1][w - 24]));
+                else asm volatile("" : "+v"(pf[0][0][w - 24]));
             }
         };
         if constexpr (MORE) {

@@ -123,9 +123,14 @@ static bool core_split_capable(const avd_core_weights* w, int64_t M) {
     }
     return true;
 }
+// Rows of the WHOLE step when avd_denoise_step_f32 runs its cond / null halves as two calls on two streams (0 otherwise): the kernel
+// family is chosen once per step from the stacked 2B x N row count and both halves take it, so the one-stream and the two-stream layouts
+// stay bit-identical in the band where one half alone would fall under the row threshold (2,048 <= 2 B N < 4,096 rows).
+static thread_local int64_t t_step_rows = 0;
 static bool core_use_split(const avd_core_weights* w, int64_t M) {
     // (the reduced-precision one-term mode is an explicit request, not a speed heuristic: it takes the split kernels at any size)
-    if (M < split_min_rows(w->split_terms) && w->split_terms != 1 && w->attn_mode != 1) return false;
+    const int64_t Mt = t_step_rows > M ? t_step_rows : M;
+    if (Mt < split_min_rows(w->split_terms) && w->split_terms != 1 && w->attn_mode != 1) return false;
     return core_split_capable(w, M);
 }
 
@@ -437,7 +442,10 @@ static bool head_split_capable(const avd_head_weights* w, int64_t rows) {
     return gemm_bf16x3_supported(rows, w->hidden, w->d_in) && gemm_bf16x3_supported(rows, w->hidden, w->hidden) &&
            gemm_bf16x3_supported(rows, w->d_out, w->hidden);
 }
-static bool head_use_split(const avd_head_weights* w, int64_t rows) { return rows >= split_min_rows() && head_split_capable(w, rows); }
+static thread_local int64_t t_step_head_rows = 0;      // as t_step_rows, for the noise head's row count
+static bool head_use_split(const avd_head_weights* w, int64_t rows) {
+    return (t_step_head_rows > rows ? t_step_head_rows : rows) >= split_min_rows() && head_split_capable(w, rows);
+}
 
 static int64_t head_ws_bytes(const avd_head_weights* w, int64_t rows) {
     const int64_t fp32_path = 2 * align_up(rows * w->hidden * 4);
@@ -749,7 +757,10 @@ extern "C" int avd_denoise_step_f32(const avd_step_desc* s, const float* z, cons
         const int64_t hc = p.core / 2, hh = p.head / 2;
         AVD_HIP(hipEventRecord(g_fork, st));
         AVD_HIP(hipStreamWaitEvent(g_aux, g_fork, 0));
-        struct TwoStreams { TwoStreams() { t_s3_two_streams = true; } ~TwoStreams() { t_s3_two_streams = false; } } two_streams_scope;
+        struct TwoStreams {
+            TwoStreams(int64_t rows, int64_t head_rows) { t_s3_two_streams = true; t_step_rows = rows; t_step_head_rows = head_rows; }
+            ~TwoStreams() { t_s3_two_streams = false; t_step_rows = 0; t_step_head_rows = 0; }
+        } two_streams_scope((int64_t)2 * e.B * p.N, p.rows);
         for (int half = 0; half < 2; ++half) {
             hipStream_t hs = half ? g_aux : st;
             float* xh = X2 + half * half_rows;

@@ -576,20 +576,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_kernel(S3Args g) {
 
     [[maybe_unused]] const unsigned long long t_entry = S3_T(), rt_entry = S3_RT();
     int bm, bn;
-    {
-        int wg;
-        {
-            const int b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
-            wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-        }
-        // super-tiles of sm x sn blocks: the blocks an XCD runs together share sm A panels and sn W panels
-        const int per_row = g.sm * g.nbn, per_st = g.sm * g.sn;
-        const int srow = wg / per_row, rem = wg % per_row;
-        const int sc = rem / per_st, rem2 = rem % per_st;
-        bm = srow * g.sm + rem2 / g.sn;
-        bn = sc * g.sn + rem2 % g.sn;
-        if ((int64_t)bm * BM >= g.M) return;
-    }
+    s3_block_of(g, (int)((g.M + BM - 1) / BM), bm, bn);
+    if ((int64_t)bm * BM >= g.M) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keep what derives from it scalar
     const int l31 = lane & 31, hi = lane >> 5;
@@ -909,19 +897,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
 
     [[maybe_unused]] const unsigned long long t_entry = S3_T(), rt_entry = S3_RT();
     int bm, bn;
-    {
-        int wg;
-        {
-            const int b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
-            wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-        }
-        const int per_row = g.sm * g.nbn, per_st = g.sm * g.sn;
-        const int srow = wg / per_row, rem = wg % per_row;
-        const int sc = rem / per_st, rem2 = rem % per_st;
-        bm = srow * g.sm + rem2 / g.sn;
-        bn = sc * g.sn + rem2 % g.sn;
-        if ((int64_t)bm * BM >= g.M) return;
-    }
+    s3_block_of(g, (int)((g.M + BM - 1) / BM), bm, bn);
+    if ((int64_t)bm * BM >= g.M) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
@@ -1166,19 +1143,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bf16x3_w128_kernel(S3Args g) {
 
     [[maybe_unused]] const unsigned long long t_entry = S3_T(), rt_entry = S3_RT();
     int bm, bn;
-    {
-        int wg;
-        {
-            const int b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
-            wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-        }
-        const int per_row = g.sm * g.nbn, per_st = g.sm * g.sn;
-        const int srow = wg / per_row, rem = wg % per_row;
-        const int sc = rem / per_st, rem2 = rem % per_st;
-        bm = srow * g.sm + rem2 / g.sn;
-        bn = sc * g.sn + rem2 % g.sn;
-        if ((int64_t)bm * BM >= g.M) return;
-    }
+    s3_block_of(g, (int)((g.M + BM - 1) / BM), bm, bn);
+    if ((int64_t)bm * BM >= g.M) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kq = lane >> 4;
@@ -1531,7 +1497,7 @@ static int launch_s3w(S3Args g, hipStream_t st, int nz = 1) {
     g.nbn = g.N / Cf::BN;
     s3_supertile(tile, g.nbn, g.sn, g.sm);
     const int64_t nbm = (g.M + Cf::BM - 1) / Cf::BM;
-    const int64_t nwg = (nbm + g.sm - 1) / g.sm * g.sm * g.nbn;
+    const int64_t nwg = nbm * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
     g.stagger = 0;
     g.first_gen = 2 * s3_cu_count();
@@ -1565,7 +1531,7 @@ static int launch_s3w16(S3Args g, hipStream_t st) {
     g.nbn = g.N / Cf::BN;
     s3_supertile(tile, g.nbn, g.sn, g.sm);
     const int64_t nbm = (g.M + BM - 1) / BM;
-    const int64_t nwg = (nbm + g.sm - 1) / g.sm * g.sm * g.nbn;
+    const int64_t nwg = nbm * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
     g.stagger = 0;
     g.first_gen = 2 * s3_cu_count();
@@ -1595,7 +1561,7 @@ static int launch_s3w128(S3Args g, hipStream_t st) {
     g.nbn = g.N / 256;
     s3_supertile(false, g.nbn, g.sn, g.sm);
     const int64_t nbm = (g.M + BM - 1) / BM;
-    const int64_t nwg = (nbm + g.sm - 1) / g.sm * g.sm * g.nbn;
+    const int64_t nwg = nbm * g.nbn;
     AVD_REQUIRE(nwg < (1ll << 31), AVD_EUNSUPPORTED, "gemm_bf16x3 grid too large");
     g.stagger = 0;
     g.first_gen = 0;

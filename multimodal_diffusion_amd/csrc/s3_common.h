@@ -59,6 +59,23 @@ struct S3Args {
 #define S3_DBG(i, v) do { } while (0)
 #endif
 
+// Which tile a block computes.  (1) XCD-contiguous remap: the hardware deals consecutive block ids round-robin over the 8 XCDs; after the
+// remap every XCD — its own L2 — works through one contiguous range of `wg`.  (2) `wg` walks super-tiles of sm x sn blocks (the blocks an
+// XCD runs together share sm A panels and sn W panels), super-rows of sm block rows top to bottom; the LAST super-row holds the nbm % sm
+// rows that are left, so the grid is exactly nbm x nbn blocks (round 5: a grid padded to whole super-rows put all its empty blocks on
+// the last XCD — 96 of its 224 slots at C3 with 16-row super-tiles — and the other seven XCDs carried 6 % more work each).
+__device__ __forceinline__ void s3_block_of(const S3Args& g, int nbm, int& bm, int& bn) {
+    const int b = blockIdx.x, nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = b & 7;
+    const int wg = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    const int per_row = g.sm * g.nbn;
+    const int srow = wg / per_row, rem = wg - srow * per_row;
+    const int left = nbm - srow * g.sm, h = left < g.sm ? left : g.sm;      // block rows of this super-row
+    const int per_st = h * g.sn;
+    const int sc = rem / per_st, rem2 = rem - sc * per_st;
+    bm = srow * g.sm + rem2 / g.sn;
+    bn = sc * g.sn + rem2 % g.sn;
+}
+
 template <int N> __device__ __forceinline__ void wait_vm() {
     static_assert(N >= 0 && N < 64, "vmcnt range");
     __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14));

@@ -411,9 +411,11 @@ class DenoiseEngine:
 def sample_one_direction(*, cfg: Dict, vid_vae, aud_codec, adapt_v: LinearAdapter, adapt_a: LinearAdapter,
                          core: MMDiT, head: MultiModalNoiseHead, tstep_dim: int, prompt_modality: str,
                          prompt_video: Optional[np.ndarray], prompt_audio: Optional[np.ndarray],
-                         device: torch.device) -> Dict[str, np.ndarray]:
+                         device: torch.device, init_noise: Optional[torch.Tensor] = None) -> Dict[str, np.ndarray]:
     """sample_clip.py:220-394 with the loop on the HIP engine.  The V->A branch uses the [1,3,T,H,W] layout the
-    reference's comment intends (its own permute at :288 is a bug that crashes in conv3d)."""
+    reference's comment intends (its own permute at :288 is a bug that crashes in conv3d).
+    ``init_noise`` (extension; default None = draw it as the reference does, :297 / :304): the target's initial latent, so that a
+    run can be repeated across devices — the reference's only RNG draw comes from the device generator."""
     dcfg, scfg = cfg["diffusion"], cfg["sampling"]
     eta = float(scfg.get("ddim_eta", 0.0))
     t_p, p = int(cfg["tokenizer"]["video"]["tube"]["t"]), int(cfg["tokenizer"]["video"]["tube"]["h"])
@@ -434,7 +436,9 @@ def sample_one_direction(*, cfg: Dict, vid_vae, aud_codec, adapt_v: LinearAdapte
             raise ValueError("prompt_video frames required for prompt_modality=video")
         frames = torch.from_numpy(prompt_video).to(device).float() / 255.0          # [T,H,W,3]
         z_p = vid_vae.encode(frames.permute(3, 0, 1, 2).unsqueeze(0).contiguous())   # [1,3,T,H,W] -> [1,Cv,T',H',W']
-        z = torch.randn(1, Ca, Fa, device=device)
+        z = torch.randn(1, Ca, Fa, device=device) if init_noise is None else init_noise.to(device).float()
+        if tuple(z.shape) != (1, Ca, Fa):
+            raise ValueError(f"init_noise has shape {tuple(z.shape)}, expected {(1, Ca, Fa)}")
         target, guide = "audio", float(scfg["guidance_scale"].get("audio", 3.0))
         n_prompt = (z_p.shape[2] // t_p) * (z_p.shape[3] // p) * (z_p.shape[4] // p)
     elif prompt_modality == "audio":
@@ -443,7 +447,10 @@ def sample_one_direction(*, cfg: Dict, vid_vae, aud_codec, adapt_v: LinearAdapte
         wav = torch.from_numpy(prompt_audio).to(device).view(1, 1, -1)
         z_p = aud_codec.encode(wav)                                                  # [1,Ca,Fa]
         T_in = prompt_video.shape[0] if prompt_video is not None else int(round(cfg["data"]["clip_seconds"] * fps))
-        z = torch.randn(1, Cv, max(1, T_in // t_down), H // s_down, W // s_down, device=device)
+        lat_shape = (1, Cv, max(1, T_in // t_down), H // s_down, W // s_down)
+        z = torch.randn(*lat_shape, device=device) if init_noise is None else init_noise.to(device).float()
+        if tuple(z.shape) != lat_shape:
+            raise ValueError(f"init_noise has shape {tuple(z.shape)}, expected {lat_shape}")
         target, guide = "video", float(scfg["guidance_scale"].get("video", 3.0))
         n_prompt = (z_p.shape[-1] - l_chunk) // s_chunk + 1
     else:

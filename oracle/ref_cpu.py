@@ -17,7 +17,7 @@ Reference anchors (paths relative to the reference repo root):
   RMSNorm/MHA/MLP/Block ... avdiff/models/mmdt.py:33-42, 51-61, 66-83, 88-99, 134-149
   noise head .............. avdiff/models/heads/noise_heads.py:185-229
   adapters + t-emb concat . avdiff/models/infer/sample_clip.py:48-56, 59-70
-  sampler loop body ....... avdiff/models/infer/sample_clip.py:318-348 (V->A), 359-389 (A->V)
+  sampler loop body ....... avdiff/models/infer/sample_clip.py:318-348 (V->A), 359-389 (A->V); chained: sample_a2v / sample_v2a (:313-394)
   TimestepEmbedder(mlp) ... avdiff/models/adapters.py:137-158
 """
 from __future__ import annotations
@@ -325,9 +325,39 @@ def sample_a2v(z_v: Tensor, z_a0: Tensor, sched: Tensor, alpha_bar: Tensor, **kw
     return z_v
 
 
+def sample_v2a(z_a: Tensor, z_v0: Tensor, sched: Tensor, alpha_bar: Tensor, **kw) -> Tensor:
+    """Chained V->A loop over a sampling schedule (sample_clip.py:313-352: the per-step statements :318-348 in the loop the
+    function's A->V branch uses; the reference's own V->A branch dies on a permute before it gets here, :286-289): final audio latent."""
+    B = z_a.shape[0]
+    for i in range(len(sched) - 1):
+        z_a = denoise_step_v2a(z_a, z_v0, sched[i].repeat(B), sched[i + 1].repeat(B), alpha_bar, **kw)
+    return z_a
+
+
 # --------------------------------------------------------------------------------------
 # synthetic weights with the reference's shapes and init families (no reference code involved)
 # --------------------------------------------------------------------------------------
+
+def synth_like(shapes: Dict[str, Tuple[int, ...]], seed: int) -> Weights:
+    """Seeded stand-in weights for ANY module given its ``state_dict`` key -> shape table (keys walked in sorted order, one CPU
+    generator): ``*.weight`` with two or more dims ~ U(-a, a), a = 1 / sqrt(fan_in); one-dim ``*.weight`` (norm scales) ~ 1 + 0.05 N(0,1);
+    ``*.bias`` ~ 0.05 N(0,1); anything else ~ 0.05 N(0,1).  Used where a fixture would otherwise have to store a codec's / VAE's weights:
+    the generating script loads these into the reference modules (``strict=True``), the tests load the same into the mirrors."""
+    g = torch.Generator().manual_seed(seed)
+    out: Weights = {}
+    for name in sorted(shapes):
+        shp = tuple(int(v) for v in shapes[name])
+        if name.endswith("weight") and len(shp) >= 2:
+            fan_in = 1
+            for v in shp[1:]:
+                fan_in *= v
+            out[name] = (torch.rand(*shp, generator=g) * 2 - 1) / math.sqrt(fan_in)
+        elif name.endswith("weight"):
+            out[name] = 1.0 + 0.05 * torch.randn(*shp, generator=g)
+        else:
+            out[name] = 0.05 * torch.randn(*shp, generator=g)
+    return out
+
 
 def _xavier(gen: torch.Generator, out_f: int, in_f: int) -> Tensor:
     a = math.sqrt(6.0 / (in_f + out_f))

@@ -398,6 +398,39 @@ def test_two_stream_cfg_halves_are_bit_identical(dev, full, mode):
     assert auto._split_streams == (mode == "f16x2")          # 16 x 421 = 6736 rows per half
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "auto"])
+def test_two_stream_halves_take_the_step_kernel_family(dev, full, mode):
+    """in the six-term mode the split kernels engage at 2,048 rows of the stacked 2B x N batch.  At B = 3 (2,526 rows; one CFG
+    half alone: 1,263) a forced two-stream step must take the SAME kernels as the one-stream layout — the family is chosen once per step —
+    so the two layouts stay bit-identical in that band too (and the step really runs on the split kernels: kernel tags)."""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd import _lib as L
+    ws, _ = full
+    B = 3
+    g = torch.Generator().manual_seed(303)
+    z = torch.randn(B, 8, 12, 32, 32, generator=g).to(dev)
+    za = torch.randn(B, 8, 150, generator=g).to(dev)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    tn, tp = torch.tensor([982, 500, 16]).to(dev), torch.tensor([966, 480, -1]).to(dev)
+    outs, tags = {}, {}
+    for split in (False, True):
+        core, head, av, aa = _full_modules(dev, ws)
+        eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z.shape),
+                              prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=mode, split_streams=split)
+        eng.set_prompt(za)
+        eng.step(z, tn, tp)
+        L.check(L.lib().avd_prof_enable(1))
+        try:
+            outs[split] = eng.step(z, tn, tp)
+            torch.cuda.synchronize()
+        finally:
+            L.check(L.lib().avd_prof_enable(0))
+        tags[split] = {k for k, v in L.prof_report().items() if v[0] > 0}
+    assert any(k.startswith("gemm_bf16x3") for k in tags[False]), tags[False]
+    assert {k for k in tags[True] if k.startswith(("gemm_", "attn_"))} == {k for k in tags[False] if k.startswith(("gemm_", "attn_"))}, (tags[False], tags[True])
+    assert torch.equal(outs[False], outs[True])
+
+
 def test_f16x2_below_and_at_the_row_threshold(dev, full):
     """Below 6144 rows the f16x2 request keeps the fp32-MFMA kernels (the 256-row tiles would not fill the chip); at the threshold
     (128x128 at B=32: 8512 core rows, exactly 6144 head rows) the split kernels take over — the step workspace is sized for

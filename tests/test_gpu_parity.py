@@ -556,13 +556,89 @@ def test_sample_one_direction_end_to_end(dev, full):
     frames = (R.vae_decode(zf, Wv).clamp(0, 1)[0].permute(1, 2, 3, 0).numpy() * 255.0).astype(np.uint8)
     diff = np.abs(frames.astype(np.int32) - res["video"].astype(np.int32))
     assert diff.max() <= 1 and (diff > 0).mean() < 1e-3        # <= 1 LSB on >= 99.9 % of pixels
-    # V -> A with the layout the reference's comment intends
+    # V -> A with the layout the reference's comment intends, against the oracle PIPELINE on the same draw (VERDICT r4 missing 3):
+    # VideoVAE.encode (mean path) -> 3 chained CFG + DDIM steps on the audio latent (sample_clip.py:318-348) -> AudioCodec.decode
     vid = (torch.rand(8, 32, 32, 3, generator=torch.Generator().manual_seed(6)) * 255).to(torch.uint8).numpy()
-    out = A.sample_one_direction(prompt_modality="video", prompt_video=vid, prompt_audio=None, **kw)
+    z_a_init = torch.randn(1, 8, 150, generator=torch.Generator().manual_seed(78))
+    out = A.sample_one_direction(prompt_modality="video", prompt_video=vid, prompt_audio=None, init_noise=z_a_init, **kw)
     assert out["audio"].shape == (48000,) and out["sr"] == 16000 and np.isfinite(out["audio"]).all()
     assert np.abs(out["audio"]).max() <= 1.0
+    x_p = (torch.from_numpy(vid).float() / 255.0).permute(3, 0, 1, 2).unsqueeze(0)            # [1,3,T,H,W]
+    z_v0 = R.vae_encode(x_p, Wv)
+    za_f = R.sample_v2a(z_a_init, z_v0, R.sampling_schedule(1000, 3), abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"], core=ws["core"],
+                        head=ws["head"], n_layers=8, n_heads=8, guidance=2.0)
+    wav_ref = R.codec_decode(za_f, Wc)[0, 0].double()
+    l2 = float((torch.from_numpy(out["audio"]).double() - wav_ref).norm() / wav_ref.norm())
+    assert l2 < 1e-3, l2                      # chained tolerance
+    with pytest.raises(ValueError):
+        A.sample_one_direction(prompt_modality="video", prompt_video=vid, prompt_audio=None, init_noise=torch.zeros(1, 8, 149), **kw)
     with pytest.raises(ValueError):
         A.sample_one_direction(prompt_modality="smell", prompt_video=None, prompt_audio=wav, **kw)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "auto"])
+def test_sample_one_direction_shipped_config_golden(dev, mode):
+    """Fixture g19 (VERDICT r4 missing 4): the reference's OWN sample_one_direction(prompt_modality="audio") on its unmodified shipped
+    configuration (configs/mvp.yaml + a2v.yaml: d = 512, L = 8, 128 x 128 x 48 frames, 60 DDIM steps, g = 3.5) — here through the mirror
+    entry point with the same config, the same seeded-recipe weights and the same initial latent: codec encode, 60 chained steps, VideoVAE
+    decode, uint8 frames, all on HIP.  "bf16x3" forces the split-operand kernels at this 266-row batch (they engage at 2,048 by default)."""
+    import multimodal_diffusion_amd as A
+    from test_oracle_golden import frames_close, g19_setup
+    g, meta, ws, Wv, Wc, wav = g19_setup()
+    cfg = dict(meta["cfg"], runtime={"matmul": mode})
+    vae, codec, av, aa, core, head, tdim = A.build_components(cfg, dev)
+    core.load_state_dict(ws["core"], strict=True)
+    head.load_state_dict(ws["head"], strict=True)
+    av.load_state_dict(ws["adapt_v"], strict=True)
+    aa.load_state_dict(ws["adapt_a"], strict=True)
+    vae.load_state_dict(Wv, strict=True)
+    codec.load_state_dict(Wc, strict=True)
+    rec = {}
+    dec0 = vae.decode
+    vae.decode = lambda z, *a, **k: (rec.__setitem__("z", z.clone()), dec0(z, *a, **k))[1]
+    try:
+        if mode == "bf16x3":
+            _tune("s3_min_rows", 0)
+        res = A.sample_one_direction(cfg=cfg, vid_vae=vae, aud_codec=codec, adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=tdim,
+                                     prompt_modality="audio", prompt_video=None, prompt_audio=wav, device=dev, init_noise=T(g["z_init"]))
+    finally:
+        _tune("s3_min_rows", -1)
+    ref = T(g["z_final"]).double()
+    l2 = float((rec["z"].cpu().double() - ref).norm() / ref.norm())
+    assert l2 < 1e-3, (mode, l2)              # chained tolerance (SURVEY 8c)
+    assert res["video"].shape == (48, 128, 128, 3) and res["video"].dtype == np.uint8 and res["fps"] == 16
+    mx, frac = frames_close(res["video"][::meta["frame_stride"]], g["frames"])
+    assert mx <= 1 and frac < 1e-3, (mode, mx, frac)      # <= 1 LSB on >= 99.9 % of the pixels
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3", "f16x2", "auto"])
+def test_chain_full_width_vs_oracle(dev, full, mode):
+    """A 10-step DDIM + CFG trajectory at the C3 shape (256 x 256: 384 + 37 tokens, d = 512, L = 8) at batch 4 against the CPU ORACLE's
+    chain (R.sample_a2v) — not against another mode of this library (VERDICT r4 missing 4 / next-round 5c).  3,368 rows: "auto" and
+    "bf16x3" take the six-term split kernels, "f16x2" needs its row threshold lowered."""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd import schedule_utils as su
+    ws, _ = full
+    B = 4
+    g = torch.Generator().manual_seed(1010)
+    z = torch.randn(B, 8, 12, 32, 32, generator=g)
+    za = torch.randn(B, 8, 150, generator=g)
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    sched = su.make_sampling_schedule(1000, 10)
+    ref = R.sample_a2v(z, za, R.sampling_schedule(1000, 10), abar, adapt_v=ws["adapt_v"], adapt_a=ws["adapt_a"], core=ws["core"],
+                       head=ws["head"], n_layers=8, n_heads=8, guidance=3.5).double()
+    core, head, av, aa = _full_modules(dev, ws)
+    try:
+        if mode == "f16x2":
+            _tune("s3_min_rows", 0)
+        eng = A.DenoiseEngine(adapt_v=av, adapt_a=aa, core=core, head=head, tstep_dim=256, target="video", latent_shape=tuple(z.shape),
+                              prompt_tokens=37, alpha_bar=abar, guidance=3.5, matmul=mode)
+        eng.set_prompt(za.to(dev))
+        out = eng.run(z.to(dev), sched)
+    finally:
+        _tune("s3_min_rows", -1)
+    l2 = float((out.cpu().double() - ref).norm() / ref.norm())
+    assert torch.isfinite(out).all() and l2 < 1e-3, (mode, l2)       # chained tolerance (SURVEY 8c); final |z| ~ 1e4
 
 
 # ------------------------------------------------------------------------------------------------- stream_infer (next-3)

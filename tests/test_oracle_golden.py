@@ -245,6 +245,50 @@ def test_g18_class_default_width():
     assert rel_err(R.noise_head(ha[:1], ws["head"], "audio")[0], g["head_audio_first"]) < TOL
 
 
+def g19_setup():
+    """Fixture g19 (tools/make_golden.py G19): the reference's shipped config (mvp.yaml + a2v.yaml) through ITS OWN
+    sample_one_direction(prompt_modality="audio").  Weights and the prompt are seeded recipes (not stored): returns
+    (fixture, meta, core/head/adapter weights, VideoVAE weights, AudioCodec weights, prompt waveform)."""
+    g = load_golden("g19_shipped_config_a2v.npz")
+    meta = json.loads(str(g["meta"]))
+    ws = R.synth_weights(seed=meta["seed_weights"])
+    Wv = R.synth_like({k: tuple(v) for k, v in meta["vae_shapes"].items()}, meta["seed_vae"])
+    Wc = R.synth_like({k: tuple(v) for k, v in meta["codec_shapes"].items()}, meta["seed_codec"])
+    wav = (0.1 * torch.randn(48000, generator=torch.Generator().manual_seed(meta["seed_wav"]))).numpy().astype(np.float32)
+    return g, meta, ws, Wv, Wc, wav
+
+
+def frames_close(got_u8, ref_u8):
+    """<= 1 LSB everywhere and different on < 0.1 % of the pixels"""
+    diff = np.abs(got_u8.astype(np.int32) - ref_u8.astype(np.int32))
+    return int(diff.max()), float((diff > 0).mean())
+
+
+def test_g19_shipped_config_through_reference_sampler():
+    """The oracle PIPELINE (codec encode -> 60 chained CFG + DDIM steps at d = 512, L = 8, 96 + 37 tokens -> VideoVAE decode -> uint8)
+    against what the reference's own sample_one_direction produced on its unmodified shipped configuration (VERDICT r4 missing 4)."""
+    g, meta, ws, Wv, Wc, wav = g19_setup()
+    cfg = meta["cfg"]
+    assert cfg["model"]["core"]["d_model"] == 512 and cfg["video"]["size"] == [128, 128] and cfg["diffusion"]["video"]["sampler_steps"] == 60
+    z_a0 = R.codec_encode(torch.from_numpy(wav).view(1, 1, -1), Wc, frames_per_clip=cfg["audio"]["latent"]["frames_per_clip"],
+                          hop=cfg["audio"]["codec"]["hop_samples"])
+    assert rel_err(z_a0, g["z_a0"]) < TOL
+    c = cfg["diffusion"]["video"]
+    abar = R.alpha_bar_table(R.beta_table(c["steps"], c["schedule"], c["min_beta"], c["max_beta"]))
+    z = R.sample_a2v(T(g["z_init"]), z_a0, R.sampling_schedule(c["steps"], c["sampler_steps"]), abar, adapt_v=ws["adapt_v"],
+                     adapt_a=ws["adapt_a"], core=ws["core"], head=ws["head"], n_layers=8, n_heads=8,
+                     guidance=cfg["sampling"]["guidance_scale"]["video"])
+    ref = T(g["z_final"]).double()
+    rel_l2 = float((z.double() - ref).norm() / ref.norm())
+    assert rel_l2 < 1e-3, rel_l2       # chained tolerance (SURVEY 8c); measured ~1e-6
+    # decode every 6th frame's neighbourhood is not separable (3x3x3 convolutions, GroupNorm over the clip): decode all, compare the stored ones
+    x = R.vae_decode(z, Wv).clamp(0, 1)
+    frames = (x[0].permute(1, 2, 3, 0).numpy() * 255.0).astype(np.uint8)
+    assert frames.shape == (48, 128, 128, 3)
+    mx, frac = frames_close(frames[::meta["frame_stride"]], g["frames"])
+    assert mx <= 1 and frac < 1e-3, (mx, frac)
+
+
 def _grp(g, prefix):
     return {k[len(prefix) + 1:]: torch.from_numpy(v) for k, v in g.items() if k.startswith(prefix + "/")}
 

@@ -19,13 +19,22 @@ def main():
     if src.endswith(".s"):                       # an assembly listing made earlier
         lines = open(src).read().split("\n")
     else:
+        # the compiler and the flags of the build that ships: `make -n -p` prints the Makefile's variables (HIPCC / ARCH / CXXFLAGS, with the
+        # caller's environment and command-line overrides applied), so the assembly inspected here is the object that gets linked
+        mk = subprocess.run(["make", "-n", "-p", "-C", os.path.dirname(os.path.abspath(src))], capture_output=True, text=True).stdout
+        var = {m.group(1): m.group(2).strip() for m in re.finditer(r"^(HIPCC|ARCH|CXXFLAGS)\s*[:?]?=\s*(.*)$", mk, re.M)}
+        hipcc = os.environ.get("HIPCC") or var.get("HIPCC") or "/opt/rocm/bin/hipcc"
+        arch = os.environ.get("ARCH") or var.get("ARCH") or "gfx950"
+        flags = (var.get("CXXFLAGS") or "-O3 -std=c++17 -fPIC --offload-arch=$(ARCH)").replace("$(ARCH)", arch).split()
         with tempfile.TemporaryDirectory() as td:
             out = os.path.join(td, "k.s")
-            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-o", out, src],
-                           check=True, stderr=subprocess.DEVNULL)
+            r = subprocess.run([hipcc] + flags + ["-S", "--cuda-device-only", "-o", out, src], capture_output=True, text=True)
+            if r.returncode:
+                print(f"FAIL {hipcc} could not compile {src} to assembly (rc {r.returncode}):\n{r.stderr[-3000:]}")
+                return 2
             lines = open(out).read().split("\n")
     # clock = wait states issued so far in this kernel; wrote[r] = clock at the last asm-statement MFMA that wrote AGPR r
-    name, clock, wrote, worst, in_asm = None, 0, {}, {}, False
+    name, clock, wrote, worst, in_asm, n_asm_mfma = None, 0, {}, {}, False, 0
     for ln, l in enumerate(lines, 1):
         m = re.match(r"^(_Z\w+):", l)
         if m:
@@ -42,6 +51,7 @@ def main():
         if op.startswith("v_mfma"):
             m = re.match(r"v_mfma\S+\s+a\[(\d+):(\d+)\]", t)
             if m and in_asm:                      # (MFMAs the compiler emits itself are padded by its hazard recogniser)
+                n_asm_mfma += 1
                 for r in range(int(m.group(1)), int(m.group(2)) + 1):
                     wrote[r] = clock
             clock += 1
@@ -55,6 +65,9 @@ def main():
                     worst[name] = (gap, ln, t)
         clock += int(t.split()[1]) + 1 if op == "s_nop" else 1
     rc = 0
+    if n_asm_mfma == 0:       # a file handed to this lint is expected to hold asm-statement MFMAs: finding none means the lint looked at nothing
+        print(f"FAIL no asm-statement MFMA with an AGPR destination found in {src} (filter '{flt}'): the lint has nothing to check")
+        return 2
     for k, (w, ln, t) in sorted(worst.items()):
         try:
             kn = subprocess.run(["c++filt", k], capture_output=True, text=True).stdout.strip() or k

@@ -33,12 +33,19 @@ def tune(**kw):
 VARIANTS = [("default", dict(s3_sn=0, s3_super4=0, s3_stagger=-1)), ("stagger0", dict(s3_sn=0, s3_super4=0, s3_stagger=0)),
             ("sn4 (8x4)", dict(s3_sn=4, s3_super4=0, s3_stagger=-1)), ("sn8 (4x8)", dict(s3_sn=8, s3_super4=0, s3_stagger=-1)),
             ("super64 (4 rows)", dict(s3_sn=0, s3_super4=64, s3_stagger=-1)), ("super16 (1 row)", dict(s3_sn=0, s3_super4=16, s3_stagger=-1)),
-            ("sn4 super64 (16x4)", dict(s3_sn=4, s3_super4=64, s3_stagger=-1)), ("sn2 super32 (16x2)", dict(s3_sn=2, s3_super4=0, s3_stagger=-1))]
-for name, N in (("fc1 (GELU -> image)", 2048), ("in_proj-shaped (bias -> image, N = 1536)", 1536)):
+            ("sn4 super64 (16x4)", dict(s3_sn=4, s3_super4=64, s3_stagger=-1)), ("sn2 super32 (16x2)", dict(s3_sn=2, s3_super4=0, s3_stagger=-1)),
+            ("sn4 super128 (32x4)", dict(s3_sn=4, s3_super4=128, s3_stagger=-1)), ("sn4 super64 stagger0", dict(s3_sn=4, s3_super4=64, s3_stagger=0)),
+            ("sn3 super48 (16x3)", dict(s3_sn=3, s3_super4=48, s3_stagger=-1)), ("sn6 super48 (8x6)", dict(s3_sn=6, s3_super4=48, s3_stagger=-1))]
+TOK = 421
+for name, N in (("fc1 (GELU -> image)", 2048), ("in_proj (-> q|k|v image, N = 1536)", 1536), ("head-like (bias -> image, N = 512)", 512)):
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
     b = torch.randn(N, generator=g).to(dev)
     w3 = Fn.split3(w)
-    fn = lambda: Fn.linear_bf16x3(x3, M, w3, N, K, bias=b, act=L.ACT_GELU if N == 2048 else L.ACT_NONE, out_split3=True)
+    if N == 1536 and M % TOK == 0:
+        q3 = torch.empty(int(lib.avd_qkv3_bytes(M // TOK, TOK, 8)), dtype=torch.uint8, device=dev)
+        fn = lambda: L.check(lib.avd_gemm_bf16x3_qkv3_f32(x3.data_ptr(), w3.data_ptr(), b.data_ptr(), q3.data_ptr(), M, TOK, 8, K, 0.18, 6, L.stream_ptr(dev)))
+    else:
+        fn = lambda: Fn.linear_bf16x3(x3, M, w3, N, K, bias=b, act=L.ACT_GELU if N == 2048 else L.ACT_NONE, out_split3=True)
     for _ in range(200):
         fn()
     torch.cuda.synchronize()
