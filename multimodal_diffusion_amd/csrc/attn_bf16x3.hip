@@ -290,6 +290,20 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
 // The O rescale is unconditional here (alpha = 1 when no maximum moved): a wave-uniform branch would cut the schedule in two.
 int g_attn_pipe = getenv("AVD_ATTN_PIPE") ? atoi(getenv("AVD_ATTN_PIPE")) : 1;
 
+// Round 5: the tile loop is PEELED.  The instruction mix of round 4's loop body (867 instructions per 64-key tile, 96 of them MFMAs) held ~250
+// vector instructions that do no arithmetic of the algorithm: the ragged-tail mask (32 compares + 32 selects, executed by EVERY tile because a
+// branch would have cut the schedule), the DMA's per-piece row / clamp / 64-bit address arithmetic (24 v_mad_u64 + ... for 12 pieces), and
+// 32 register moves that hand the next tile's scores to the current tile's names.  Now
+//   * only the LAST tile can be ragged, so only the iteration that issues its K fetch (KCL), the one that issues its V fetch and computes its
+//     scores (VCL) and the prologue carry the clamp / the mask; every other iteration moves whole 24 KiB tiles with one wave-uniform base + lane
+//     offset per piece and masks nothing (template flags: the bodies are separate instantiations, as the last tile already was);
+//   * the main loop is unrolled twice with the two score register sets trading roles — no copies (the tail iterations copy).
+// The VALU work that is left per tile is the algorithm's: 32 exp2 + 32 subtractions, 32 row-sum adds, 32 O multiplies, 16 max3, the 16 pair
+// splits of P (11 instructions per pair for three planes).
+template <bool MORE_, bool KCL_, bool VCL_, bool COPY_> struct A3Flags {
+    static constexpr bool MORE = MORE_, KCL = KCL_, VCL = VCL_, COPY = COPY_;
+};
+
 template <bool SPLIT_OUT, int TERMS>
 __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const unsigned char* __restrict__ img, float* __restrict__ out,
                                                                          int Bt, int N, int Npad, int H, int n_query, int nqb,
@@ -310,7 +324,8 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
         h = (w / nqb) % H;
         b = w / (nqb * H);
     }
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform: what derives from it stays scalar
     const int l31 = lane & 31, hi = lane >> 5;
     const int64_t hstride = (int64_t)Npad * ROWB;
     const unsigned char* Qb = img + (((int64_t)0 * Bt + b) * H + h) * hstride;
@@ -326,7 +341,10 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
 #pragma unroll
             for (int p = 0; p < NPL; ++p) qf[s][p] = *reinterpret_cast<const bf16x8*>(src + p * 128 + s * 32);
     }
-    auto dma = [&](const unsigned char* gsrc, unsigned char* ldst, int kt) {
+    // DMA of tile kt.  dma_clamp: rows past the last token are fetched from token N-1 (finite filler: the scores of those keys are masked,
+    // and a zero probability times a finite V is zero) — needed for the last tile only.  dma_full: a whole tile, linear: wave-uniform base,
+    // the lane's 16 bytes as the only vector part of the address.
+    auto dma_clamp = [&](const unsigned char* gsrc, unsigned char* ldst, int kt) {
         const int last_row = N - 1 - kt * A3_KT;
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
@@ -339,6 +357,13 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
                                              0, 0);
         }
     };
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto dma_full = [&](const unsigned char* gsrc, unsigned char* ldst, int kt) {
+        const unsigned char* base = gsrc + ((int64_t)kt * (A3_KT * ROWB) + wave * 1024);        // wave-uniform
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(base + i * (NW * 1024) + lane16), AVD_LDS_PTR(ldst + (wave + NW * i) * 1024), 16, 0, 0);
+    };
     auto sync = [&]() {
         __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's DMA pieces have landed
         __syncthreads();
@@ -346,22 +371,22 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
 
     const int nkt = (N + A3_KT - 1) / A3_KT;
     const bool ragged = (N & (A3_KT - 1)) != 0;
-    dma(Kb, Ks, 0);
-    dma(Vb, Vs, 0);
+    dma_clamp(Kb, Ks, 0);
+    dma_clamp(Vb, Vs, 0);
     sync();
 
     const bool active = qb * (NW * 32) + wave * 32 < n_query;   // wave-uniform: a wave of padding rows only loads
     if (!active) {
         // same barriers and the same DMA duty as the computing waves
         sync();
-        if (nkt > 1) dma(Kb, Ks, 1);
+        if (nkt > 1) dma_clamp(Kb, Ks, 1);
         sync();
         for (int kt = 0; kt < nkt; ++kt) {
             sync();
-            if (kt + 2 < nkt) dma(Kb, Ks, kt + 2);
+            if (kt + 2 < nkt) dma_clamp(Kb, Ks, kt + 2);
             if (kt + 1 < nkt) {
                 sync();
-                dma(Vb, Vs, kt + 1);
+                dma_clamp(Vb, Vs, kt + 1);
             }
         }
         return;
@@ -373,9 +398,9 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
     const int v_q = i16 >> 2, v_p = i16 & 3;
 #define A3_SB() __builtin_amdgcn_sched_barrier(0)
 
-    f32x16 o0, o1, sc0, sc1, sn0, sn1;        // O^T halves; scores / probabilities of the current tile; scores of the next tile
+    f32x16 o0, o1, sa0, sa1, sb0, sb1;        // O^T halves; two score / probability register sets that trade roles (current tile / next tile)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; sc0[r] = 0.f; sc1[r] = 0.f; sn0[r] = 0.f; sn1[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; sa0[r] = 0.f; sa1[r] = 0.f; sb0[r] = 0.f; sb1[r] = 0.f; }
     float m_run = A3_NEG, l_run = 0.f;
 
     // the two MFMAs (keys 0..31 and 32..63) of term t of d-step s of S^T = K Q^T, with that d-step's K fragments read in front of term 0
@@ -414,18 +439,18 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
 #pragma unroll
     for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int t = 0; t < TT::N; ++t) s_slot(sc0, sc1, s, t);
-    if (nkt == 1 && ragged) mask_tail(sc0, sc1, 0);
+        for (int t = 0; t < TT::N; ++t) s_slot(sa0, sa1, s, t);
+    if (nkt == 1 && ragged) mask_tail(sa0, sa1, 0);
     sync();
-    if (nkt > 1) dma(Kb, Ks, 1);
-    float m_new = fmaxf(m_run, tile_max(sc0, sc1));
+    if (nkt > 1) dma_clamp(Kb, Ks, 1);
+    float m_new = fmaxf(m_run, tile_max(sa0, sa1));
     sync();
 
     u32x4 pf[2][3];               // P fragments (planes) of two consecutive 16-key groups
-    // pair e (two of the eight probabilities) of key group g = (kb, t) of sc0 / sc1, split into planes: dword e of every plane
-    auto split_pair = [&](int g, int e, u32x4 (&dst)[3]) {
-        const float a = (g >> 1) ? sc1[8 * (g & 1) + 2 * e] : sc0[8 * (g & 1) + 2 * e];
-        const float c = (g >> 1) ? sc1[8 * (g & 1) + 2 * e + 1] : sc0[8 * (g & 1) + 2 * e + 1];
+    // pair e (two of the eight probabilities) of key group g = (kb, t) of the current tile (c0 / c1), split into planes: dword e of every plane
+    auto split_pair = [&](const f32x16& c0, const f32x16& c1, int g, int e, u32x4 (&dst)[3]) {
+        const float a = (g >> 1) ? c1[8 * (g & 1) + 2 * e] : c0[8 * (g & 1) + 2 * e];
+        const float c = (g >> 1) ? c1[8 * (g & 1) + 2 * e + 1] : c0[8 * (g & 1) + 2 * e + 1];
         if constexpr (F16) {
             const unsigned int hh = pk_f16(a, c);
             const f32x2 u = unpk_f16(hh);
@@ -464,10 +489,13 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
         else o1 = mma16<F16>(vf[TT::PA[tt]], __builtin_bit_cast(bf16x8, P[TT::PB[tt]]), o1);
     };
 
-    // one tile; MORE (compile time): a tile kt+1 exists.  The last tile is a separate instantiation behind the loop — as the two arms of
-    // one `if (more)` the compiler hoists the VALU items, common to both arms, in front of the branch and the schedule is gone.
-    auto tile = [&](auto more_tag, int kt) {
-        constexpr bool MORE = decltype(more_tag)::value;
+    // One tile.  c0 / c1: scores (then probabilities) of tile kt; n0 / n1: receive the scores of tile kt + 1.  Flags (compile time; each
+    // combination is its own instantiation — as the two arms of a runtime `if` the compiler hoists the VALU items common to both arms in
+    // front of the branch and the schedule is gone): MORE a tile kt + 1 exists; KCL tile kt + 2 may be the ragged last one (its K fetch
+    // clamps rows); VCL tile kt + 1 may be the ragged last one (its V fetch clamps, its scores are masked); COPY hand n back to c at the end.
+    auto tile = [&](auto flags, int kt, f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1) {
+        using FL = decltype(flags);
+        constexpr bool MORE = FL::MORE;
         // ================= phase A: S(kt+1) beside the exponentials of tile kt =================
         const float m_sub = F16 ? m_new - 15.0f : m_new;        // f16x2: probabilities are kept at scale 2^15 (sum and planes alike)
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -480,20 +508,20 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
         // compiler sinks the whole item into the block of its first use (behind the barrier) and the MFMAs run alone again.
         auto item_a = [&](int w) {
             if (w < 16) {
-                const float e0 = F16 ? sc0[w] * s_inv2 : sc0[w], e1 = F16 ? sc1[w] * s_inv2 : sc1[w];
+                const float e0 = F16 ? c0[w] * s_inv2 : c0[w], e1 = F16 ? c1[w] * s_inv2 : c1[w];
                 float p0 = __builtin_amdgcn_exp2f(e0 - m_sub), p1 = __builtin_amdgcn_exp2f(e1 - m_sub);
                 ps += p0 + p1;
                 asm volatile("" : "+v"(p0), "+v"(p1), "+v"(ps));
-                sc0[w] = p0;
-                sc1[w] = p1;
+                c0[w] = p0;
+                c1[w] = p1;
             } else if (w < 24) {
                 const int r0 = (w - 16) * 2;
-                float a0 = o0[r0] * alpha, a1 = o0[r0 + 1] * alpha, c0 = o1[r0] * alpha, c1 = o1[r0 + 1] * alpha;
-                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(c0), "+v"(c1));
+                float a0 = o0[r0] * alpha, a1 = o0[r0 + 1] * alpha, q0 = o1[r0] * alpha, q1 = o1[r0 + 1] * alpha;
+                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(q0), "+v"(q1));
                 o0[r0] = a0; o0[r0 + 1] = a1;
-                o1[r0] = c0; o1[r0 + 1] = c1;
+                o1[r0] = q0; o1[r0 + 1] = q1;
             } else {
-                split_pair(0, w - 24, pf[0]);
+                split_pair(c0, c1, 0, w - 24, pf[0]);
                 // (name only the planes this mode writes: an unwritten plane as a read-write operand would read an uninitialised register
                 // and pin it for nothing — ADVICE r4)
                 if constexpr (NPL == 3) asm volatile("" : "+v"(pf[0][0][w - 24]), "+v"(pf[0][1][w - 24]), "+v"(pf[0][2][w - 24]));
@@ -503,16 +531,18 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
         };
         if constexpr (MORE) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { sn0[r] = 0.f; sn1[r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { n0[r] = 0.f; n1[r] = 0.f; }
 #pragma unroll
             for (int sl = 0; sl < NSLOT_A; ++sl) {
                 A3_SB();
-                s_slot(sn0, sn1, sl / TT::N, sl % TT::N);
+                s_slot(n0, n1, sl / TT::N, sl % TT::N);
 #pragma unroll
                 for (int w = sl * NITEM_A / NSLOT_A; w < (sl + 1) * NITEM_A / NSLOT_A; ++w) item_a(w);
             }
             A3_SB();
-            if (kt + 2 == nkt && ragged) mask_tail(sn0, sn1, kt + 1);
+            if constexpr (FL::VCL) {
+                if (ragged) mask_tail(n0, n1, kt + 1);          // wave-uniform; this instantiation runs once per block
+            }
         } else {
 #pragma unroll
             for (int w = 0; w < NITEM_A; ++w) item_a(w);
@@ -520,7 +550,10 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
         l_run = l_run * alpha + ps;
         // V(kt) has landed (issued a phase ago); every wave is past its reads of K(kt+1)
         sync();
-        if (kt + 2 < nkt) dma(Kb, Ks, kt + 2);
+        if constexpr (MORE) {
+            if constexpr (FL::KCL) { if (kt + 2 < nkt) dma_clamp(Kb, Ks, kt + 2); }
+            else if constexpr (!FL::VCL) dma_full(Kb, Ks, kt + 2);      // (VCL: tile kt + 1 is the last one, nothing left to fetch)
+        }
 
         // ================= phase B: O += V(kt) P(kt) beside the remaining splits and the maximum of tile kt+1 =================
         // slots: (g, db, tt) in that order, 2 x TT::N per key group.  Items: the split of group g+1, one pair behind each of the first
@@ -535,11 +568,11 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
                 if (g < 3) {        // the split of the next group: its four pairs behind the first slots of this group
                     constexpr int SPS = 2 * TT::N >= 4 ? 1 : 2;      // pairs per slot (one-term mode: two slots per group)
 #pragma unroll
-                    for (int e = sl * SPS; e < (sl + 1) * SPS && e < 4; ++e) split_pair(g + 1, e, pf[(g + 1) & 1]);
+                    for (int e = sl * SPS; e < (sl + 1) * SPS && e < 4; ++e) split_pair(c0, c1, g + 1, e, pf[(g + 1) & 1]);
                 }
                 if (MORE && g == 3) {
 #pragma unroll
-                    for (int w = sl * 16 / (2 * TT::N); w < (sl + 1) * 16 / (2 * TT::N); ++w) mt = fmaxf(mt, fmaxf(sn0[w], sn1[w]));
+                    for (int w = sl * 16 / (2 * TT::N); w < (sl + 1) * 16 / (2 * TT::N); ++w) mt = fmaxf(mt, fmaxf(n0[w], n1[w]));
                     asm volatile("" : "+v"(mt));      // stays in this slot
                 }
             }
@@ -549,17 +582,32 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
             if constexpr (F16) mt *= s_inv2;
             mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
             m_new = fmaxf(m_run, mt);
-            sc0 = sn0;
-            sc1 = sn1;
+            if constexpr (FL::COPY) {
+                c0 = n0;
+                c1 = n1;
+            }
             // K(kt+2) has landed; every wave is past its reads of V(kt)
             sync();
-            dma(Vb, Vs, kt + 1);
+            if constexpr (FL::VCL) dma_clamp(Vb, Vs, kt + 1);
+            else dma_full(Vb, Vs, kt + 1);
         }
     };
     {
+        using Main = A3Flags<true, false, false, false>;        // tiles kt + 1 and kt + 2 exist and are full; register sets trade roles
+        using MainC = A3Flags<true, false, false, true>;
+        using KClamp = A3Flags<true, true, false, true>;        // tile kt + 2 is the last one (if it exists)
+        using VClamp = A3Flags<true, false, true, true>;        // tile kt + 1 is the last one
+        using Last = A3Flags<false, false, false, false>;
         int kt = 0;
-        for (; kt + 1 < nkt; ++kt) tile(std::integral_constant<bool, true>{}, kt);
-        tile(std::integral_constant<bool, false>{}, kt);
+        for (; kt + 4 < nkt; kt += 2) {
+            tile(Main{}, kt, sa0, sa1, sb0, sb1);
+            tile(Main{}, kt + 1, sb0, sb1, sa0, sa1);
+        }
+        // 1 .. 4 tiles left, the current scores in sa: each of these hands the next scores back to sa
+        if (nkt - kt == 4) { tile(MainC{}, kt, sa0, sa1, sb0, sb1); ++kt; }
+        if (nkt - kt == 3) { tile(KClamp{}, kt, sa0, sa1, sb0, sb1); ++kt; }
+        if (nkt - kt == 2) { tile(VClamp{}, kt, sa0, sa1, sb0, sb1); ++kt; }
+        tile(Last{}, kt, sa0, sa1, sb0, sb1);
     }
 #undef A3_SB
 

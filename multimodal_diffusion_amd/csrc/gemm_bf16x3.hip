@@ -1465,9 +1465,8 @@ static int s3_cu_count() {                 // CUs of the current device (looked 
 }
 
 // Super-tiles: the blocks an XCD runs together (consecutive ids after the XCD remap) form sm x sn blocks that share sm A panels and sn W
-// panels.  256x128 tiles (tile = true, two blocks per CU): whole block rows per super-tile when the launch has at most 16 column blocks, so
-// the 12-16 column blocks that share an A panel run together and the panel is fetched into the XCD's L2 once (in_proj at C3: 2.02 -> 1.84
-// ms per step); 32 blocks per super-tile, 16 for the one-block-per-CU tiles.
+// panels.  256x128 tiles (tile = true, two blocks per CU): rounds 2-4 ran whole block rows per super-tile (the 12-16 column blocks that
+// share an A panel together, 2 rows x all columns); 16 blocks per super-tile for the one-block-per-CU tiles.
 // AVD_S3_SN / AVD_S3_SUPER4 / AVD_S3_SUPER8 (avd_tune_set "s3_sn" / "s3_super4" / "s3_super8"): measurement aids — super-tile width in blocks /
 // blocks per super-tile of the two-per-CU and one-per-CU kernels; profiles/r05_fetch_ab.txt holds the FETCH_SIZE of fc1 / in_proj across them.
 int g_s3_sn = getenv("AVD_S3_SN") ? atoi(getenv("AVD_S3_SN")) : 0;                  // avd_tune_set "s3_sn": 0 = the rule below
@@ -1478,6 +1477,10 @@ static void s3_supertile(bool tile, int nbn, int& sn_out, int& sm_out) {
     while (nbn % sn) sn >>= 1;
     if (tile && nbn <= 16) sn = nbn;
     int total = tile ? 32 : 16;
+    // round 5 (profiles/r05_supertile_ab.txt): two-per-CU kernels with 8 or more column blocks run 16 x 4 super-tiles — the XCD keeps only FOUR
+    // W panels live (1.5 MB of its 4 MB L2 at K = 512; they are re-read by every row block and now stay resident) and streams each A panel
+    // past them once per column group: fc1 294 -> 278 us, in_proj 226 -> 208 us per launch at C3, nothing at 8,512 rows
+    if (tile && nbn >= 8 && nbn % 4 == 0) { sn = 4; total = 64; }
     if (g_s3_sn > 0) { sn = g_s3_sn < nbn ? g_s3_sn : nbn; while (nbn % sn) --sn; }
     if ((tile ? g_s3_super4 : g_s3_super8) > 0) total = tile ? g_s3_super4 : g_s3_super8;
     sn_out = sn;

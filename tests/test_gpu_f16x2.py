@@ -427,7 +427,10 @@ def test_two_stream_halves_take_the_step_kernel_family(dev, full, mode):
             L.check(L.lib().avd_prof_enable(0))
         tags[split] = {k for k, v in L.prof_report().items() if v[0] > 0}
     assert any(k.startswith("gemm_bf16x3") for k in tags[False]), tags[False]
-    assert {k for k in tags[True] if k.startswith(("gemm_", "attn_"))} == {k for k in tags[False] if k.startswith(("gemm_", "attn_"))}, (tags[False], tags[True])
+    # the same split-operand kernels in both layouts (the fp32 launches of the noise head may pick another tile / ring depth for the
+    # half-size call: those variants are bit-identical by construction and are checked by the equality below)
+    fam = lambda t: {k for k in t if k.startswith(("gemm_bf16x3", "attn_bf16x3"))}
+    assert fam(tags[True]) == fam(tags[False]), (tags[False], tags[True])
     assert torch.equal(outs[False], outs[True])
 
 
