@@ -25,6 +25,7 @@ constexpr float A3_NEG = -1.0e30f;
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4t __attribute__((ext_vector_type(4)));
 
 #define AVD_LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 #define AVD_GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_kernel(const unsign
 #pragma unroll
                 for (int p = 0; p < NPL; ++p) pf[p] = __builtin_bit_cast(bf16x8, P[p]);
                 const int key0 = 32 * kb + 16 * t + 4 * hi + v_q;     // this lane's ADDRESS row of the first 4-key block
-                const int sw = ((key0 >> 1) & 1) << 2;                // same for key0 + 8
+                const int sw = qkv3_swizzle(2, key0);                 // same for key0 + 8
 #pragma unroll
                 for (int db = 0; db < 2; ++db) {
                     const int chunk = 4 * db + 2 * cb + (v_p >> 1);
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
     auto pv_slot = [&](int g, int db, int tt, const u32x4 (&P)[3]) {
         if (tt == 0) {
             const int key0 = 16 * g + 4 * hi + v_q;
-            const int sw = ((key0 >> 1) & 1) << 2;
+            const int sw = qkv3_swizzle(2, key0);
             const int chunk = 4 * db + 2 * cb + (v_p >> 1);
 #pragma unroll
             for (int p = 0; p < NPL; ++p) {
@@ -652,6 +653,384 @@ __global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_pipe_kernel(const u
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Round 5: the same pipeline on v_mfma_f32_16x16x32 (VERDICT r4 next-round 3 a; avd_tune_set "attn_m16").  Why build it: the step runs on the
+// socket power cap, cycles per FLOP of the two MFMA shapes are equal, and the 16x16x32 shape draws less power per FLOP (MI355X_MICROARCH.md,
+// DVFS give-back 7: 1.12-1.15x the FLOP/s of the 32x32x16 loop at equal cycles) — the change that bought clock on the GEMMs (DESIGN 4.8 d).
+// Same wave tile (64 keys x 32 queries per step, 32 queries x 64 d of O), same LDS tiles, same DMA, same number of LDS reads:
+//   S^T tiles [4 key tiles of 16][2 query tiles of 16]: A = K fragment (key = lane & 15, d = 32 s + 8 (lane >> 4) + j), B = Q fragment
+//       (query = lane & 15, same d); a lane holds keys 4 (lane >> 4) + r of ONE query column per tile: 2 queries x 16 keys (32x32: 1 x 32),
+//       so the row maxima / sums cross the four 16-lane groups (v_permlane16_swap + v_permlane32_swap) instead of one lane half;
+//   O^T tiles [4 d tiles][2 query tiles]: K = 32 keys per MFMA = the registers of S^T tiles 2g and 2g + 1 of the lane (the MFMA k order is
+//       free), V read transposed by ds_read_b64_tr_b16 in exactly that key order (keys 32 g + 4 (lane >> 4) + q, then + 16).
+// An MFMA of this shape holds the vector issue port for 8 of its 16 cycles (32x32x16: 8 of 32), so there is less room for the softmax VALU
+// work beside the matrix pipe; which of the two effects wins is a measurement (profiles/r05_attn_m16.txt).
+template <bool F16>
+__device__ __forceinline__ f32x4t mma16s(bf16x8 a, bf16x8 b, f32x4t c) {
+    if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+int g_attn_m16 = getenv("AVD_ATTN_M16") ? atoi(getenv("AVD_ATTN_M16")) : 0;
+
+struct S16 { f32x4t t[4][2]; };       // scores / probabilities of one 64-key tile: [key tile][query tile]
+
+template <bool SPLIT_OUT, int TERMS>
+__global__ __launch_bounds__(A3_NW * 64, 2) void attn_bf16x3_p16_kernel(const unsigned char* __restrict__ img, float* __restrict__ out,
+                                                                        int Bt, int N, int Npad, int H, int n_query, int nqb,
+                                                                        float s_inv2, float v_inv, float o_scale, int out_tok) {
+    constexpr int NW = A3_NW, ROWB = QKV3_ROWB;
+    constexpr bool F16 = TERMS == 3;
+    constexpr int NPL = s3_planes(TERMS);
+    constexpr int PPW = 24 / NW;
+    using TT = A3Terms<TERMS>;
+    __shared__ __attribute__((aligned(16))) unsigned char Ks[A3_KT * ROWB];
+    __shared__ __attribute__((aligned(16))) unsigned char Vs[A3_KT * ROWB];
+
+    int qb, h, b;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, r = nwg & 7, x = id & 7;
+        const int w = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (id >> 3);
+        qb = w % nqb;
+        h = (w / nqb) % H;
+        b = w / (nqb * H);
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, kq = lane >> 4;
+    const int64_t hstride = (int64_t)Npad * ROWB;
+    const unsigned char* Qb = img + (((int64_t)0 * Bt + b) * H + h) * hstride;
+    const unsigned char* Kb = img + (((int64_t)1 * Bt + b) * H + h) * hstride;
+    const unsigned char* Vb = img + (((int64_t)2 * Bt + b) * H + h) * hstride;
+
+    // Q fragments: query tile qt, d-step s (32 d), plane p: Q[query 16 qt + l15][32 s + 8 kq .. + 7]
+    const int q_row0 = qb * (NW * 32) + wave * 32 + l15;
+    bf16x8 qf[2][2][3];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int qr = q_row0 + 16 * qt;
+        const unsigned char* src = Qb + (int64_t)(qr < N ? qr : N - 1) * ROWB + kq * 16;
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) qf[qt][sd][p] = *reinterpret_cast<const bf16x8*>(src + p * 128 + sd * 64);
+    }
+    auto dma_clamp = [&](const unsigned char* gsrc, unsigned char* ldst, int kt) {
+        const int last_row = N - 1 - kt * A3_KT;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int p = wave + NW * i;
+            const int off = p * 1024 + lane * 16;
+            int row = off / ROWB;
+            const int within = off - row * ROWB;
+            row = row < last_row ? row : last_row;
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(gsrc + ((int64_t)kt * A3_KT + row) * ROWB + within), AVD_LDS_PTR(ldst + p * 1024), 16,
+                                             0, 0);
+        }
+    };
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto dma_full = [&](const unsigned char* gsrc, unsigned char* ldst, int kt) {
+        const unsigned char* base = gsrc + ((int64_t)kt * (A3_KT * ROWB) + wave * 1024);
+#pragma unroll
+        for (int i = 0; i < PPW; ++i)
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(base + i * (NW * 1024) + lane16), AVD_LDS_PTR(ldst + (wave + NW * i) * 1024), 16, 0, 0);
+    };
+    auto sync = [&]() {
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+    };
+
+    const int nkt = (N + A3_KT - 1) / A3_KT;
+    const bool ragged = (N & (A3_KT - 1)) != 0;
+    dma_clamp(Kb, Ks, 0);
+    dma_clamp(Vb, Vs, 0);
+    sync();
+
+    const bool active = qb * (NW * 32) + wave * 32 < n_query;
+    if (!active) {
+        sync();
+        if (nkt > 1) dma_clamp(Kb, Ks, 1);
+        sync();
+        for (int kt = 0; kt < nkt; ++kt) {
+            sync();
+            if (kt + 2 < nkt) dma_clamp(Kb, Ks, kt + 2);
+            if (kt + 1 < nkt) {
+                sync();
+                dma_clamp(Vb, Vs, kt + 1);
+            }
+        }
+        return;
+    }
+
+    // K row reads: key 16 kt4 + l15, chunk (4 s + kq) ^ ((key >> 1) & 7) — 16 kt4 does not reach the swizzle bits
+    const int ksw = (l15 >> 1) & 7;
+    const int k_rd = l15 * ROWB;
+    // V transposed reads: the 16-lane group kq takes the 4-key block 32 g + 4 kq (+ 16) of a d tile; lane 4 q + p of the group supplies the
+    // address of key row q, columns 4 p .. 4 p + 3, and receives column l15 of the four rows
+    const int v_q = l15 >> 2, v_p = l15 & 3;
+    const int v_key = 4 * kq + v_q;
+    const int v_sw = qkv3_swizzle(2, v_key);            // (+ 32 g, + 16: the swizzle bits of the key do not change)
+    const int v_rd = v_key * ROWB + 8 * (v_p & 1);
+#define A3_SB() __builtin_amdgcn_sched_barrier(0)
+
+    f32x4t o[4][2];                           // O^T: [d tile][query tile]
+    S16 sa, sb;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { o[i][j] = f32x4t{0.f, 0.f, 0.f, 0.f}; sa.t[i][j] = o[i][j]; sb.t[i][j] = o[i][j]; }
+    float m_run[2] = {A3_NEG, A3_NEG}, l_run[2] = {0.f, 0.f}, m_new[2];
+
+    // the 2 MFMAs (query tiles 0, 1) of term t of (key tile kt4, d-step sd) of S^T = K Q^T, that pair's K fragments read in front of term 0
+    bf16x8 ka[3];
+    auto s_slot = [&](S16& d, int kt4, int sd, int t) {
+        if (t == 0) {
+            const int ch = ((4 * sd + kq) ^ ksw) << 4;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) ka[p] = *reinterpret_cast<const bf16x8*>(Ks + k_rd + kt4 * (16 * ROWB) + p * 128 + ch);
+        }
+        d.t[kt4][0] = mma16s<F16>(ka[TT::PA[t]], qf[0][sd][TT::PB[t]], d.t[kt4][0]);
+        d.t[kt4][1] = mma16s<F16>(ka[TT::PA[t]], qf[1][sd][TT::PB[t]], d.t[kt4][1]);
+    };
+    auto mask_tail = [&](S16& d, int kt) {
+        const int kbase = kt * A3_KT + 4 * kq;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (kbase + 16 * i + r >= N) { d.t[i][0][r] = A3_NEG; d.t[i][1][r] = A3_NEG; }
+    };
+    // maximum over the four 16-lane groups that share a query column
+    auto xmax = [&](float v) {
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+        const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return fmaxf(__uint_as_float(c[0]), __uint_as_float(c[1]));
+    };
+    auto xsum = [&](float v) {
+        const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+        const auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        return __uint_as_float(c[0]) + __uint_as_float(c[1]);
+    };
+    auto tile_max = [&](const S16& d, int qt) {
+        float mt = A3_NEG;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mt = fmaxf(mt, d.t[i][qt][r]);
+        if constexpr (F16) mt *= s_inv2;
+        return xmax(mt);
+    };
+
+    // ---- prologue: S(0) with nothing beside it, K(1) on its way while its maxima are taken ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+            for (int t = 0; t < TT::N; ++t) s_slot(sa, i, sd, t);
+    if (nkt == 1 && ragged) mask_tail(sa, 0);
+    sync();
+    if (nkt > 1) dma_clamp(Kb, Ks, 1);
+    m_new[0] = fmaxf(m_run[0], tile_max(sa, 0));
+    m_new[1] = fmaxf(m_run[1], tile_max(sa, 1));
+    sync();
+
+    // P fragments: [32-key group parity][query tile][plane], dword e = pair e of the eight probabilities of (group g, query tile qt):
+    // e < 2: registers 2 e, 2 e + 1 of S^T tile 2 g; e >= 2: registers 2 (e - 2), + 1 of tile 2 g + 1
+    u32x4 pf[2][2][3];
+    auto split_pair = [&](const S16& c, int g, int qt, int e, u32x4 (&dst)[3]) {
+        const float a = c.t[2 * g + (e >> 1)][qt][2 * (e & 1)], cc = c.t[2 * g + (e >> 1)][qt][2 * (e & 1) + 1];
+        if constexpr (F16) {
+            const unsigned int hh = pk_f16(a, cc);
+            const f32x2 u = unpk_f16(hh);
+            dst[0][e] = hh;
+            dst[1][e] = pk_f16(a - u[0], cc - u[1]);
+        } else {
+            const unsigned int hh = pk_bf16(a, cc);
+            const float ra = a - bf16_lo(hh), rc = cc - bf16_hi(hh);
+            dst[0][e] = hh;
+            if constexpr (NPL > 1) {
+                const unsigned int mm = pk_bf16(ra, rc);
+                dst[1][e] = mm;
+                dst[2][e] = pk_bf16(ra - bf16_lo(mm), rc - bf16_hi(mm));
+            }
+        }
+    };
+    // the 2 MFMAs (query tiles 0, 1) of (key group g, d tile dt, term tt) of O^T += V^T P^T, that (g, dt)'s V fragments read in front of term 0
+    bf16x8 vf[3];
+    auto pv_slot = [&](int g, int dt, int tt, const u32x4 (&P)[2][3]) {
+        if (tt == 0) {
+            const int chunk = (2 * dt + (v_p >> 1)) ^ v_sw;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                const unsigned char* a0 = Vs + v_rd + g * (32 * ROWB) + p * 128 + (chunk << 4);
+                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)AVD_LDS_PTR(a0));
+                const s16x4 up = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)AVD_LDS_PTR(a0 + 16 * ROWB));
+                const u32x2 a = __builtin_bit_cast(u32x2, lo), c2 = __builtin_bit_cast(u32x2, up);
+                const u32x4 w = {a[0], a[1], c2[0], c2[1]};
+                vf[p] = __builtin_bit_cast(bf16x8, w);
+            }
+        }
+        o[dt][0] = mma16s<F16>(vf[TT::PA[tt]], __builtin_bit_cast(bf16x8, P[0][TT::PB[tt]]), o[dt][0]);
+        o[dt][1] = mma16s<F16>(vf[TT::PA[tt]], __builtin_bit_cast(bf16x8, P[1][TT::PB[tt]]), o[dt][1]);
+    };
+
+    auto tile = [&](auto flags, int kt, S16& c, S16& n) {
+        using FL = decltype(flags);
+        constexpr bool MORE = FL::MORE;
+        // ================= phase A: S(kt+1) beside the exponentials of tile kt =================
+        float m_sub[2], alpha[2], ps[2] = {0.f, 0.f};
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            m_sub[qt] = F16 ? m_new[qt] - 15.0f : m_new[qt];
+            alpha[qt] = __builtin_amdgcn_exp2f(m_run[qt] - m_new[qt]);
+            m_run[qt] = m_new[qt];
+        }
+        // VALU items: 0..15 two exponentials each (registers 2 (w & 1), + 1 of S^T tile (w >> 2, (w >> 1) & 1)), 16..23 four O multiplies each
+        // (tile (w - 16) >> 1, query tile (w - 16) & 1), 24..31 one pair each of the split of key group 0 (query tile (w - 24) >> 2)
+        constexpr int NSLOT_A = 8 * TT::N, NITEM_A = 32;
+        auto item_a = [&](int w) {
+            if (w < 16) {
+                const int i = w >> 2, qt = (w >> 1) & 1, r0 = 2 * (w & 1);
+                const float e0 = F16 ? c.t[i][qt][r0] * s_inv2 : c.t[i][qt][r0], e1 = F16 ? c.t[i][qt][r0 + 1] * s_inv2 : c.t[i][qt][r0 + 1];
+                float p0 = __builtin_amdgcn_exp2f(e0 - m_sub[qt]), p1 = __builtin_amdgcn_exp2f(e1 - m_sub[qt]);
+                ps[qt] += p0 + p1;
+                asm volatile("" : "+v"(p0), "+v"(p1), "+v"(ps[qt]));
+                c.t[i][qt][r0] = p0;
+                c.t[i][qt][r0 + 1] = p1;
+            } else if (w < 24) {
+                const int dt = (w - 16) >> 1, qt = (w - 16) & 1;
+                float a0 = o[dt][qt][0] * alpha[qt], a1 = o[dt][qt][1] * alpha[qt], a2 = o[dt][qt][2] * alpha[qt], a3 = o[dt][qt][3] * alpha[qt];
+                asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));
+                o[dt][qt] = f32x4t{a0, a1, a2, a3};
+            } else {
+                const int qt = (w - 24) >> 2, e = (w - 24) & 3;
+                split_pair(c, 0, qt, e, pf[0][qt]);
+                if constexpr (NPL == 3) asm volatile("" : "+v"(pf[0][qt][0][e]), "+v"(pf[0][qt][1][e]), "+v"(pf[0][qt][2][e]));
+                else if constexpr (NPL == 2) asm volatile("" : "+v"(pf[0][qt][0][e]), "+v"(pf[0][qt][1][e]));
+                else asm volatile("" : "+v"(pf[0][qt][0][e]));
+            }
+        };
+        // the exponentials of key group 0 (S^T tiles 0, 1 = items 0..7) come before its split (items 24..31): items are dealt in index order
+        if constexpr (MORE) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) n.t[i][j] = f32x4t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sl = 0; sl < NSLOT_A; ++sl) {
+                A3_SB();
+                s_slot(n, sl / (2 * TT::N), (sl / TT::N) & 1, sl % TT::N);
+#pragma unroll
+                for (int w = sl * NITEM_A / NSLOT_A; w < (sl + 1) * NITEM_A / NSLOT_A; ++w) item_a(w);
+            }
+            A3_SB();
+            if constexpr (FL::VCL) {
+                if (ragged) mask_tail(n, kt + 1);
+            }
+        } else {
+#pragma unroll
+            for (int w = 0; w < NITEM_A; ++w) item_a(w);
+        }
+        l_run[0] = l_run[0] * alpha[0] + ps[0];
+        l_run[1] = l_run[1] * alpha[1] + ps[1];
+        sync();
+        if constexpr (MORE) {
+            if constexpr (FL::KCL) { if (kt + 2 < nkt) dma_clamp(Kb, Ks, kt + 2); }
+            else if constexpr (!FL::VCL) dma_full(Kb, Ks, kt + 2);
+        }
+
+        // ================= phase B: O += V(kt) P(kt) beside the split of key group 1 and the maxima of tile kt+1 =================
+        // slots (g, dt, tt): 4 TT::N per key group; items: group 0's slots carry the 8 pairs of group 1, group 1's slots the 32 maxima
+        float mt[2] = {A3_NEG, A3_NEG};
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+#pragma unroll
+            for (int sl = 0; sl < 4 * TT::N; ++sl) {
+                A3_SB();
+                pv_slot(g, sl / TT::N, sl % TT::N, pf[g]);
+                if (g == 0) {
+                    constexpr int NS = 4 * TT::N;
+#pragma unroll
+                    for (int w = sl * 8 / NS; w < (sl + 1) * 8 / NS; ++w) split_pair(c, 1, w >> 2, w & 3, pf[1][w >> 2]);
+                }
+                if (MORE && g == 1) {
+                    constexpr int NS = 4 * TT::N;
+#pragma unroll
+                    for (int w = sl * 16 / NS; w < (sl + 1) * 16 / NS; ++w) {         // item w: two registers of S^T tile (w >> 2, (w >> 1) & 1)
+                        const int i = w >> 2, qt = (w >> 1) & 1, r0 = 2 * (w & 1);
+                        mt[qt] = fmaxf(mt[qt], fmaxf(n.t[i][qt][r0], n.t[i][qt][r0 + 1]));
+                    }
+                    asm volatile("" : "+v"(mt[0]), "+v"(mt[1]));
+                }
+            }
+        }
+        A3_SB();
+        if constexpr (MORE) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                if constexpr (F16) mt[qt] *= s_inv2;
+                m_new[qt] = fmaxf(m_run[qt], xmax(mt[qt]));
+            }
+            if constexpr (FL::COPY) c = n;
+            sync();
+            if constexpr (FL::VCL) dma_clamp(Vb, Vs, kt + 1);
+            else dma_full(Vb, Vs, kt + 1);
+        }
+    };
+    {
+        using Main = A3Flags<true, false, false, false>;
+        using MainC = A3Flags<true, false, false, true>;
+        using KClamp = A3Flags<true, true, false, true>;
+        using VClamp = A3Flags<true, false, true, true>;
+        using Last = A3Flags<false, false, false, false>;
+        int kt = 0;
+        for (; kt + 4 < nkt; kt += 2) {
+            tile(Main{}, kt, sa, sb);
+            tile(Main{}, kt + 1, sb, sa);
+        }
+        if (nkt - kt == 4) { tile(MainC{}, kt, sa, sb); ++kt; }
+        if (nkt - kt == 3) { tile(KClamp{}, kt, sa, sb); ++kt; }
+        if (nkt - kt == 2) { tile(VClamp{}, kt, sa, sb); ++kt; }
+        tile(Last{}, kt, sa, sb);
+    }
+#undef A3_SB
+
+    // ---- normalise and store.  Lane (l15, kq) holds O[query 16 qt + l15][16 dt + 4 kq + r] in o[dt][qt][r]; one v_permlane16_swap per register
+    // pair (qt = 0, 1) leaves it with 8 consecutive d of ONE query: query tile kq & 1, d = 16 dt + 8 (kq >> 1) + (0..7) ----
+    float inv[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float l_tot = xsum(l_run[qt]);
+        inv[qt] = F16 ? v_inv / l_tot : 1.0f / l_tot;
+    }
+    const int d = H * A3_DH;
+    const int q_row = q_row0 + 16 * (kq & 1);
+    unsigned char* o3 = reinterpret_cast<unsigned char*>(out);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[dt][0][r] * inv[0]), __float_as_uint(o[dt][1][r] * inv[1]), false, false);
+            v[r] = __uint_as_float(sw[0]);
+            v[4 + r] = __uint_as_float(sw[1]);
+        }
+        const int col = h * A3_DH + 16 * dt + 8 * (kq >> 1);
+        if (q_row < n_query) {
+            if constexpr (SPLIT_OUT) {
+                if constexpr (F16) store_split8_h2(o3, (int64_t)b * out_tok + q_row, col, d, v, o_scale);
+                else store_split8(o3, (int64_t)b * out_tok + q_row, col, d, v);
+            } else {
+                float* dst = out + ((int64_t)b * out_tok + q_row) * d + col;
+                *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+            }
+        }
+    }
+}
+
 int64_t qkv3_bytes(int B, int N, int H) { return (int64_t)3 * B * H * qkv3_npad(N) * QKV3_ROWB; }
 
 // out3 != null: split3 image of the [B*N, H*64] result; otherwise fp32 out [B, N, H*64]
@@ -661,6 +1040,15 @@ static void attn3_launch(const unsigned char* img, float* out, void* out3, int B
     const float s_inv2 = 1.0f / (img_scale * img_scale), v_inv = 1.0f / img_scale;
     // the pipelined kernel pays for the exact three-plane modes (C3: 175 -> 170 us per launch, profiles/r04_attn_pipe.txt); with two fp16
     // planes or one bf16 plane a tile has half / a sixth of the MFMAs to hide the VALU work behind and the plain kernel is as fast or faster
+    if (g_attn_m16 && (TERMS == 6 || TERMS == 9 || g_attn_m16 == 2)) {
+        if (out3)
+            hipLaunchKernelGGL((attn_bf16x3_p16_kernel<true, TERMS>), dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, static_cast<float*>(out3),
+                               B, N, Npad, H, n_query, nqb, s_inv2, v_inv, out_scale, out_tok);
+        else
+            hipLaunchKernelGGL((attn_bf16x3_p16_kernel<false, TERMS>), dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, out, B, N, Npad, H,
+                               n_query, nqb, s_inv2, v_inv, out_scale, out_tok);
+        return;
+    }
     if (g_attn_pipe == 2 || (g_attn_pipe == 1 && (TERMS == 6 || TERMS == 9))) {
         if (out3)
             hipLaunchKernelGGL((attn_bf16x3_pipe_kernel<true, TERMS>), dim3(nqb * H * B), dim3(A3_NW * 64), 0, st, img, static_cast<float*>(out3),

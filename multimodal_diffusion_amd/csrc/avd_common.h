@@ -225,7 +225,9 @@ constexpr int QKV3_ROWB = 384;
 __host__ __device__ __forceinline__ int qkv3_npad(int n) { return (n + 63) / 64 * 64; }
 __host__ __device__ __forceinline__ int qkv3_swizzle(int part, int n) {
     // q: read straight from global; k: ds_read_b128 of 32 key rows; v: ds_read_b64_tr_b16 of 4-key x 16-d blocks
-    return part == 0 ? 0 : part == 1 ? (n >> 1) & 7 : ((n >> 1) & 1) << 2;
+    // (v, round 5: bit 2 of the key joins the swizzle — conflict-free for the transposed reads of BOTH MFMA shapes; with bit 1 alone the
+    // 16x16x32 kernel's reads, whose 32-lane half spans keys k and k + 4, were 2-way; brute-forced over all linear 4-bit swizzles)
+    return part == 0 ? 0 : part == 1 ? (n >> 1) & 7 : (((n >> 1) & 1) << 2) | (((n >> 2) & 1) << 1);
 }
 
 // measurement hooks (see avd_prof_enable): RAII bracket around one launch
@@ -284,12 +286,14 @@ extern int g_mlp_fused;          // 1: fc1 -> GELU -> fc2 of the six-term bf16x3
 bool mlp_bf16x3_supported(int d, int hidden, int terms);
 int mlp_bf16x3(const void* X3, const void* W1n3, const float* b1, const void* W23, const float* b2, const float* ss_in, float eps,
                const float* R, float* C, void* C3, float* ss_out, int64_t M, int d, int hidden, hipStream_t st);
+extern int g_attn_m16;           // 1: the split-operand attention of the three-plane modes on v_mfma_f32_16x16x32 (2: every split mode; avd_tune_set "attn_m16")
 extern int g_attn_pipe;          // 1 (default): the split-operand attention as one software pipeline per wave (avd_tune_set "attn_pipe")
 extern int g_s3_m16;             // 1 (default): bf16x3 GEMMs on v_mfma_f32_16x16x32_bf16, two terms per MFMA; 0: 32x32x16 (avd_tune_set "s3_m16")
 extern int g_s3_w128;            // 1: the 8-wave bf16x3 blocks with an image epilogue run as 4 waves with a 128 x 128 wave tile (avd_tune_set "s3_w128")
 extern int g_s3_rt4;             // row tiles per wave of the 4-wave image-epilogue blocks: 0 automatic, 5 .. 8 = 160 .. 256-row blocks (avd_tune_set "s3_rt4")
 extern int g_s3_deep4;           // 1: residual + image launches whose 4-wave blocks fit the CUs once run one block per CU on a four-stage ring (avd_tune_set "s3_deep4")
 extern int g_s3_rt;              // rows per 8-wave block of the residual + image epilogue: 0 automatic, 7 = 224 rows, 8 = 256 rows (avd_tune_set "s3_rt")
+extern int g_cfg_rows;           // 1 (default): fused CFG + un-patch + DDIM through whole 128-byte lines (tokens.hip; avd_tune_set "cfg_rows")
 extern int g_s3_sn, g_s3_super4, g_s3_super8;      // super-tile shape overrides of the split GEMMs, 0 = default (avd_tune_set "s3_sn" / "s3_super4" / "s3_super8")
 extern int g_s3_tile;            // -1 = per epilogue; 0 / 1 = 8-wave 256x256 / 4-wave 256x128 blocks (avd_tune_set "s3_tile")
 extern thread_local bool t_s3_two_streams;

@@ -650,10 +650,12 @@ extern "C" int avd_tune_set(const char* key, int64_t value) {
         return AVD_OK;
     }
     if (!strcmp(key, "s3_stagger")) { g_s3_stagger = (int)value; return AVD_OK; }
+    if (!strcmp(key, "cfg_rows")) { g_cfg_rows = value != 0; return AVD_OK; }
     if (!strcmp(key, "s3_sn")) { g_s3_sn = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_super4")) { g_s3_super4 = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_super8")) { g_s3_super8 = (int)value; return AVD_OK; }
     if (!strcmp(key, "attn_pipe")) { g_attn_pipe = (int)value; return AVD_OK; }
+    if (!strcmp(key, "attn_m16")) { g_attn_m16 = (int)value; return AVD_OK; }
     if (!strcmp(key, "core_trim")) { g_core_trim = value != 0; return AVD_OK; }
     if (!strcmp(key, "mlp_fused")) { g_mlp_fused = (int)value; return AVD_OK; }
     if (!strcmp(key, "gemm_tile")) { g_gemm_force_tile = (int)value; return AVD_OK; }

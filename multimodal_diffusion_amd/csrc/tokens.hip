@@ -10,6 +10,8 @@
 // element, which is its HBM roofline.
 #include "avd_common.h"
 
+#include <stdlib.h>
+
 namespace avd {
 
 // ------------------------------------------------------------------ timestep embedding
@@ -240,6 +242,7 @@ int ddim_step_f32(const float* x_t, const float* eps, const int64_t* t_now, cons
 }
 
 // ------------------------------------------------------------------ fused CFG + unpatch + DDIM (video target)
+int g_cfg_rows = getenv("AVD_CFG_ROWS") ? atoi(getenv("AVD_CFG_ROWS")) : 1;      // avd_tune_set "cfg_rows": 0 = the 16-bytes-per-lane gather form
 __global__ __launch_bounds__(256) void cfg_unpatch_ddim_kernel(
     const float* __restrict__ eps2, const float* __restrict__ z, const int64_t* __restrict__ t_now,
     const int64_t* __restrict__ t_prev, const float* __restrict__ abar, int T_train, float guidance, float eta,
@@ -266,6 +269,54 @@ __global__ __launch_bounds__(256) void cfg_unpatch_ddim_kernel(
     *reinterpret_cast<f32x4*>(z_out + lat) = o;
 }
 
+// Coalesced form (round 5).  In the kernel above a lane's 16 bytes of latent (4 consecutive w) are one 16-byte piece of a token row, and
+// the NEXT 16 bytes of latent belong to the next token, 1 KiB further on: every wave-wide token read touches 64 cache lines for 16 bytes
+// each (FETCH_SIZE 63 MB per launch at C3 against 37.7 MB algorithmic).  Here a block owns GT tokens that are neighbours along w' — GT x w
+// = one 128-byte line of latent per (c, t, h) — reads their cond / null rows as whole contiguous rows (GT x D floats each, 16 B per lane),
+// combines (CFG) in registers, parks the combined eps in LDS as [token][feature] and reads it back as [(c, t, h)][GT x w]: eight lanes then
+// cover one full 128-byte line of z / z_out.  Same arithmetic per element, in the same order: bit-identical to the kernel above.
+template <int GT>      // tokens per block
+__global__ __launch_bounds__(256) void cfg_unpatch_ddim_rows_kernel(
+    const float* __restrict__ eps2, const float* __restrict__ z, const int64_t* __restrict__ t_now,
+    const int64_t* __restrict__ t_prev, const float* __restrict__ abar, int T_train, float guidance, float eta,
+    const float* __restrict__ noise, float* __restrict__ z_out, Tube g, int B, int groups_per_sample) {
+    extern __shared__ __attribute__((aligned(16))) float ebuf[];       // [GT][D + 4]: the pad keeps the transposed 16-byte reads off one bank group
+    const int LD = g.D + 4;
+    const int b = blockIdx.x / groups_per_sample, grp = blockIdx.x % groups_per_sample;
+    const int n0 = grp * GT;                                            // first token of the group (GT divides W / w: one (t', h') row)
+    const float* tc = eps2 + ((int64_t)b * (g.per / g.D) + n0) * g.D;
+    const float* tn = eps2 + (((int64_t)B + b) * (g.per / g.D) + n0) * g.D;
+    const int nf4 = GT * g.D / 4;
+    for (int i = threadIdx.x; i < nf4; i += 256) {
+        const f32x4 ec = *reinterpret_cast<const f32x4*>(tc + (int64_t)i * 4), en = *reinterpret_cast<const f32x4*>(tn + (int64_t)i * 4);
+        f32x4 e;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) e[k] = en[k] + guidance * (ec[k] - en[k]);
+        const int tok = (i * 4) / g.D, k0 = (i * 4) % g.D;
+        *reinterpret_cast<f32x4*>(ebuf + tok * LD + k0) = e;
+    }
+    __syncthreads();
+    const Ddim c = ddim_coef(t_now, t_prev, abar, T_train, eta, b);
+    // token coordinates of the group: n = (t' Ht + h') Wt + w'
+    const int wq = n0 % g.Wt, hq = (n0 / g.Wt) % g.Ht, tq = n0 / (g.Wt * g.Ht);
+    const int segs = g.D / g.w;                                          // (c, t, h) combinations of a token
+    const int per_seg4 = GT * g.w / 4;                                   // float4s of one latent line piece
+    for (int i = threadIdx.x; i < segs * per_seg4; i += 256) {
+        const int sg = i / per_seg4, j = i % per_seg4;                   // piece j of line sg: token j * 4 / w, offset (j * 4) % w
+        const int tok = (j * 4) / g.w, wo = (j * 4) % g.w;
+        const int hh = sg % g.h, tt = (sg / g.h) % g.t, cc = sg / (g.h * g.t);
+        const f32x4 e = *reinterpret_cast<const f32x4*>(ebuf + tok * LD + sg * g.w + wo);
+        const int64_t lat = (int64_t)b * g.per + (((int64_t)cc * g.T + (tq * g.t + tt)) * g.H + (hq * g.h + hh)) * g.W + (wq + tok) * g.w + wo;
+        const f32x4 x = *reinterpret_cast<const f32x4*>(z + lat);
+        f32x4 zn = {0.f, 0.f, 0.f, 0.f};
+        if (eta > 0.f) zn = *reinterpret_cast<const f32x4*>(noise + lat);
+        f32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = ddim_apply(c, x[k], e[k], zn[k]);
+        *reinterpret_cast<f32x4*>(z_out + lat) = o;
+    }
+}
+
 int cfg_unpatch_ddim_f32(const float* eps2, const float* z, const int64_t* t_now, const int64_t* t_prev,
                          const float* abar, int T_train, float guidance, float eta, const float* noise, float* z_out,
                          int B, int C, int T, int H, int W, int t, int h, int w, hipStream_t st) {
@@ -278,6 +329,20 @@ int cfg_unpatch_ddim_f32(const float* eps2, const float* z, const int64_t* t_now
     const int64_t total4 = (int64_t)B * (g.per >> 2);
     static const int tag = prof_tag_id("cfg_unpatch_ddim_kernel");
     ProfScope prof(tag, 16.0 * (double)B * g.per, st);
+    // whole-line form: groups of tokens along w' that make up 128 bytes (or the whole row when W is shorter) of latent per (c, t, h)
+    const int gt = (g.W < 32 ? g.W : 32) / g.w;
+    if (g_cfg_rows && (gt == 8 || gt == 4) && g.Wt % gt == 0 && g.D % 4 == 0 && (int64_t)gt * (g.D + 4) * 4 <= 64 * 1024) {
+        const int groups = (int)(g.per / g.D) / gt;
+        const size_t lds = (size_t)gt * (g.D + 4) * 4;
+        if (gt == 8)
+            hipLaunchKernelGGL(cfg_unpatch_ddim_rows_kernel<8>, dim3((unsigned)(B * groups)), dim3(256), lds, st, eps2, z, t_now, t_prev, abar,
+                               T_train, guidance, eta, noise, z_out, g, B, groups);
+        else
+            hipLaunchKernelGGL(cfg_unpatch_ddim_rows_kernel<4>, dim3((unsigned)(B * groups)), dim3(256), lds, st, eps2, z, t_now, t_prev, abar,
+                               T_train, guidance, eta, noise, z_out, g, B, groups);
+        AVD_CHECK_LAUNCH("cfg_unpatch_ddim (rows)");
+        return AVD_OK;
+    }
     hipLaunchKernelGGL(cfg_unpatch_ddim_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, eps2, z, t_now,
                        t_prev, abar, T_train, guidance, eta, noise, z_out, g, B, total4);
     AVD_CHECK_LAUNCH("cfg_unpatch_ddim");

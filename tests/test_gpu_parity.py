@@ -930,6 +930,44 @@ def test_attention_bf16x3_edge_shapes(dev, B, N, H, nq):
     assert torch.all(out[:, nq:] == 7.0)
 
 
+@pytest.mark.parametrize("B,N,H,nq,terms", [(2, 133, 4, 133, 6), (1, 421, 8, 421, 6), (3, 64, 8, 64, 6), (2, 37, 4, 37, 6), (1, 5, 4, 5, 6),
+                                             (1, 200, 4, 1, 6), (1, 129, 8, 128, 6), (1, 1573, 4, 1536, 6), (2, 421, 4, 384, 9), (2, 257, 4, 257, 1)])
+def test_attention_m16_shape(dev, B, N, H, nq, terms):
+    """Round 5: the split-operand attention on v_mfma_f32_16x16x32 (avd_tune_set "attn_m16"; attn_bf16x3_p16_kernel — query columns spread
+    over the four 16-lane groups, V read in the key order two S^T tiles give): against softmax(q k^T / 8) v in fp64 at the 32x32x16 kernel's
+    tolerance, next to that kernel's own error, rows past n_query untouched, and the operand-image output equal to the fp32 output."""
+    from multimodal_diffusion_amd import functional as Fn, _lib as L
+    d = H * 64
+    g = torch.Generator().manual_seed(N * 7 + H + terms)
+    qkv = torch.randn(B * N, 3 * d, generator=g) * 1.5
+    lib = L.lib()
+    img = torch.empty(lib.avd_qkv3_bytes(B, N, H), dtype=torch.uint8, device=dev)
+    x3, w3 = Fn.split3(qkv.to(dev)), Fn.split3(torch.eye(3 * d).to(dev))
+    zb = torch.zeros(3 * d, device=dev)
+    L.check(lib.avd_gemm_bf16x3_qkv3_f32(x3.data_ptr(), w3.data_ptr(), zb.data_ptr(), img.data_ptr(), B * N, N, H, 3 * d,
+                                         0.125 * 1.4426950408889634, 6, L.stream_ptr(dev)))
+    full = qkv.double().view(B, N, 3, H, 64)
+    q, k, v = (full[:, :, i].transpose(1, 2) for i in range(3))
+    ref = (torch.softmax(q @ k.transpose(-1, -2) / 8.0, dim=-1) @ v).transpose(1, 2).reshape(B, N, d)
+    outs = {}
+    try:
+        for m16 in (0, 2):
+            _tune("attn_m16", m16)
+            out = torch.full((B, N, d), 7.0, device=dev)
+            L.check(lib.avd_attn_fwd_qkv3_f32(img.data_ptr(), out.data_ptr(), None, B, N, H, nq, terms, L.stream_ptr(dev)))
+            outs[m16] = out.cpu()
+        o3 = torch.zeros(lib.avd_split3_bytes(B * N, d), dtype=torch.uint8, device=dev)
+        L.check(lib.avd_attn_fwd_qkv3_f32(img.data_ptr(), None, o3.data_ptr(), B, N, H, nq, terms, L.stream_ptr(dev)))
+    finally:
+        _tune("attn_m16", 0)
+    tol = 2e-6 if terms != 1 else 2e-2          # (one plane: plain bf16 operands, reduced precision)
+    e16, e32 = rel_err(outs[2][:, :nq], ref[:, :nq]), rel_err(outs[0][:, :nq], ref[:, :nq])
+    assert e16 < tol and e16 < 2.0 * e32 + 2e-7, (e16, e32)
+    assert torch.all(outs[2][:, nq:] == 7.0)
+    got = _split3_decode(o3.cpu().numpy(), B * N, d).astype(np.float64).sum(0).reshape(B, N, d)
+    assert np.array_equal(got[:, :nq], outs[2].double().numpy()[:, :nq]) and not got[:, nq:].any()
+
+
 def test_vae_decode_bf16x3(dev):
     """Decoder convolutions on the bf16 matrix pipe with split operands: golden fixture, ragged tiles, and the fp64 oracle at
     128x128 — same tolerance as the fp32-MFMA decoder, and no further from fp64 than that decoder is."""
@@ -997,6 +1035,40 @@ def test_full_step_v2a_bf16x3(dev, full):
     f32.set_prompt(z_v.to(dev))
     o32 = f32.step(z_a.to(dev), tn.to(dev), tp.to(dev))
     assert not torch.equal(out, o32) and rel_err(out.cpu(), o32.cpu()) < 2e-5
+
+
+@pytest.mark.parametrize("B,C,T,H,W,eta", [(3, 8, 12, 32, 32, 0.0), (2, 8, 12, 64, 64, 0.0), (2, 8, 12, 16, 16, 0.5), (5, 8, 4, 8, 32, 0.0),
+                                            (2, 8, 4, 8, 8, 0.0)])
+def test_cfg_unpatch_ddim_row_form_is_bit_identical(dev, B, C, T, H, W, eta):
+    """Round 5: the fused CFG + un-patch + DDIM kernel moves whole token rows in and whole 128-byte latent lines out through an LDS
+    transpose (avd_tune_set "cfg_rows" 1, default) instead of one 16-byte gather per lane: the same arithmetic per element — results
+    equal bit for bit (W = 32 / 64: eight tokens per line; W = 16: four; W = 8 falls back to the gather form), and both match the oracle."""
+    from multimodal_diffusion_amd import _lib as L
+    g = torch.Generator().manual_seed(B * 100 + W)
+    Nv = (T // 2) * (H // 4) * (W // 4)
+    eps2 = torch.randn(2 * B, Nv, C * 2 * 4 * 4, generator=g)
+    z = torch.randn(B, C, T, H, W, generator=g)
+    noise = torch.randn(B, C, T, H, W, generator=g) if eta > 0 else None
+    tn = torch.tensor([982, 500, 16, 999, 3][:B])
+    tp = torch.tensor([966, 480, -1, 979, -1][:B])
+    abar = R.alpha_bar_table(R.beta_table(1000))
+    outs = {}
+    for rows in (0, 1):
+        _tune("cfg_rows", rows)
+        try:
+            out = torch.empty(B, C, T, H, W, device=dev)
+            L.check(L.lib().avd_cfg_unpatch_ddim_f32(eps2.to(dev).data_ptr(), z.to(dev).data_ptr(), tn.to(dev).data_ptr(), tp.to(dev).data_ptr(),
+                                                     abar.to(dev).data_ptr(), 1000, 3.5, eta, L.ptr(None if noise is None else noise.to(dev)),
+                                                     out.data_ptr(), B, C, T, H, W, 2, 4, 4, L.stream_ptr(dev)))
+            torch.cuda.synchronize()
+            outs[rows] = out.cpu()
+        finally:
+            _tune("cfg_rows", 1)
+    assert torch.equal(outs[0], outs[1])
+    e = eps2[B:] + 3.5 * (eps2[:B] - eps2[B:])
+    if eta == 0:
+        ref = R.ddim_update(z.double(), tn, tp, R.tube_unpatch(e.double(), C, T, H, W, 2, 4, 4), abar.double())
+        assert rel_err(outs[1], ref) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------------- round-2 coverage
