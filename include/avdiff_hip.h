@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AVD_ABI_VERSION 5
+#define AVD_ABI_VERSION 6
 
 #define AVD_OK            0
 #define AVD_EINVAL       -1   /* bad shape / argument (reference: AssertionError / ValueError) */
@@ -52,7 +52,8 @@ int         avd_device_arch(char* buf, int buflen);
  * partial sums added in slice order, no atomics), "s3_tile" (-1 per epilogue, 0 = 8-wave
  * 256x256, 1 = 4-wave 256x128 blocks of the split-operand GEMMs), "s3_stagger" (first-generation stagger of co-resident 4-wave blocks,
  * x 1024 cycles; -1 automatic), "cfg_rows" (1 default: the fused CFG + un-patch + DDIM kernel reads token rows whole and writes whole 128-byte lines of latent through an LDS
- * transpose; 0: one 16-byte gather per lane; bit-identical), "s3_sn" / "s3_super4" / "s3_super8" (super-tile of the split GEMMs' block order — the blocks an XCD runs together: width in column blocks /
+ * transpose; 0: one 16-byte gather per lane; bit-identical), "vae_lat" (1 default: avd_vae_decode_f32 takes the latent-composed first convolution when the descriptor
+ * carries conv0_lat_w3; 0: from_lat -> upsample -> 64-channel convolution), "s3_sn" / "s3_super4" / "s3_super8" (super-tile of the split GEMMs' block order — the blocks an XCD runs together: width in column blocks /
  * blocks per super-tile of the two-per-CU / one-per-CU kernels; 0 = default; bit-identical, measurement aid of profiles/r05_fetch_ab.txt), "s3_min_rows" (smallest 2B*N that takes the split-operand kernels: -1 default = 2,048 rows for the core in the six-term bf16x3 mode, 6,144 otherwise; >= 0 = that many in every mode), "no_fold" (1 = keep RMSNorm as
  * separate kernels in avd_core_forward_f32, in every mode), "s3_m16" (1 default: bf16x3 GEMMs on v_mfma_f32_16x16x32_bf16 with two product
  * terms per instruction; 0: the 32x32x16 kernel), "s3_rt" (rows per block of the bf16x3 residual + image epilogue: 0 automatic,
@@ -64,7 +65,7 @@ int         avd_device_arch(char* buf, int buflen);
  * fill at most half of the chip's block slots — small and mid-size batches; 0 = never, default and maximum 4; partial sums are added in
  * slice order by a reduction kernel, no atomics), "attn_pipe" (1 default: the three-plane split-operand attention runs as one software
  * pipeline per wave — the next tile's score MFMAs beside this tile's softmax; 0: the plain kernel everywhere, 2: the pipeline in every
- * split mode), "core_trim" (1 default: the last block of avd_core_forward_f32 runs out_proj / fc1 / fc2 / the final norm on the caller's
+ * split mode), "attn_m16" (1 default: that pipeline on v_mfma_f32_16x16x32 in the three-plane modes — same cycles per FLOP, less power, so a higher clock under the cap; 0: the 32x32x16 kernels; 2: the 16x16x32 kernel in every split mode), "core_trim" (1 default: the last block of avd_core_forward_f32 runs out_proj / fc1 / fc2 / the final norm on the caller's
  * row window only; 0: on every row; the window's results are bit-identical), "mlp_fused" (0 default; 1: fc1 -> GELU -> fc2 of the six-term
  * bf16x3 path as ONE launch whose hidden activations stay on the CU — d = 512 only; bit-identical to the two launches, and measures
  * 1.5x slower: DESIGN.md 4.9). */
@@ -397,6 +398,15 @@ typedef struct {
     const float* conv_a_scale;         /* conv_terms 3: HOST array [n_blocks], scales of each block's INPUT image: entry i >= 1 from the bound
                                         * |GroupNorm output| <= sqrt(n - 1) max|gamma| + max|beta| (n = elements of one group of one sample);
                                         * entry 0 is ignored — the first image's scale is derived on the device from max |from_lat(z)| */
+    /* ABI 6 — the first convolution composed with what precedes it (vae_video3d.py:205-209: from_lat -> trilinear upsample -> dec_net.0.0):
+     * upsampling is linear, channel-wise and its weights sum to one, so conv(upsample(from_lat(z))) is a convolution of upsample(z) — Cv <= 16
+     * input channels instead of 64, a quarter of the matrix work — plus a bias term.  With conv_w3 and conv0_lat_w3 both given the decoder
+     * takes that route for block 0 (same operator up to fp32 rounding); NULL = the three separate passes. */
+    const void* conv0_lat_w3;          /* avd_conv3_weight_[f16x2_]f32 image of the composite weight [out][kt][kh][kw][in], in < Cv:
+                                        * sum_c conv_w[0][out][c][tap] * from_lat_w[c][in], in >= Cv zero */
+    const float* conv0_lat_btab;       /* [64 border classes][base]: sum over the taps INSIDE the volume of sum_c conv_w[0][out][c][tap] * from_lat_b[c];
+                                        * class bits: t-1 inside, t+1 inside, h-1, h+1, w-1, w+1 (the conv zero-pads u = from_lat(.), not its bias) */
+    float conv0_lat_w_scale;           /* conv_terms 3: scale of the conv0_lat_w3 image */
 } avd_vae_decode_desc;
 /* weight image of one 3x3x3 64->64 convolution for the split-operand decoders: w_tap_major is [out][kt][kh][kw][in] fp32 */
 int64_t avd_conv3_weight_bytes(void);

@@ -670,7 +670,9 @@ __device__ __forceinline__ f32x4t mma16s(bf16x8 a, bf16x8 b, f32x4t c) {
     if constexpr (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
-int g_attn_m16 = getenv("AVD_ATTN_M16") ? atoi(getenv("AVD_ATTN_M16")) : 0;
+// Measured (profiles/r05_attn_m16.txt): C3 151.8 -> 146.2 us per launch alone (shader clock 2,140 -> 2,254 MHz at the same ~1,355 W), 157.4 -> 152.3 us inside
+// the step, C5 geometry 415.6 -> 400.8 us: default 1 for the three-plane modes (2: every split mode, 0: the 32x32x16 kernels).
+int g_attn_m16 = getenv("AVD_ATTN_M16") ? atoi(getenv("AVD_ATTN_M16")) : 1;
 
 struct S16 { f32x4t t[4][2]; };       // scores / probabilities of one 64-key tile: [key tile][query tile]
 

@@ -211,9 +211,17 @@ __device__ __forceinline__ Ddim ddim_coef(const int64_t* t_now, const int64_t* t
     return c;
 }
 
+// No fp contraction in these two: the reference evaluates them as separate torch ops, one rounding each (schedule_utils.py:186-199,
+// sample_clip.py:381), and hipcc's default -ffp-contract=fast picks its fused multiply-adds per CALL SITE — the same expression came out one
+// ulp apart in two kernels of this file (round 5: the whole-line CFG kernel against the gather form; round 4 met the same in split8).
 __device__ __forceinline__ float ddim_apply(const Ddim& c, float x, float e, float zn) {
+#pragma clang fp contract(off)
     const float x0 = (x - c.sqrt_omb_t * e) / c.den;
     return c.sqrt_a_prev * x0 + c.coeff_eps * e + c.sigma * zn;
+}
+__device__ __forceinline__ float cfg_combine(float e_cond, float e_null, float guidance) {
+#pragma clang fp contract(off)
+    return e_null + guidance * (e_cond - e_null);
 }
 
 __global__ __launch_bounds__(256) void ddim_kernel(const float* __restrict__ x, const float* __restrict__ eps,
@@ -263,7 +271,7 @@ __global__ __launch_bounds__(256) void cfg_unpatch_ddim_kernel(
     f32x4 o;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const float e = en[k] + guidance * (ec[k] - en[k]);
+        const float e = cfg_combine(ec[k], en[k], guidance);
         o[k] = ddim_apply(c, x[k], e, zn[k]);
     }
     *reinterpret_cast<f32x4*>(z_out + lat) = o;
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256) void cfg_unpatch_ddim_rows_kernel(
         const f32x4 ec = *reinterpret_cast<const f32x4*>(tc + (int64_t)i * 4), en = *reinterpret_cast<const f32x4*>(tn + (int64_t)i * 4);
         f32x4 e;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) e[k] = en[k] + guidance * (ec[k] - en[k]);
+        for (int k = 0; k < 4; ++k) e[k] = cfg_combine(ec[k], en[k], guidance);
         const int tok = (i * 4) / g.D, k0 = (i * 4) % g.D;
         *reinterpret_cast<f32x4*>(ebuf + tok * LD + k0) = e;
     }
@@ -375,7 +383,7 @@ __global__ void cfg_untoken_ddim_audio_kernel(const float* __restrict__ eps2, co
         for (int n = n_lo; n <= n_hi; ++n) {
             const int64_t o = (int64_t)n * D + c * len + (f - n * stride);
             const float vn = tn[o];
-            acc += vn + guidance * (tc[o] - vn);
+            acc += cfg_combine(tc[o], vn, guidance);
             cnt += 1.f;
         }
         e = acc / fmaxf(cnt, 1e-8f);

@@ -14,6 +14,8 @@
 // next conv's padded input — or, after the last block, fuses normalise + to_img (64->3) + sigmoid and writes NCDHW.
 #include "avd_common.h"
 
+#include <stdlib.h>
+
 namespace avd {
 
 constexpr int VC = 64;          // channels of the decoder trunk (reference default dec_base = 64)
@@ -471,6 +473,9 @@ struct Conv3Args {
     // when the activation scale was derived on the device (decoder block 0) a_inv_dev points at 1 / s_act and ab_inv is 1 / s_w
     float ab_inv;
     const float* a_inv_dev;
+    // latent-composed first decoder conv (LAT instantiations, see upsample_lat16_kernel): per border class, what the from_lat bias
+    // contributes through the taps that fall inside the volume — btab[class][64 out], class = 6 bits (t lo, t hi, h lo, h hi, w lo, w hi)
+    const float* btab;
 };
 
 // scale slot in the workspace: [0] max |x|, [1] (max row norm, unused), [2] s, [3] 1 / s
@@ -589,6 +594,56 @@ __global__ __launch_bounds__(256) void gn_apply_pad3_kernel(const float* __restr
     store_act3<F16>(X3, pv, c8, o, sc);
 }
 
+// ---- input image of the latent-composed first decoder conv: per padded voxel 96 B = [plane h | m | l][16 ch bf16] (f16x2: planes h, l at
+// the device-derived scale), channels 0 .. Cv-1 = trilinear upsample of the LATENT z itself (NCDHW, Cv <= 16), the rest zero.  One thread
+// per output voxel: 8 neighbours x Cv channels of a latent that is a few hundred KB per sample (L2-resident), 96 contiguous bytes out.
+constexpr int L16_ROWB = 96;
+template <bool F16>
+__global__ __launch_bounds__(256) void upsample_lat16_kernel(const float* __restrict__ z, unsigned char* __restrict__ X16, int Cv, int Tp,
+                                                             int Hp_, int Wp_, int T, int H, int W, float st, float sh, float sw,
+                                                             int64_t nvox, const float* __restrict__ sc_dev) {
+    const int64_t vox = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (vox >= nvox) return;
+    const int THW = T * H * W;
+    const int smp = (int)(vox / THW), v = (int)(vox % THW);
+    const int w = v % W, h = (v / W) % H, t = v / (W * H);
+    int t0, t1, h0, h1, w0, w1;
+    float tl0, tl1, hl0, hl1, wl0, wl1;
+    tri_src(t, st, Tp, t0, t1, tl0, tl1);
+    tri_src(h, sh, Hp_, h0, h1, hl0, hl1);
+    tri_src(w, sw, Wp_, w0, w1, wl0, wl1);
+    const int vol = Tp * Hp_ * Wp_;
+    const int o00 = (t0 * Hp_ + h0) * Wp_, o01 = (t0 * Hp_ + h1) * Wp_, o10 = (t1 * Hp_ + h0) * Wp_, o11 = (t1 * Hp_ + h1) * Wp_;
+    float o[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        o[c] = 0.f;
+        if (c < Cv) {
+            const float* b = z + ((int64_t)smp * Cv + c) * vol;
+            // the association of torch's CPU kernel (and of upsample_pad3_kernel)
+            o[c] = tl0 * (hl0 * (wl0 * b[o00 + w0] + wl1 * b[o00 + w1]) + hl1 * (wl0 * b[o01 + w0] + wl1 * b[o01 + w1])) +
+                   tl1 * (hl0 * (wl0 * b[o10 + w0] + wl1 * b[o10 + w1]) + hl1 * (wl0 * b[o11 + w0] + wl1 * b[o11 + w1]));
+        }
+    }
+    const int64_t pv = (((int64_t)smp * (T + 2) + t + 1) * (H + 2) + h + 1) * (W + 2) + w + 1;
+    unsigned char* dst = X16 + pv * L16_ROWB;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if constexpr (F16) {
+            u32x4 Hh, Lo;
+            split8_h2(o + 8 * half, sc_dev[0], Hh, Lo);
+            *reinterpret_cast<u32x4*>(dst + half * 16) = Hh;
+            *reinterpret_cast<u32x4*>(dst + 32 + half * 16) = Lo;
+        } else {
+            u32x4 Hh, Mi, Lo;
+            split8(o + 8 * half, Hh, Mi, Lo);
+            *reinterpret_cast<u32x4*>(dst + half * 16) = Hh;
+            *reinterpret_cast<u32x4*>(dst + 32 + half * 16) = Mi;
+            *reinterpret_cast<u32x4*>(dst + 64 + half * 16) = Lo;
+        }
+    }
+}
+
 // conv 3x3x3 64 -> 64 + bias + GELU + GroupNorm partial statistics on the 16-bit matrix pipe — HALO-TILE kernel (round 3).
 // Rounds 1-2 ran this as an implicit GEMM that re-fetched the block's A tile from global memory for every tap (27 x), 12-24 MFMAs
 // per wave between barriers on a 64 x 32 wave tile: 0.30 of the matrix peak, a K stage of ~2,150 cycles of which ~770 were MFMA.
@@ -617,12 +672,21 @@ template <int TERMS> struct HaloCfg {
     static constexpr int VOX = HT_T * TH * HT_W;                      // output voxels per block: 512 / 256
 };
 
-template <int TERMS>     // 6: bf16x3; 3: f16x2 (planes h, l of the same buffers; the third plane is neither moved nor read)
+// NSLAB: 16-channel slabs of the input.  4 = the 64 -> 64 convolutions (act3 rows of 384 B).  1 (LAT) = the decoder's FIRST convolution
+// composed with what precedes it (round 5): its input is upsample(from_lat(z)) = from_lat_w . upsample(z) + from_lat_b — upsampling is
+// linear, channel-wise and its weights sum to one — so conv(u) = (conv_w . from_lat_w) * upsample(z) + a bias term, a convolution with Cv = 8
+// (<= 16) input channels instead of 64: ONE slab of 27 taps instead of four, a quarter of the MFMAs (the composite weights are built once per
+// parameter version by the host; the input image holds upsample(z) in rows of 96 B = [plane][16 ch]).  The from_lat bias reaches an output
+// voxel through the taps that fall inside the volume only (the conv zero-pads u, not from_lat's bias): a table per border class, added in
+// the epilogue.  Same operator up to fp32 rounding (fewer roundings than the reference's order: u is never rounded).
+template <int TERMS, int NSLAB = 4>     // TERMS 6: bf16x3; 3: f16x2 (planes h, l of the same buffers; the third plane is neither moved nor read)
 __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
     using Cf = HaloCfg<TERMS>;
     constexpr int NPL = Cf::NPL, TH = Cf::TH, HH = Cf::HH, TM = Cf::TM, NCH = Cf::NCH, RB = Cf::RB, NWS = Cf::NWS, WST = Cf::WST;
     constexpr bool F16 = TERMS == 3;
-    constexpr int NSTEP = 4 * 27;
+    constexpr bool LAT = NSLAB == 1;
+    constexpr int XROWB = LAT ? L16_ROWB : A3_ROWB, XPLS = LAT ? 32 : 128;      // bytes per voxel / per plane of the input image
+    constexpr int NSTEP = NSLAB * 27;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     unsigned char* halo = smem3;
     unsigned char* wring = smem3 + Cf::HALO_B;
@@ -662,7 +726,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
             hh = hh < Hp ? hh : Hp - 1;
             ww = ww < Wp ? ww : Wp - 1;
             const int64_t pv = (((int64_t)smp * (g.T + 2) + tt) * Hp + hh) * Wp + ww;
-            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(g.X3 + pv * A3_ROWB + (c >> 1) * 128 + slab * 32 + (c & 1) * 16),
+            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(g.X3 + pv * XROWB + (c >> 1) * XPLS + slab * 32 + (c & 1) * 16),
                                              AVD_LDS_PTR(halo + q * 1024), 16, 0, 0);
         }
     };
@@ -747,7 +811,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
         const bool last_tap = ndt == 3;
         if (last_tap) { ndt = 0; ++nslab; }
         const unsigned char* wnext = wring + ((q + 1) % NWS) * WST;
-        if (last_tap && nslab < 4) {
+        if (last_tap && nslab < NSLAB) {
             fill_halo(nslab);
             __builtin_amdgcn_sched_barrier(0);
             mma_step(cur);
@@ -773,7 +837,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
         if (dt == 3) {                           // last tap of the slab: once every wave holds its fragments the tile is refilled
             dt = 0;
             ++slab;
-            if (slab < 4) {
+            if (slab < NSLAB) {
                 __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
                 __builtin_amdgcn_s_barrier();
                 fill_halo(slab);
@@ -785,10 +849,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
     };
     if constexpr (PREFETCH) {
 #pragma unroll 1
-        for (int q = 0; q < NSTEP; q += 2) {
+        for (int q = 0; q + 1 < NSTEP; q += 2) {
             step(q, f0, f1);
             step(q + 1, f1, f0);
         }
+        if constexpr (NSTEP & 1) step(NSTEP - 1, f0, f1);
     } else {
 #pragma unroll 1
         for (int q = 0; q < NSTEP; ++q) step1(q, f0);
@@ -818,6 +883,10 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
             f32x4 y = *reinterpret_cast<const f32x4*>(slab_f + row * CLD + cc);
             if constexpr (F16) y *= ab_inv;
             y += bv;
+            if constexpr (LAT) {      // from_lat's bias through the taps inside the volume (class 63 = interior)
+                const int cls = (tt >= 1) | ((tt <= g.T - 2) << 1) | ((hh >= 1) << 2) | ((hh <= g.H - 2) << 3) | ((ww >= 1) << 4) | ((ww <= g.W - 2) << 5);
+                y += *reinterpret_cast<const f32x4*>(g.btab + cls * VC + cc);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) y[e] = gelu_erf(y[e]);
             if (tt < g.T && hh < g.H && ww < g.W) {
@@ -852,18 +921,36 @@ template <int TERMS> static int conv3_blocks(int T, int H, int W) {
 static int conv3_tiles(int terms, int T, int H, int W) {
     return terms == 3 ? conv3_blocks<3>(T, H, W) * (HaloCfg<3>::VOX / 128) : conv3_blocks<6>(T, H, W) * (HaloCfg<6>::VOX / 128);
 }
-static int conv3_launch(Conv3Args a3, int terms, int B, double flops, hipStream_t st) {
+int g_vae_lat = getenv("AVD_VAE_LAT") ? atoi(getenv("AVD_VAE_LAT")) : 1;      // avd_tune_set "vae_lat": 0 = from_lat -> upsample -> 64-channel first conv
+static LdsAttr g_conv3_lat_attr[2];
+static int conv3_launch(Conv3Args a3, int terms, int B, double flops, hipStream_t st, bool lat = false) {
     a3.tiles = conv3_tiles(terms, a3.T, a3.H, a3.W);
+    if (lat) {
+        AVD_REQUIRE(a3.btab, AVD_EINVAL, "conv3d (latent-composed): null bias table");
+        if (terms == 3) {
+            if (int rc = g_conv3_lat_attr[1].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<3, 1>), HaloCfg<3>::LDS, "conv3d f16x2 (latent)")) return rc;
+            static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<3, 1>");
+            ProfScope prof(tag, flops, st);
+            hipLaunchKernelGGL((conv3d_k3_bf16x3_kernel<3, 1>), dim3((unsigned)(B * conv3_blocks<3>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<3>::LDS, st, a3);
+        } else {
+            if (int rc = g_conv3_lat_attr[0].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<6, 1>), HaloCfg<6>::LDS, "conv3d bf16x3 (latent)")) return rc;
+            static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<6, 1>");
+            ProfScope prof(tag, flops, st);
+            hipLaunchKernelGGL((conv3d_k3_bf16x3_kernel<6, 1>), dim3((unsigned)(B * conv3_blocks<6>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<6>::LDS, st, a3);
+        }
+        AVD_CHECK_LAUNCH("conv3d (latent-composed)");
+        return AVD_OK;
+    }
     if (terms == 3) {
-        if (int rc = g_conv3_attr[1].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<3>), HaloCfg<3>::LDS, "conv3d f16x2")) return rc;
-        static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<3>");
+        if (int rc = g_conv3_attr[1].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<3, 4>), HaloCfg<3>::LDS, "conv3d f16x2")) return rc;
+        static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<3, 4>");
         ProfScope prof(tag, flops, st);
-        hipLaunchKernelGGL(conv3d_k3_bf16x3_kernel<3>, dim3((unsigned)(B * conv3_blocks<3>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<3>::LDS, st, a3);
+        hipLaunchKernelGGL((conv3d_k3_bf16x3_kernel<3, 4>), dim3((unsigned)(B * conv3_blocks<3>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<3>::LDS, st, a3);
     } else {
-        if (int rc = g_conv3_attr[0].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<6>), HaloCfg<6>::LDS, "conv3d bf16x3")) return rc;
-        static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<6>");
+        if (int rc = g_conv3_attr[0].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<6, 4>), HaloCfg<6>::LDS, "conv3d bf16x3")) return rc;
+        static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<6, 4>");
         ProfScope prof(tag, flops, st);
-        hipLaunchKernelGGL(conv3d_k3_bf16x3_kernel<6>, dim3((unsigned)(B * conv3_blocks<6>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<6>::LDS, st, a3);
+        hipLaunchKernelGGL((conv3d_k3_bf16x3_kernel<6, 4>), dim3((unsigned)(B * conv3_blocks<6>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<6>::LDS, st, a3);
     }
     AVD_CHECK_LAUNCH("conv3d (split operands)");
     return AVD_OK;
@@ -964,6 +1051,30 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
         for (int blk = 0; blk < d->n_blocks; ++blk) AVD_REQUIRE(d->conv_w3[blk], AVD_EINVAL, "vae_decode: null conv_w3[%d]", blk);
         if (int rc = check_conv_terms(d->conv_terms, d->conv_w_scale, d->conv_a_scale, d->n_blocks, 0, true)) return rc;
     }
+    // latent-composed first convolution (conv3d_k3_bf16x3_kernel<.., 1>): its input image is upsample(z), 96 B per voxel
+    const bool lat = s3 && d->conv0_lat_w3 != nullptr && g_vae_lat;
+    if (lat) {
+        AVD_REQUIRE(d->conv0_lat_btab && d->Cv <= 16, AVD_EINVAL, "vae_decode: the latent-composed first conv needs its bias table and Cv <= 16");
+        AVD_REQUIRE(!h2 || (d->conv0_lat_w_scale > 0.f && d->conv0_lat_w_scale < __builtin_inff()), AVD_EINVAL,
+                    "vae_decode: conv0_lat_w_scale must be positive and finite");
+        if (int rc = zero_halo(Xp, B, p.T, p.H, p.W, L16_ROWB, st)) return rc;
+        if (h2) {   // |upsample(z)| <= max |z| (a convex combination): the image scale is derived from the data on the device
+            if (int rc = weight_bounds_f32(z, (int64_t)B * d->Cv, d->Tp * d->Hp * d->Wp, scale_ws, st)) return rc;
+            hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, st, scale_ws);
+            AVD_CHECK_LAUNCH("pow2_scale");
+        }
+        const int64_t nvox = (int64_t)B * p.THW;
+        static const int tag = prof_tag_id("upsample_lat16_kernel");
+        ProfScope prof(tag, (double)nvox * L16_ROWB, st);
+        const float fst = (float)d->Tp / (float)p.T, fsh = (float)d->Hp / (float)p.H, fsw = (float)d->Wp / (float)p.W;
+        if (h2)
+            hipLaunchKernelGGL(upsample_lat16_kernel<true>, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, z, X3, d->Cv, d->Tp, d->Hp, d->Wp,
+                               p.T, p.H, p.W, fst, fsh, fsw, nvox, scale_ws + 2);
+        else
+            hipLaunchKernelGGL(upsample_lat16_kernel<false>, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, z, X3, d->Cv, d->Tp, d->Hp, d->Wp,
+                               p.T, p.H, p.W, fst, fsh, fsw, nvox, nullptr);
+        AVD_CHECK_LAUNCH("upsample_lat16");
+    } else {
     // zero halo (interiors are overwritten below by the upsample / GroupNorm-apply passes, the halo stays zero for every conv)
     if (int rc = zero_halo(Xp, B, p.T, p.H, p.W, s3 ? A3_ROWB : VC * 4, st)) return rc;
     {   // from_lat on the latent grid, then trilinear upsample into the padded conv input
@@ -1004,19 +1115,25 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
                            (float)d->Wp / (float)p.W, total4);
         AVD_CHECK_LAUNCH("upsample_pad");
     }
+    }       // (!lat)
     constexpr int stage_lds = 2 * (VBM + VC) * VBK * 4, epi_lds = 4 * 64 * 36 * 4;
     constexpr int lds = stage_lds > epi_lds ? stage_lds : epi_lds;
     for (int blk = 0; blk < d->n_blocks; ++blk) {
         ConvArgs a{Xp, d->conv_w[blk], d->conv_b[blk], Y, part, p.T, p.H, p.W, p.tiles};
         int gn_tiles = p.tiles;           // partials entries / 2 the conv of this block writes (the halo-tile kernel has its own tiling)
         if (s3) {
-            Conv3Args a3{X3, static_cast<const unsigned char*>(d->conv_w3[blk]), d->conv_b[blk], Y, part, p.T, p.H, p.W, p.tiles, 1.f, nullptr};
+            const bool lat0 = lat && blk == 0;
+            Conv3Args a3{X3, static_cast<const unsigned char*>(lat0 ? d->conv0_lat_w3 : d->conv_w3[blk]), d->conv_b[blk], Y, part, p.T, p.H, p.W, p.tiles,
+                         1.f, nullptr, lat0 ? d->conv0_lat_btab : nullptr};
             if (h2) {
-                a3.ab_inv = blk == 0 ? 1.0f / d->conv_w_scale[0] : 1.0f / (d->conv_w_scale[blk] * d->conv_a_scale[blk]);
+                a3.ab_inv = blk == 0 ? 1.0f / (lat0 ? d->conv0_lat_w_scale : d->conv_w_scale[0]) : 1.0f / (d->conv_w_scale[blk] * d->conv_a_scale[blk]);
                 a3.a_inv_dev = blk == 0 ? scale_ws + 3 : nullptr;
             }
-            if (int rc = conv3_launch(a3, h2 ? 3 : 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st)) return rc;
+            if (int rc = conv3_launch(a3, h2 ? 3 : 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * (lat0 ? 16 : VC), st, lat0)) return rc;
             gn_tiles = conv3_tiles(h2 ? 3 : 6, p.T, p.H, p.W);
+            // the act3 buffer of the next conv overlays the latent image: its halo is zeroed now that conv 0 has read the latent image
+            if (lat0 && blk + 1 < d->n_blocks)
+                if (int rc = zero_halo(Xp, B, p.T, p.H, p.W, A3_ROWB, st)) return rc;
         } else {
             static const int tag = prof_tag_id("conv3d_k3_gelu_stats_kernel<64>");
             ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st);

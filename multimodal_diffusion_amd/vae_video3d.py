@@ -77,6 +77,9 @@ class VideoVAE(nn.Module):
         # exactly split operands; "f16x2": the same convolutions with two scaled fp16 planes per operand and three product terms
         # (csrc/vae3d_f32.hip)
         self.matmul = "auto"
+        # split-operand modes: run the first decoder convolution on upsample(z) with composite weights (8 input channels instead of 64;
+        # _lat_composite) instead of from_lat -> upsample -> 64-channel convolution.  Same operator up to fp32 rounding.
+        self.lat_composed = True
 
     @classmethod
     def from_config(cls, d: Dict) -> "VideoVAE":
@@ -243,6 +246,48 @@ class VideoVAE(nn.Module):
             d.conv_w_scale = C.cast(ws, C.POINTER(C.c_float))
             d.conv_a_scale = C.cast(as_, C.POINTER(C.c_float))
 
+    def _lat_composite(self, f16x2: bool):
+        """The decoder's FIRST convolution composed with from_lat and the trilinear upsample (vae_video3d.py:205-209).  Upsampling is linear,
+        acts per channel and its weights sum to one, so dec_net.0.0(upsample(from_lat(z))) = (W1 . Wf) * upsample(z) + bias terms: a
+        convolution with lat_ch (<= 16) input channels instead of dec_base = 64 — a quarter of the matrix work of that layer.  Returns
+        (weight image of the composite [out][kt][kh][kw][in] with in >= lat_ch zero, bias table [64 border classes][out], image scale):
+        the conv zero-pads from_lat's OUTPUT, so from_lat's bias reaches a voxel only through the taps inside the volume — one table row
+        per combination of (t-1, t+1, h-1, h+1, w-1, w+1 inside).  Composed in fp64, rounded to fp32 once; rebuilt when a parameter changes."""
+        w1, wf, bf = self.dec_net[0][0].weight, self.from_lat.weight, self.from_lat.bias
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in (w1, wf, bf)) + (f16x2,)
+        hit = self._conv3.get(("lat", f16x2))
+        if hit is None or hit[0] != key:
+            D, Cv = self.cfg.dec_base, self.cfg.lat_ch
+            W1 = w1.detach().double()                                          # [out, c, kt, kh, kw]
+            Wf = wf.detach().double().reshape(D, Cv)                           # [c, in]
+            comp = torch.einsum("octhw,ci->othwi", W1, Wf)                     # [out, kt, kh, kw, in]
+            src = torch.zeros(D, 3, 3, 3, D, device=w1.device, dtype=torch.float32)
+            src[..., :Cv] = comp.float()
+            bt = torch.einsum("octhw,c->othw", W1, bf.detach().double())       # [out, kt, kh, kw]: bias through one tap
+            tab = torch.zeros(64, D, device=w1.device, dtype=torch.float64)
+            for cls in range(64):
+                ok = [[True] * 3 for _ in range(3)]                            # per dim: taps -1, 0, +1 allowed
+                for dim in range(3):
+                    ok[dim][0] = bool((cls >> (2 * dim)) & 1)
+                    ok[dim][2] = bool((cls >> (2 * dim + 1)) & 1)
+                mt = torch.tensor(ok[0], device=w1.device, dtype=torch.float64)
+                mh = torch.tensor(ok[1], device=w1.device, dtype=torch.float64)
+                mw = torch.tensor(ok[2], device=w1.device, dtype=torch.float64)
+                tab[cls] = torch.einsum("othw,t,h,w->o", bt, mt, mh, mw)
+            tab = tab.float().contiguous()
+            img = torch.empty(L.lib().avd_conv3_weight_bytes(), dtype=torch.uint8, device=w1.device)
+            src = src.contiguous()
+            scale = 0.0
+            if f16x2:
+                from . import functional as Fn
+                scale = Fn.f16x2_scale(Fn.weight_bounds([src.reshape(D, -1)])[0][0])
+                L.check(L.lib().avd_conv3_weight_f16x2_f32(src.data_ptr(), img.data_ptr(), scale, L.stream_ptr(w1.device)))
+            else:
+                L.check(L.lib().avd_conv3_weight_f32(src.data_ptr(), img.data_ptr(), L.stream_ptr(w1.device)))
+            self._conv3[("lat", f16x2)] = (key, img, tab, scale)
+        hit = self._conv3[("lat", f16x2)]
+        return hit[1], hit[2], hit[3]
+
     def _tap_major(self, i: int) -> torch.Tensor:
         w = self.dec_net[i][0].weight
         key = (i, w.data_ptr(), w._version, str(w.device))
@@ -290,6 +335,10 @@ class VideoVAE(nn.Module):
             raise ValueError(f"matmul must be 'auto', 'f32', 'bf16x3' or 'f16x2', got {self.matmul!r}")
         if self.matmul != "f32":
             self._split_conv_desc(d, keep, nb, 0, False, (self.cfg.dec_base // 8) * T * H * W)
+            if self.lat_composed and Cv <= 16 and self.cfg.dec_base == 64:
+                img, tab, sc = self._lat_composite(self.matmul == "f16x2")
+                keep.extend([img, tab])
+                d.conv0_lat_w3, d.conv0_lat_btab, d.conv0_lat_w_scale = img.data_ptr(), tab.data_ptr(), float(sc) if sc else 1.0
         # chunk the batch so the NDHWC activations (2 x 0.85 GB per 48x256x256 sample) stay inside the budget
         d.B = 1
         per = L.lib().avd_vae_decode_workspace_bytes(C.byref(d))

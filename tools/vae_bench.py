@@ -16,11 +16,13 @@ ap.add_argument("--size", type=int, default=256)
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--matmul", default="f32", choices=["f32", "bf16x3", "f16x2"])
+ap.add_argument("--lat", type=int, default=1, help="0: from_lat -> upsample -> 64-channel first conv (rounds 1-4); 1: the latent-composed first conv")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval().to(dev)
 vae.matmul = args.matmul
+vae.lat_composed = bool(args.lat)
 z = torch.randn(args.batch, 8, 12, args.size // 8, args.size // 8, device=dev)
 for _ in range(2):
     x = vae.decode(z)
@@ -32,7 +34,7 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / args.iters
 vox = args.batch * 48 * args.size * args.size
 fl = 2 * 2.0 * vox * 64 * 27 * 64
-print(f"[{args.matmul}] decode B={args.batch} {args.size}x{args.size}: {dt*1e3:.2f} ms  ({fl/dt/1e12:.1f} TFLOP/s on the two 3x3x3 convs), "
+print(f"[{args.matmul}{'' if args.lat else ', lat 0'}] decode B={args.batch} {args.size}x{args.size}: {dt*1e3:.2f} ms  ({fl/dt/1e12:.1f} TFLOP/s counting the reference's two 64-channel 3x3x3 convs), "
       f"out {tuple(x.shape)} finite={bool(torch.isfinite(x).all())}")
 L.prof_enable(True)
 vae.decode(z)
