@@ -1053,13 +1053,14 @@ def test_cfg_unpatch_ddim_row_form_is_bit_identical(dev, B, C, T, H, W, eta):
     tp = torch.tensor([966, 480, -1, 979, -1][:B])
     abar = R.alpha_bar_table(R.beta_table(1000))
     outs = {}
+    d_eps, d_z, d_tn, d_tp, d_ab = eps2.to(dev), z.to(dev), tn.to(dev), tp.to(dev), abar.to(dev)     # (kept alive across the launches)
+    d_noise = None if noise is None else noise.to(dev)
     for rows in (0, 1):
         _tune("cfg_rows", rows)
         try:
             out = torch.empty(B, C, T, H, W, device=dev)
-            L.check(L.lib().avd_cfg_unpatch_ddim_f32(eps2.to(dev).data_ptr(), z.to(dev).data_ptr(), tn.to(dev).data_ptr(), tp.to(dev).data_ptr(),
-                                                     abar.to(dev).data_ptr(), 1000, 3.5, eta, L.ptr(None if noise is None else noise.to(dev)),
-                                                     out.data_ptr(), B, C, T, H, W, 2, 4, 4, L.stream_ptr(dev)))
+            L.check(L.lib().avd_cfg_unpatch_ddim_f32(d_eps.data_ptr(), d_z.data_ptr(), d_tn.data_ptr(), d_tp.data_ptr(), d_ab.data_ptr(), 1000, 3.5,
+                                                     eta, L.ptr(d_noise), out.data_ptr(), B, C, T, H, W, 2, 4, 4, L.stream_ptr(dev)))
             torch.cuda.synchronize()
             outs[rows] = out.cpu()
         finally:

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Everything the round's measurement record is built from, in one GPU-box call (run from the repo root):
-#   bash tools/profile_round.sh r04
+#   bash tools/profile_round.sh r05
 # Output under gpurun_out/<tag>/; tools/collect_profiles.py copies the judged summaries into profiles/.
 # Every long step appends to a file under gpurun_out/ (gpurun kills a call that writes nothing for 7 minutes).
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
@@ -33,19 +33,15 @@ $B --size 128 --batch 8 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OU
 $B --batch 8 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_c3_b8.json 2>> $OUT/bench.err || exit 1
 $B --size 32 --batch 4 --steps 200 --warmup 20 --no-alt --cpu-steps 3 --matmul f32 > $OUT/bench_c1_gpu.json 2>> $OUT/bench.err || exit 1
 
-step "round-4 A/B lines (tune keys through the environment)"
+step "round-5 A/B lines (tune keys through the environment)"
 AB="$B --no-alt --no-cpu-baseline --steps 40 --warmup 5"
-AVD_MLP_FUSED=1 $AB > $OUT/bench_ab_mlp_fused.json 2>> $OUT/bench.err || exit 1          # fc1 -> GELU -> fc2 as one launch
-AVD_ATTN_PIPE=0 $AB > $OUT/bench_ab_attn_plain.json 2>> $OUT/bench.err || exit 1         # the round-3 attention kernel
-AVD_CORE_TRIM=0 $AB > $OUT/bench_ab_notrim.json 2>> $OUT/bench.err || exit 1             # last block on every row
+AVD_ATTN_M16=0 $AB > $OUT/bench_ab_attn_32x32.json 2>> $OUT/bench.err || exit 1          # the 32x32x16 attention pipeline (round 4's shape, peeled)
+AVD_ATTN_M16=0 AVD_ATTN_PIPE=0 $AB > $OUT/bench_ab_attn_plain.json 2>> $OUT/bench.err || exit 1   # the round-3 attention kernel
+AVD_S3_SN=16 AVD_S3_SUPER4=32 $AB > $OUT/bench_ab_supertile_r4.json 2>> $OUT/bench.err || exit 1   # rounds 2-4's block order: 2 block rows x all columns
+AVD_CFG_ROWS=0 $AB > $OUT/bench_ab_cfg_gather.json 2>> $OUT/bench.err || exit 1          # CFG + un-patch + DDIM as one 16-byte gather per lane
+AVD_MLP_FUSED=1 $AB > $OUT/bench_ab_mlp_fused.json 2>> $OUT/bench.err || exit 1          # fc1 -> GELU -> fc2 as one launch (round 4; kept as a record)
 $AB > $OUT/bench_ab_default.json 2>> $OUT/bench.err || exit 1                            # the default, same flags, right after
-AVD_CORE_TRIM=0 $B --size 128 --batch 32 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_ab_128_notrim.json 2>> $OUT/bench.err || exit 1
-# mid-size batches: 256-row blocks on the two-stage ring everywhere (round 3), and the round-3 row threshold of the split path
-AVD_S3_RT4=8 AVD_S3_DEEP4=0 $B --size 128 --batch 32 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_ab_128_rt8.json 2>> $OUT/bench.err || exit 1
-AVD_S3_DEEP4=0 $B --size 128 --batch 32 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_ab_128_nodeep.json 2>> $OUT/bench.err || exit 1
-AVD_S3_MIN_ROWS=6144 $B $C2 --no-cpu-baseline > $OUT/bench_ab_c2_minrows6144.json 2>> $OUT/bench.err || exit 1
-AVD_S3_MIN_ROWS=6144 $B --size 128 --batch 8 --steps 100 --warmup 10 --no-alt --no-cpu-baseline > $OUT/bench_ab_128_b8_minrows6144.json 2>> $OUT/bench.err || exit 1
-AVD_GEMM_SPLITK=0 $B --size 32 --batch 4 --steps 200 --warmup 20 --no-alt --no-cpu-baseline --matmul f32 > $OUT/bench_ab_c1_nosplitk.json 2>> $OUT/bench.err || exit 1
+AVD_ATTN_M16=0 $B $C5 --no-cpu-baseline > $OUT/bench_ab_c5_attn_32x32.json 2>> $OUT/bench.err || exit 1
 
 step "rocprofv3 kernel traces"
 prof() { name=$1; shift; (cd /tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o run -- python3 "$@" > $OUT/prof_$name.log 2>&1) || exit 1; step "  traced $name"; }
@@ -78,16 +74,21 @@ timeout -k 10 400 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2
     --backend gloo --share-device --no-alt --verify-ranks > $OUT/bench_n2.out 2> $OUT/bench_n2.err || exit 1
 grep '^{' $OUT/bench_n2.out > $OUT/bench_n2_gloo_rehearsal.json || exit 1
 
+step "per-kernel clock / power, block phases of fc1 / in_proj, L2 counters"
+timeout -k 10 300 python3 tools/micro/kernel_power.py > $OUT/kernel_power.txt 2>&1 || echo "kernel_power failed"
+timeout -k 10 400 python3 tools/pmc_counters.py --out gpurun_out/$TAG/l2_counters_bf16x3.json --sets "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" > $OUT/l2_counters_bf16x3.txt 2>&1 || echo "l2 counters failed"
+timeout -k 10 500 python3 tools/micro/s3_phase.py > $OUT/s3_phase.txt 2>&1 || echo "s3_phase failed"
 step "K sweep + in-kernel stamps of the split GEMMs"
 timeout -k 10 300 python3 tools/micro/s3_ksweep.py > $OUT/s3_ksweep.txt 2>&1 || echo "ksweep failed"
-timeout -k 10 400 python3 tools/micro/s3_stamps.py --build > $OUT/s3_stamps.txt 2>&1 || echo "stamps failed"
+timeout -k 10 400 python3 tools/micro/s3_stamps.py > $OUT/s3_stamps.txt 2>&1 || echo "stamps failed"
 for v in AVD_LAB_NODMA AVD_LAB_NOLDS AVD_LAB_NOSTORE; do
     echo "== variant $v (diagnostic build, wrong results by design)" >> $OUT/s3_stamps.txt
-    timeout -k 10 400 python3 tools/micro/s3_stamps.py --build --modes bf16x3,f16x2 --variant $v >> $OUT/s3_stamps.txt 2>&1 || echo "stamps $v failed"
+    timeout -k 10 400 python3 tools/micro/s3_stamps.py --modes bf16x3,f16x2 --variant $v >> $OUT/s3_stamps.txt 2>&1 || echo "stamps $v failed"
 done
 
 step "VAE decode timings, end to end, soak"
 for m in f32 bf16x3 f16x2; do timeout -k 10 200 python3 tools/vae_bench.py --matmul $m 2>&1 | grep -v amdgpu.ids >> $OUT/vae_decode.txt; done
+for m in bf16x3 f16x2; do timeout -k 10 200 python3 tools/vae_bench.py --matmul $m --lat 0 2>&1 | grep -v amdgpu.ids >> $OUT/vae_decode.txt; done      # rounds 1-4: 64-channel first conv
 timeout -k 10 200 python3 tools/vae_bench.py --matmul f16x2 --batch 8 2>&1 | grep -v amdgpu.ids >> $OUT/vae_decode.txt
 timeout -k 10 600 python3 tools/e2e_bench.py > $OUT/e2e.txt 2>&1 || echo "e2e failed"
 step "  e2e done"
