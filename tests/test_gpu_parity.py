@@ -991,6 +991,44 @@ def test_vae_decode_bf16x3(dev):
     assert errs["bf16x3"] < TOL and errs["bf16x3"] < 2.0 * errs["f32"] + 1e-7, errs
 
 
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_vae_decode_latent_composed_first_conv(dev, mode):
+    """Round 5: in the split-operand modes the decoder's first convolution runs on upsample(z) with composite weights (from_lat folded
+    into dec_net.0.0: 8 input channels instead of 64, one 16-channel slab of 27 taps; from_lat's bias through a border-class table —
+    VideoVAE._lat_composite, conv3d_k3_bf16x3_kernel<.., 1>).  Same operator as from_lat -> upsample -> 64-channel conv up to fp32
+    rounding: against that route (lat_composed = False), against the golden fixture (also the ragged output size, whose border voxels
+    take the border rows of the bias table) and against the fp64 oracle on a decoder with a large from_lat bias."""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd import _lib as L
+    g = load_golden("g11_vae_decode.npz")
+    outs = {}
+    for lat in (False, True):
+        vae = _vae_from(split_weights(g)["w"], dev)
+        vae.matmul, vae.lat_composed = mode, lat
+        L.prof_enable(True)
+        x = vae.decode(G(g["z"], dev)).cpu()
+        torch.cuda.synchronize()
+        L.prof_enable(False)
+        used = {k for k, v in L.prof_report().items() if v[0] > 0}
+        assert any(k.endswith(", 1>") and k.startswith("conv3d_k3_bf16x3_kernel") for k in used) == lat, used
+        assert ("upsample_lat16_kernel" in used) == lat and ("fromlat_kernel" in used) == (not lat), used
+        outs[lat] = (x, vae.decode(G(g["z"][:1], dev), out_size=(6, 24, 40)).cpu())
+    assert rel_err(outs[True][0], g["x"]) < TOL and rel_err(outs[True][1], g["x_odd"]) < TOL
+    assert rel_err(outs[True][0], outs[False][0]) < 2e-5 and rel_err(outs[True][1], outs[False][1]) < 2e-5
+    # a decoder whose from_lat bias dominates: the border table carries real weight (tiny volume: every voxel class occurs)
+    W = R.synth_vae_decoder(seed=5, n_blocks=2)
+    W["from_lat.bias"] = W["from_lat.bias"] * 0 + torch.linspace(-3.0, 3.0, 64)
+    z = torch.randn(2, 8, 1, 2, 3, generator=torch.Generator().manual_seed(6))
+    ref = R.vae_decode(z.double(), {k: v.double() for k, v in W.items()}, n_blocks=2)
+    errs = {}
+    for lat in (False, True):
+        v = A.VideoVAE(A.VideoVAEConfig(dec_blocks=2)).eval()
+        v.load_state_dict(W, strict=False)
+        v.matmul, v.lat_composed = mode, lat
+        errs[lat] = rel_err(v.to(dev).decode(z.to(dev)).cpu(), ref)
+    assert errs[True] < TOL and errs[True] < 2.0 * errs[False] + 1e-6, errs
+
+
 def test_vae_encode_bf16x3(dev):
     """Encoder with its 64 -> 64 convolution(s) on the bf16x3 path: golden fixture at the fp32 encoder's tolerance."""
     import warnings
