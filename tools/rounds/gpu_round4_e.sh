@@ -8,7 +8,7 @@ echo "[$(date +%T)] pytest fused MLP"
 timeout -k 10 600 python3 -m pytest tests -m gpu -q -x -s -k "fused_mlp" > $OUT/pytest_mlp.log 2>&1 || { tail -40 $OUT/pytest_mlp.log; echo FUSED-MLP-TEST-FAILED; }
 grep -E "fused MLP|passed|failed" $OUT/pytest_mlp.log | tail -5
 echo "[$(date +%T)] pytest subset"
-timeout -k 10 900 python3 -m pytest tests -m gpu -q -x -k "last_block or block_rows or splitk or shipped or full_step_c3 or tile_configurations or chain or default_mode" > $OUT/pytest.log 2>&1 || { tail -40 $OUT/pytest.log; exit 1; }
+timeout -k 10 900 python3 -m pytest tests -m gpu -q -x -k "last_block or block_rows or splitk or shipped or full_step_c3 or tile_configurations or chain or default_mode" > $OUT/pytest.log 2>&1 || { tail -40 $OUT/pytest.log; exit 1; echo "pytest failed: no bench lines from a failing tree"; exit 1; }
 tail -3 $OUT/pytest.log
 B="timeout -k 10 300 python3 bench.py --no-alt --no-cpu-baseline"
 for p in 0 1; do

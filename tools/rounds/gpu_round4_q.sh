@@ -8,6 +8,9 @@ export TMPDIR=/tmp
 C=multimodal_diffusion_amd/csrc
 echo "[$(date +%T)] default build"
 timeout -k 10 200 python3 tools/vae_bench.py --matmul bf16x3 2>&1 | grep -v amdgpu.ids | tee $OUT/vae_default.txt
+# the diagnostic build edits a tracked source and relinks the product library: both are restored when the script ends, however it ends
+cp $C/vae3d_f32.hip $OUT/vae3d_f32.hip.orig && cp $C/libavdiff_hip.so $OUT/libavdiff_hip.so.orig && cp $C/vae3d_f32.o $OUT/vae3d_f32.o.orig || exit 1
+trap 'cp $OUT/vae3d_f32.hip.orig $C/vae3d_f32.hip; cp $OUT/vae3d_f32.o.orig $C/vae3d_f32.o; cp $OUT/libavdiff_hip.so.orig $C/libavdiff_hip.so; rm -f $OUT/*.orig' EXIT
 echo "[$(date +%T)] rebuild vae3d_f32.o with TH = 8 for three planes, one block per CU (edits the box's scratch copy only)"
 sed -i 's/static constexpr int TH = NPL == 2 ? 8 : 4, HH = TH + 2;/static constexpr int TH = 8, HH = TH + 2;/; s/__global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel/__global__ __launch_bounds__(256, TERMS == 3 ? 2 : 1) void conv3d_k3_bf16x3_kernel/' $C/vae3d_f32.hip
 grep -c "static constexpr int TH = 8, HH" $C/vae3d_f32.hip || exit 1
