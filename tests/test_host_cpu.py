@@ -19,10 +19,12 @@ def test_documented_tune_keys_are_accepted():
     header = (ROOT / "include" / "avdiff_hip.h").read_text()
     block = header[header.index("Measurement / test hooks"):header.index("int         avd_tune_set")]
     keys = sorted(set(re.findall(r'"([a-z0-9_]+)"', block)))
-    assert {"gemm_tile", "gemm_stages", "s3_tile", "s3_stagger", "s3_min_rows", "no_fold", "s3_m16", "s3_rt", "s3_rt4", "s3_deep4", "s3_w128", "s3_splitk", "attn_pipe", "core_trim", "mlp_fused", "gemm_splitk"} <= set(keys)
+    assert {"gemm_tile", "gemm_stages", "s3_tile", "s3_stagger", "s3_min_rows", "no_fold", "s3_m16", "s3_rt", "s3_rt4", "s3_deep4", "s3_w128", "s3_splitk", "attn_pipe", "core_trim", "mlp_fused", "gemm_splitk",
+            "attn_m16", "cfg_rows", "vae_lat", "s3_sn", "s3_super4", "s3_super8"} <= set(keys)
     lib = L.lib()
     defaults = {"gemm_tile": -1, "gemm_stages": 0, "s3_tile": -1, "s3_stagger": -1, "s3_min_rows": -1, "no_fold": 0, "s3_m16": 1,
-                "s3_rt": 0, "s3_rt4": 0, "s3_deep4": 1, "s3_w128": 1, "s3_splitk": 4, "attn_pipe": 1, "core_trim": 1, "mlp_fused": 0, "gemm_splitk": 4}
+                "s3_rt": 0, "s3_rt4": 0, "s3_deep4": 1, "s3_w128": 1, "s3_splitk": 4, "attn_pipe": 1, "core_trim": 1, "mlp_fused": 0, "gemm_splitk": 4,
+                "attn_m16": 1, "cfg_rows": 1, "vae_lat": 1, "s3_sn": 0, "s3_super4": 0, "s3_super8": 0}
     for k in keys:
         assert lib.avd_tune_set(k.encode(), defaults[k]) == 0, k
     assert lib.avd_tune_set(b"no_such_knob", 1) != 0
@@ -219,7 +221,8 @@ def test_checkpoint_interop(tmp_path, small_model):
 def test_agpr_hazard_lint_on_synthetic_listings(tmp_path):
     """tools/check_agpr_hazards.py (run by build() on the two kernels whose MFMAs are asm statements): an AGPR read one slot behind the
     asm-statement MFMA that wrote it fails the lint; the same read behind the kernels' `s_nop 15` pair passes; an MFMA the compiler
-    emitted itself (outside ASMSTART / ASMEND: its hazard recogniser pads it) is not counted."""
+    emitted itself (outside ASMSTART / ASMEND: its hazard recogniser pads it) is not counted — and a listing with NO asm-statement MFMA at all
+    is refused (round 5, ADVICE r4: the files handed to the lint are expected to hold such MFMAs; finding none means it looked at nothing)."""
     import subprocess
     import sys
     tool = str(ROOT / "tools" / "check_agpr_hazards.py")
@@ -229,7 +232,7 @@ def test_agpr_hazard_lint_on_synthetic_listings(tmp_path):
     good = head + mfma.replace("a[4:7]\n\t;;#ASMEND", "a[4:7]\n\ts_nop 15\n\ts_nop 15\n\t;;#ASMEND") + "\tv_accvgpr_read_b32 v9, a5\n"
     own = head + "\tv_mfma_f32_16x16x32_bf16 a[4:7], v[0:3], v[4:7], a[4:7]\n\tv_accvgpr_read_b32 v9, a5\n"
     other = head + mfma + "\tv_accvgpr_read_b32 v9, a9\n"          # a different register: no dependence
-    for name, text, rc, word in (("bad", bad, 1, "FAIL"), ("good", good, 0, "ok"), ("own", own, 0, ""), ("other", other, 0, "")):
+    for name, text, rc, word in (("bad", bad, 1, "FAIL"), ("good", good, 0, "ok"), ("own", own, 2, "nothing to check"), ("other", other, 0, "")):
         f = tmp_path / f"{name}.s"
         f.write_text(text)
         r = subprocess.run([sys.executable, tool, str(f)], capture_output=True, text=True)
