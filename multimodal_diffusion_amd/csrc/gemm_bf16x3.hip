@@ -1060,22 +1060,66 @@ __global__ __launch_bounds__(WAVES * 64, 2) void gemm_bf16x3_m16_kernel(S3Args g
                     if (s * PER + q < PPW) { S3_SB(); issue_piece(s * PER + q, kt + NST - 1, dbuf); S3_SB(); }
             }
         };
-        bf16x8 ahl[8], ahm[8], bx[4], by[4];
+        bf16x8 ahl[8], bx[4], by[4];
         S3_SB();
         lda(ahl, st, T_HL);
         ldb(bx, st, T_LH);                       // [l|h]
         slot(0);                                  // the first DMA pieces are issued while those reads are in flight
+#ifndef AVD_LAB_HALFREAD
+        bf16x8 ahm[8];
         lda(ahm, st, T_HM);
+#else       // diagnostic build (round 5, tools/rounds/r5_j.sh): correct results, measured neutral — DESIGN.md 4.4
+        // [h|m] shares its lower 32 lanes (the h plane) with [h|l]: once a row-tile pair's hl + lh MFMAs are through, only the upper 32
+        // lanes are read again, from the m plane, into the same registers — 12 instead of 16 fragment reads' worth of LDS bytes per step,
+        // and 32 fragment registers fewer.  The masked reads are asm (exec is narrowed and restored inside one statement, so the block is
+        // not split and the sched_barrier slots hold); the compiler does not count them, so the waits before hm + mh are written out:
+        // what may still be in flight is the later pairs' reads and the four [h|m] W reads behind them.
+        bf16x8 (&ahm)[8] = ahl;
+        const unsigned am_e = (unsigned)(uintptr_t)AVD_LDS_PTR(st + a_uni + abase_e + PSA), am_o = (unsigned)(uintptr_t)AVD_LDS_PTR(st + a_uni + abase_o + PSA);
+        auto upm = [&](auto i0_tag) {
+            constexpr int I0 = decltype(i0_tag)::value;
+            if constexpr (I0 + 1 < RT) {
+                asm volatile("s_mov_b64 exec, %[m]\n\tds_read_b128 %[d0], %[a0] offset:%[o0]\n\tds_read_b128 %[d1], %[a1] offset:%[o1]\n\ts_mov_b64 exec, -1"
+                             : [d0] "+v"(ahl[I0]), [d1] "+v"(ahl[I0 + 1])
+                             : [a0] "v"(am_e), [a1] "v"(am_o), [o0] "n"(I0 * 512), [o1] "n"((I0 + 1) * 512), [m] "s"(0xFFFFFFFF00000000ull) : "memory");
+            } else if constexpr (I0 < RT) {
+                asm volatile("s_mov_b64 exec, %[m]\n\tds_read_b128 %[d0], %[a0] offset:%[o0]\n\ts_mov_b64 exec, -1"
+                             : [d0] "+v"(ahl[I0]) : [a0] "v"(am_e), [o0] "n"(I0 * 512), [m] "s"(0xFFFFFFFF00000000ull) : "memory");
+            }
+        };
+        auto upm_wait = [&](auto i0_tag) {          // row tiles I0, I0 + 1 carry [h|m]
+            constexpr int I0 = decltype(i0_tag)::value;
+            constexpr int later = (RT < 8 ? RT : 8) - (I0 + 2);
+            // (the fragments are operands: the MFMAs that read them cannot be scheduled above the wait)
+            if constexpr (I0 + 1 < RT) asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(ahl[I0]), "+v"(ahl[I0 + 1]) : "n"((later > 0 ? later : 0) + 4) : "memory");
+            else if constexpr (I0 < RT) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(ahl[I0]) : "n"((later > 0 ? later : 0) + 4) : "memory");
+        };
+        using I0T = std::integral_constant<int, 0>; using I2T = std::integral_constant<int, 2>;
+        using I4T = std::integral_constant<int, 4>; using I6T = std::integral_constant<int, 6>;
+#endif
         ldb(by, st, T_MH);                       // [m|h]
         S3_SB();
+#ifndef AVD_LAB_HALFREAD
         mm(ahl, bx, 0, 2); slot(1); S3_SB();     // hl + lh
         mm(ahl, bx, 2, 4); slot(2); S3_SB();
         mm(ahl, bx, 4, 6); slot(3); S3_SB();
         mm(ahl, bx, 6, 8); slot(4); ldb(bx, st, T_HM); S3_SB();       // [h|m] into the dead [l|h] registers
+#else
+        mm(ahl, bx, 0, 2); slot(1); upm(I0T{}); S3_SB();     // hl + lh
+        mm(ahl, bx, 2, 4); slot(2); upm(I2T{}); S3_SB();
+        mm(ahl, bx, 4, 6); slot(3); upm(I4T{}); S3_SB();
+        mm(ahl, bx, 6, 8); slot(4); upm(I6T{}); ldb(bx, st, T_HM); S3_SB();       // [h|m] into the dead [l|h] registers
+        upm_wait(I0T{}); mm(ahm, by, 0, 2); slot(5); S3_SB();     // hm + mh
+        upm_wait(I2T{}); mm(ahm, by, 2, 4); slot(6); S3_SB();
+        upm_wait(I4T{}); mm(ahm, by, 4, 6); slot(7); S3_SB();
+        upm_wait(I6T{}); mm(ahm, by, 6, 8); slot(8); S3_SB();
+#endif
+#ifndef AVD_LAB_HALFREAD
         mm(ahm, by, 0, 2); slot(5); S3_SB();     // hm + mh
         mm(ahm, by, 2, 4); slot(6); S3_SB();
         mm(ahm, by, 4, 6); slot(7); S3_SB();
         mm(ahm, by, 6, 8); slot(8); S3_SB();
+#endif
         mm(ahm, bx, 0, 2); slot(9); S3_SB();     // hh + mm
         mm(ahm, bx, 2, 4); slot(10); S3_SB();
         mm(ahm, bx, 4, 6); slot(11); S3_SB();
