@@ -187,19 +187,21 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_gelu_stats_kernel(ConvArgs g
     }
 }
 
-// mean / rstd per (sample, group): fp64 reduction of the per-block partials in a fixed order.  One block of 1,024 threads per sample;
-// a thread reads whole 64-byte entries (the 8 groups x {sum, sum of squares} one conv wave wrote) and carries 16 fp64 sums, the
-// block folds them with xor shuffles and one pass through LDS.  (Rounds 1-2 ran one 256-thread block per (sample, group) over
-// 8-byte strided reads: 96 us per launch at 256 x 256 — latency, not bytes.)
-__global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stats,
-                                                           int tiles, double count, float eps) {
-    __shared__ double sh[16][2 * VG];
-    const int smp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// mean / rstd per (sample, group): fp64 reduction of the per-block partials in a fixed order, in two launches (round 5; one block of 1,024
+// threads per sample read its 3 MB of partials at one CU's bandwidth: 80 us per launch at 256 x 256).  Stage 1: GN_FIN_CHUNKS blocks per
+// sample, a thread reads whole 64-byte entries (the 8 groups x {sum, sum of squares} one conv wave wrote) and carries 16 fp64 sums, the
+// block folds them with xor shuffles and one pass through LDS and writes 16 doubles; stage 2 adds the chunks in order.
+constexpr int GN_FIN_CHUNKS = 64;
+__global__ __launch_bounds__(256) void gn_finalize1_kernel(const float* __restrict__ part, double* __restrict__ fin, int tiles) {
+    __shared__ double sh[4][2 * VG];
+    const int chunk = blockIdx.x, smp = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     double acc[2 * VG];
 #pragma unroll
     for (int k = 0; k < 2 * VG; ++k) acc[k] = 0.0;
-    const float* base = part + (int64_t)smp * tiles * 2 * (2 * VG);
-    for (int i = tid; i < tiles * 2; i += 1024) {
+    const int n = tiles * 2, per = (n + GN_FIN_CHUNKS - 1) / GN_FIN_CHUNKS;
+    const int i1 = (chunk + 1) * per < n ? (chunk + 1) * per : n;
+    const float* base = part + (int64_t)smp * n * (2 * VG);
+    for (int i = chunk * per + tid; i < i1; i += 256) {
         const f32x4* e = reinterpret_cast<const f32x4*>(base + (int64_t)i * (2 * VG));
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -215,15 +217,32 @@ __global__ __launch_bounds__(1024) void gn_finalize_kernel(const float* __restri
         if (lane == 0) sh[wave][k] = a;
     }
     __syncthreads();
+    if (tid < 2 * VG) fin[((int64_t)smp * GN_FIN_CHUNKS + chunk) * (2 * VG) + tid] = (sh[0][tid] + sh[1][tid]) + (sh[2][tid] + sh[3][tid]);
+}
+__global__ __launch_bounds__(64) void gn_finalize2_kernel(const double* __restrict__ fin, float* __restrict__ stats, double count, float eps) {
+    __shared__ double tot[2 * VG];
+    const int smp = blockIdx.x, tid = threadIdx.x;
+    if (tid < 2 * VG) {
+        double a = 0.0;
+        for (int c = 0; c < GN_FIN_CHUNKS; ++c) a += fin[((int64_t)smp * GN_FIN_CHUNKS + c) * (2 * VG) + tid];
+        tot[tid] = a;
+    }
+    __syncthreads();
     if (tid < VG) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int w = 0; w < 16; ++w) { s1 += sh[w][2 * tid]; s2 += sh[w][2 * tid + 1]; }
-        const double mean = s1 / count;
-        double var = s2 / count - mean * mean;     // biased, as torch.nn.GroupNorm
+        const double mean = tot[2 * tid] / count;
+        double var = tot[2 * tid + 1] / count - mean * mean;     // biased, as torch.nn.GroupNorm
         if (var < 0.0) var = 0.0;
         stats[(smp * VG + tid) * 2 + 0] = (float)mean;
         stats[(smp * VG + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
     }
+}
+static int64_t gn_fin_bytes(int B) { return (int64_t)B * GN_FIN_CHUNKS * 2 * VG * 8; }
+static int gn_finalize(const float* part, double* fin, float* stats, int B, int tiles, double count, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(gn_finalize1_kernel, dim3(GN_FIN_CHUNKS, B), dim3(256), 0, st, part, fin, tiles);
+    AVD_CHECK_LAUNCH("gn_finalize (1)");
+    hipLaunchKernelGGL(gn_finalize2_kernel, dim3(B), dim3(64), 0, st, fin, stats, count, eps);
+    AVD_CHECK_LAUNCH("gn_finalize (2)");
+    return AVD_OK;
 }
 
 // zero the one-voxel halo of a padded activation buffer [B][T+2][H+2][W+2] voxels x rowb bytes (the interior is overwritten by its
@@ -476,6 +495,15 @@ struct Conv3Args {
     // latent-composed first decoder conv (LAT instantiations, see upsample_lat16_kernel): per border class, what the from_lat bias
     // contributes through the taps that fall inside the volume — btab[class][64 out], class = 6 bits (t lo, t hi, h lo, h hi, w lo, w hi)
     const float* btab;
+    // "folded" decoder route (round 5, bf16x3): the conv kernel's OUT modes.  OUT = 1: GELU(y) goes out as the NEXT conv's act3 image
+    // (X3out, interior of the padded buffer) instead of fp32 Y — the GroupNorm between the two convs is folded into the next conv's
+    // per-sample weights (conv3_weight_gn_kernel) and bias table (conv3_gn_btab_kernel).  OUT = 2 (last conv): per voxel and GroupNorm
+    // group the partial to_img sums P[vox][8 groups][4] = sum_{c in g} wimg_g[o][c] y_c (toimg_from_p_kernel finishes the 1x1x1 conv).
+    unsigned char* X3out;
+    float* P;
+    const float* wimg_g;       // [4][64] = to_img_w[o][c] gamma[c], rows >= out_ch zero
+    int64_t w3_stride;         // bytes between the samples' weight images (0: one image for all samples)
+    int btab_stride;           // floats between the samples' bias tables (0: one table)
 };
 
 // scale slot in the workspace: [0] max |x|, [1] (max row norm, unused), [2] s, [3] 1 / s
@@ -516,6 +544,127 @@ __global__ __launch_bounds__(256) void conv3_weight_kernel(const float* __restri
         *reinterpret_cast<u32x4*>(dst) = Hh;
         *reinterpret_cast<u32x4*>(dst + 2048) = Mi;
         *reinterpret_cast<u32x4*>(dst + 4096) = Lo;
+    }
+}
+
+// ---- GroupNorm folded into the NEXT convolution (round 5, three-plane mode).  conv(GN(y)) with GN(y)_c = a_c y_c + s_c per sample
+// (a_c = rstd_g gamma_c, s_c = beta_c - mean_g rstd_g gamma_c) is a convolution of y itself with the weights W[o, tap, c] a_c plus what the
+// shift contributes through the taps that fall inside the volume (the conv zero-pads GN's OUTPUT) — a bias per border class, as for
+// from_lat's bias in the latent-composed first conv.  So the producing conv writes GELU(y) straight into the act3 image and the
+// normalise pass (read 256 B + write 384 B per voxel) disappears; the price is one 648-KiB weight image and one 16-KiB table per sample.
+__global__ __launch_bounds__(256) void conv3_weight_gn_kernel(const float* __restrict__ Wt, const float* __restrict__ stats,
+                                                              const float* __restrict__ gamma, unsigned char* __restrict__ img) {
+    const int i = blockIdx.x * 256 + threadIdx.x;          // one thread = 8 in-channels (one group) of one (stage, out)
+    if (i >= 108 * 64 * 2) return;
+    const int smp = blockIdx.y;
+    const int half = i & 1, out = (i >> 1) & 63, kt = i >> 7;
+    const int slab = kt / 27, tap = kt % 27;
+    const int c0 = slab * 16 + half * 8;
+    const float rstd = stats[(smp * VG + c0 / 8) * 2 + 1];
+    float v[8], gm[8];
+    const float* src = Wt + ((int64_t)out * 27 + tap) * VC + c0;
+    *reinterpret_cast<f32x4*>(v) = *reinterpret_cast<const f32x4*>(src);
+    *reinterpret_cast<f32x4*>(v + 4) = *reinterpret_cast<const f32x4*>(src + 4);
+    *reinterpret_cast<f32x4*>(gm) = *reinterpret_cast<const f32x4*>(gamma + c0);
+    *reinterpret_cast<f32x4*>(gm + 4) = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= rstd * gm[e];
+    unsigned char* dst = img + (int64_t)smp * W3_BYTES + (int64_t)kt * W3_STAGE + out * 32 + ((half ^ ((out >> 3) & 1)) << 4);
+    u32x4 Hh, Mi, Lo;
+    split8(v, Hh, Mi, Lo);
+    *reinterpret_cast<u32x4*>(dst) = Hh;
+    *reinterpret_cast<u32x4*>(dst + 2048) = Mi;
+    *reinterpret_cast<u32x4*>(dst + 4096) = Lo;
+}
+// btab[smp][class][out] = sum over the taps inside the volume for that border class of sum_c W[out, tap, c] s_c
+// (class bits: t-1, t+1, h-1, h+1, w-1, w+1 inside — the conv kernel's epilogue)
+__global__ __launch_bounds__(256) void conv3_gn_btab_kernel(const float* __restrict__ Wt, const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ btab) {
+    __shared__ float shift[VC];
+    __shared__ float S[VC][28];
+    const int smp = blockIdx.x, tid = threadIdx.x;
+    if (tid < VC) {
+        const float mean = stats[(smp * VG + tid / 8) * 2], rstd = stats[(smp * VG + tid / 8) * 2 + 1];
+        shift[tid] = beta[tid] - mean * rstd * gamma[tid];
+    }
+    __syncthreads();
+    for (int idx = tid; idx < VC * 27; idx += 256) {
+        const int o = idx / 27, tap = idx - o * 27;
+        const float* wr = Wt + ((int64_t)o * 27 + tap) * VC;
+        float a = 0.f;
+        for (int c = 0; c < VC; ++c) a = fmaf(wr[c], shift[c], a);
+        S[o][tap] = a;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 64 * VC; idx += 256) {
+        const int cls = idx >> 6, o = idx & 63;
+        float a = 0.f;
+        for (int tap = 0; tap < 27; ++tap) {
+            const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
+            const bool in = (dt != 0 || (cls & 1)) && (dt != 2 || (cls & 2)) && (dh != 0 || (cls & 4)) && (dh != 2 || (cls & 8)) &&
+                            (dw != 0 || (cls & 16)) && (dw != 2 || (cls & 32));
+            if (in) a += S[o][tap];
+        }
+        btab[((int64_t)smp * 64 + cls) * VC + o] = a;
+    }
+}
+// to_img after the last GroupNorm, from the conv's partial sums: out[o] = sum_g rstd_g P[g][o] + K[o],
+// K[o] = to_img_b[o] + sum_c to_img_w[o][c] (beta_c - mean_g rstd_g gamma_c); consts[smp] = {rstd[8], K[4]}
+__global__ __launch_bounds__(64) void toimg_consts_kernel(const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ Wimg,
+                                                          const float* __restrict__ bimg, float* __restrict__ consts, int Cout) {
+    const int smp = blockIdx.x, c = threadIdx.x;
+    const float mean = stats[(smp * VG + c / 8) * 2], rstd = stats[(smp * VG + c / 8) * 2 + 1];
+    const float sh = beta[c] - mean * rstd * gamma[c];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        float a = o < Cout ? Wimg[o * VC + c] * sh : 0.f;
+#pragma unroll
+        for (int x = 32; x > 0; x >>= 1) a += __shfl_xor(a, x, 64);
+        if (c == 0) consts[smp * 12 + VG + o] = a + (o < Cout ? bimg[o] : 0.f);
+    }
+    if ((c & 7) == 0) consts[smp * 12 + c / 8] = rstd;
+}
+// wimg_g[o][c] = to_img_w[o][c] gamma[c] (rows >= Cout zero): what the last conv's epilogue multiplies GELU(y) with
+__global__ __launch_bounds__(256) void toimg_wg_kernel(const float* __restrict__ Wimg, const float* __restrict__ gamma, float* __restrict__ wg, int Cout) {
+    const int i = threadIdx.x, o = i >> 6, c = i & 63;
+    wg[i] = o < Cout ? Wimg[o * VC + c] * gamma[c] : 0.f;
+}
+constexpr int TOIMG_P_VOX = 128;
+__global__ __launch_bounds__(256) void toimg_from_p_kernel(const float* __restrict__ P, const float* __restrict__ consts, float* __restrict__ out,
+                                                           int THW, int Cout, int use_tanh, int64_t nvox) {
+    __shared__ float s_out[4][TOIMG_P_VOX];
+    const int tid = threadIdx.x, grp = tid & 7;
+    const int64_t vox0 = (int64_t)blockIdx.x * TOIMG_P_VOX;
+#pragma unroll
+    for (int it = 0; it < TOIMG_P_VOX / 32; ++it) {
+        const int vl = it * 32 + (tid >> 3);
+        const int64_t vox = vox0 + vl;
+        const int64_t vx = vox < nvox ? vox : nvox - 1;
+        const int smp = (int)(vx / THW);
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(P + (vx * VG + grp) * 4);
+        const float rs = consts[smp * 12 + grp];
+        f32x4 a = pv * rs;
+#pragma unroll
+        for (int x = 1; x < 8; x <<= 1)
+#pragma unroll
+            for (int o = 0; o < 4; ++o) a[o] += __shfl_xor(a[o], x, 64);
+        if (grp == 0) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) s_out[o][vl] = a[o] + consts[smp * 12 + VG + o];
+        }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < TOIMG_P_VOX * Cout; idx += 256) {
+        const int o = idx / TOIMG_P_VOX, vl = idx % TOIMG_P_VOX;
+        const int64_t vox = vox0 + vl;
+        if (vox < nvox) {
+            float v = s_out[o][vl];
+            v = use_tanh ? tanhf(v) : 1.0f / (1.0f + expf(-v));
+            const int64_t smp = vox / THW;
+            out[(smp * Cout + o) * THW + (vox - smp * THW)] = v;
+        }
     }
 }
 
@@ -679,8 +828,9 @@ template <int TERMS> struct HaloCfg {
 // parameter version by the host; the input image holds upsample(z) in rows of 96 B = [plane][16 ch]).  The from_lat bias reaches an output
 // voxel through the taps that fall inside the volume only (the conv zero-pads u, not from_lat's bias): a table per border class, added in
 // the epilogue.  Same operator up to fp32 rounding (fewer roundings than the reference's order: u is never rounded).
-template <int TERMS, int NSLAB = 4>     // TERMS 6: bf16x3; 3: f16x2 (planes h, l of the same buffers; the third plane is neither moved nor read)
+template <int TERMS, int NSLAB = 4, int OUT = 0>     // TERMS 6: bf16x3; 3: f16x2 (planes h, l of the same buffers; the third plane is neither moved nor read)
 __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
+    static_assert(OUT != 1 || TERMS == 6, "image output: the three-plane mode (an fp16 image needs a bound on the values before they exist)");
     using Cf = HaloCfg<TERMS>;
     constexpr int NPL = Cf::NPL, TH = Cf::TH, HH = Cf::HH, TM = Cf::TM, NCH = Cf::NCH, RB = Cf::RB, NWS = Cf::NWS, WST = Cf::WST;
     constexpr bool F16 = TERMS == 3;
@@ -731,13 +881,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
         }
     };
     // ---- weight stage kt = 27 slab + tap: NPL pieces of 2 KiB... 1-KiB pieces 2 NPL, dealt over the four waves
+    const unsigned char* w3 = g.W3 + (int64_t)smp * g.w3_stride;
     auto fill_w = [&](int kt) {
         unsigned char* dst = wring + (kt % NWS) * WST;
 #pragma unroll
         for (int i = 0; i < (2 * NPL + 3) / 4; ++i) {
             const int pce = wave + 4 * i;
             if (pce < 2 * NPL)
-                __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(g.W3 + (int64_t)kt * W3_STAGE + pce * 1024 + lane * 16), AVD_LDS_PTR(dst + pce * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(w3 + (int64_t)kt * W3_STAGE + pce * 1024 + lane * 16), AVD_LDS_PTR(dst + pce * 1024), 16, 0, 0);
         }
     };
 
@@ -867,6 +1018,79 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
     const f32x4 bv = *reinterpret_cast<const f32x4*>(g.bias + cc);
     const float ab_inv = F16 ? g.ab_inv * (g.a_inv_dev ? g.a_inv_dev[0] : 1.0f) : 1.0f;
     const int tt = t0 + wave;
+    if constexpr (OUT != 0) {
+        // 8 lanes per voxel row, 8 channels (one GroupNorm group) each, 8 rows per wave instruction
+        const int r8 = lane >> 3, c8 = lane & 7;
+        float b8[8];
+        *reinterpret_cast<f32x4*>(b8) = *reinterpret_cast<const f32x4*>(g.bias + c8 * 8);
+        *reinterpret_cast<f32x4*>(b8 + 4) = *reinterpret_cast<const f32x4*>(g.bias + c8 * 8 + 4);
+        [[maybe_unused]] float wg[4][8];
+        if constexpr (OUT == 2) {
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                *reinterpret_cast<f32x4*>(wg[o]) = *reinterpret_cast<const f32x4*>(g.wimg_g + o * VC + c8 * 8);
+                *reinterpret_cast<f32x4*>(wg[o] + 4) = *reinterpret_cast<const f32x4*>(g.wimg_g + o * VC + c8 * 8 + 4);
+            }
+        }
+        const float* bt = g.btab ? g.btab + (int64_t)smp * g.btab_stride : nullptr;
+#pragma unroll
+        for (int ps = 0; ps < TM / 2; ++ps) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) slab_f[(i * 32 + mfma32_row(r, hi)) * CLD + j * 32 + l31] = acc[ps * 2 + i][j][r];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int row = r8 + it * 8;
+                const int hh = h0 + 2 * (ps * 2 + (row >> 5)) + ((row >> 4) & 1), ww = w0 + (row & 15);
+                float y[8];
+                *reinterpret_cast<f32x4*>(y) = *reinterpret_cast<const f32x4*>(slab_f + row * CLD + c8 * 8);
+                *reinterpret_cast<f32x4*>(y + 4) = *reinterpret_cast<const f32x4*>(slab_f + row * CLD + c8 * 8 + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = F16 ? y[e] * ab_inv + b8[e] : y[e] + b8[e];
+                if (bt) {        // the folded GroupNorm shift (or from_lat's bias) through the taps inside the volume (class 63 = interior)
+                    const int cls = (tt >= 1) | ((tt <= g.T - 2) << 1) | ((hh >= 1) << 2) | ((hh <= g.H - 2) << 3) | ((ww >= 1) << 4) | ((ww <= g.W - 2) << 5);
+                    const f32x4 t0v = *reinterpret_cast<const f32x4*>(bt + cls * VC + c8 * 8), t1v = *reinterpret_cast<const f32x4*>(bt + cls * VC + c8 * 8 + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { y[e] += t0v[e]; y[4 + e] += t1v[e]; }
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) y[e] = gelu_erf(y[e]);
+                if (tt < g.T && hh < g.H && ww < g.W) {
+                    if constexpr (OUT == 1) {
+                        const int64_t pv = (((int64_t)smp * (g.T + 2) + tt + 1) * Hp + hh + 1) * Wp + ww + 1;
+                        store_act3<false>(g.X3out, pv, c8, y, 0.f);
+                    } else {
+                        const int64_t v = ((int64_t)tt * g.H + hh) * g.W + ww;
+                        f32x4 pp;
+#pragma unroll
+                        for (int o = 0; o < 4; ++o) {
+                            float a = 0.f;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) a = fmaf(y[e], wg[o][e], a);
+                            pp[o] = a;
+                        }
+                        *reinterpret_cast<f32x4*>(g.P + (((int64_t)smp * THW + v) * VG + c8) * 4) = pp;
+                    }
+                    s1 += ((y[0] + y[1]) + (y[2] + y[3])) + ((y[4] + y[5]) + (y[6] + y[7]));
+                    s2 += ((y[0] * y[0] + y[1] * y[1]) + (y[2] * y[2] + y[3] * y[3])) + ((y[4] * y[4] + y[5] * y[5]) + (y[6] * y[6] + y[7] * y[7]));
+                }
+            }
+            s1 += __shfl_xor(s1, 8, 64);  s2 += __shfl_xor(s2, 8, 64);
+            s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if (lane < VG) {
+                const int64_t e = ((int64_t)tile * 4 + wave) * (TM / 2) + ps;
+                float* pp = g.part + (((int64_t)smp * g.tiles * 2 + e) * VG + lane) * 2;
+                pp[0] = s1;
+                pp[1] = s2;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ps = 0; ps < TM / 2; ++ps) {
 #pragma unroll
@@ -923,18 +1147,44 @@ static int conv3_tiles(int terms, int T, int H, int W) {
 }
 int g_vae_lat = getenv("AVD_VAE_LAT") ? atoi(getenv("AVD_VAE_LAT")) : 1;      // avd_tune_set "vae_lat": 0 = from_lat -> upsample -> 64-channel first conv
 static LdsAttr g_conv3_lat_attr[2];
-static int conv3_launch(Conv3Args a3, int terms, int B, double flops, hipStream_t st, bool lat = false) {
+// avd_tune_set "vae_fold" (AVD_VAE_FOLD): 1 (default) = the three-plane decoder with two conv blocks and a latent-composed first conv writes
+// conv 0's output straight into conv 1's operand image, folds the GroupNorm between them into conv 1's per-sample weights, and finishes
+// to_img from per-group partial sums of conv 1's epilogue; 0 = fp32 activations between the kernels (rounds 1-4)
+int g_vae_fold = getenv("AVD_VAE_FOLD") ? atoi(getenv("AVD_VAE_FOLD")) : 1;
+static LdsAttr g_conv3_fold_attr[3];
+static int conv3_launch(Conv3Args a3, int terms, int B, double flops, hipStream_t st, bool lat = false, int out_mode = 0) {
     a3.tiles = conv3_tiles(terms, a3.T, a3.H, a3.W);
+    if (out_mode != 0) {
+        AVD_REQUIRE((out_mode == 1 && terms != 3 && lat && a3.X3out) || (out_mode == 2 && !lat && a3.P && a3.wimg_g), AVD_EINVAL, "conv3d (folded route): bad arguments");
+        if (out_mode == 2 && terms == 3) {
+            if (int rc = g_conv3_fold_attr[2].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<3, 4, 2>), HaloCfg<3>::LDS, "conv3d f16x2 (to_img partials out)")) return rc;
+            static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<3, 4, 2>");
+            ProfScope prof(tag, flops, st);
+            hipLaunchKernelGGL((conv3d_k3_bf16x3_kernel<3, 4, 2>), dim3((unsigned)(B * conv3_blocks<3>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<3>::LDS, st, a3);
+        } else if (out_mode == 1) {
+            if (int rc = g_conv3_fold_attr[0].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<6, 1, 1>), HaloCfg<6>::LDS, "conv3d bf16x3 (latent, image out)")) return rc;
+            static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<6, 1, 1>");
+            ProfScope prof(tag, flops, st);
+            hipLaunchKernelGGL((conv3d_k3_bf16x3_kernel<6, 1, 1>), dim3((unsigned)(B * conv3_blocks<6>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<6>::LDS, st, a3);
+        } else {
+            if (int rc = g_conv3_fold_attr[1].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<6, 4, 2>), HaloCfg<6>::LDS, "conv3d bf16x3 (to_img partials out)")) return rc;
+            static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<6, 4, 2>");
+            ProfScope prof(tag, flops, st);
+            hipLaunchKernelGGL((conv3d_k3_bf16x3_kernel<6, 4, 2>), dim3((unsigned)(B * conv3_blocks<6>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<6>::LDS, st, a3);
+        }
+        AVD_CHECK_LAUNCH("conv3d (folded route)");
+        return AVD_OK;
+    }
     if (lat) {
         AVD_REQUIRE(a3.btab, AVD_EINVAL, "conv3d (latent-composed): null bias table");
         if (terms == 3) {
             if (int rc = g_conv3_lat_attr[1].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<3, 1>), HaloCfg<3>::LDS, "conv3d f16x2 (latent)")) return rc;
-            static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<3, 1>");
+            static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<3, 1, 0>");
             ProfScope prof(tag, flops, st);
             hipLaunchKernelGGL((conv3d_k3_bf16x3_kernel<3, 1>), dim3((unsigned)(B * conv3_blocks<3>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<3>::LDS, st, a3);
         } else {
             if (int rc = g_conv3_lat_attr[0].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<6, 1>), HaloCfg<6>::LDS, "conv3d bf16x3 (latent)")) return rc;
-            static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<6, 1>");
+            static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<6, 1, 0>");
             ProfScope prof(tag, flops, st);
             hipLaunchKernelGGL((conv3d_k3_bf16x3_kernel<6, 1>), dim3((unsigned)(B * conv3_blocks<6>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<6>::LDS, st, a3);
         }
@@ -943,12 +1193,12 @@ static int conv3_launch(Conv3Args a3, int terms, int B, double flops, hipStream_
     }
     if (terms == 3) {
         if (int rc = g_conv3_attr[1].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<3, 4>), HaloCfg<3>::LDS, "conv3d f16x2")) return rc;
-        static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<3, 4>");
+        static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<3, 4, 0>");
         ProfScope prof(tag, flops, st);
         hipLaunchKernelGGL((conv3d_k3_bf16x3_kernel<3, 4>), dim3((unsigned)(B * conv3_blocks<3>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<3>::LDS, st, a3);
     } else {
         if (int rc = g_conv3_attr[0].ensure(reinterpret_cast<const void*>(conv3d_k3_bf16x3_kernel<6, 4>), HaloCfg<6>::LDS, "conv3d bf16x3")) return rc;
-        static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<6, 4>");
+        static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<6, 4, 0>");
         ProfScope prof(tag, flops, st);
         hipLaunchKernelGGL((conv3d_k3_bf16x3_kernel<6, 4>), dim3((unsigned)(B * conv3_blocks<6>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<6>::LDS, st, a3);
     }
@@ -971,7 +1221,8 @@ static inline int64_t a256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
 struct VaePlan {
     int T, H, W, tiles;
-    int64_t THW, pad_b, y_b, hlow_b, part_b, stats_b, total;
+    bool fold_img;
+    int64_t THW, pad_b, y_b, hlow_b, part_b, part_n, fold_b, stats_b, total;
 };
 
 static int vae_plan(const avd_vae_decode_desc* d, VaePlan& p) {
@@ -992,10 +1243,15 @@ static int vae_plan(const avd_vae_decode_desc* d, VaePlan& p) {
     {
         const int t3 = conv3_tiles(3, d->T, d->H, d->W), t6 = conv3_tiles(6, d->T, d->H, d->W);
         const int tmax = p.tiles > t3 ? (p.tiles > t6 ? p.tiles : t6) : (t3 > t6 ? t3 : t6);
-        p.part_b = a256((int64_t)d->B * tmax * 2 * VG * 2 * 4);
+        p.part_n = (int64_t)d->B * tmax * 2 * VG * 2;
+        p.part_b = a256(p.part_n * 4 + gn_fin_bytes(d->B));       // + gn_finalize's per-chunk fp64 sums
     }
     p.stats_b = a256((int64_t)d->B * VG * 2 * 4) + 256;       // + the scale slot of the f16x2 decoder (4 floats)
-    p.total = p.pad_b + p.y_b + p.hlow_b + p.part_b + p.stats_b;
+    // folded route (three planes, two blocks): per-sample weight image + bias table of conv 1, to_img constants, to_img_w . gamma
+    // (to_img constants and to_img_w . gamma: every split-operand decoder; the per-sample image and table: three planes, two blocks)
+    p.fold_img = d->conv_w3 && d->conv_terms != 3 && d->n_blocks == 2;
+    p.fold_b = d->conv_w3 ? a256((int64_t)d->B * 64 + 4 * VC * 4 + (p.fold_img ? (int64_t)d->B * (W3_BYTES + 64 * VC * 4) : 0)) : 0;
+    p.total = p.pad_b + p.y_b + p.hlow_b + p.part_b + p.fold_b + p.stats_b;
     return AVD_OK;
 }
 
@@ -1040,7 +1296,9 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
     float* Y = reinterpret_cast<float*>(w + p.pad_b);
     float* hlow = reinterpret_cast<float*>(w + p.pad_b + p.y_b);
     float* part = reinterpret_cast<float*>(w + p.pad_b + p.y_b + p.hlow_b);
-    float* stats = reinterpret_cast<float*>(w + p.pad_b + p.y_b + p.hlow_b + p.part_b);
+    double* fin = reinterpret_cast<double*>(part + p.part_n);
+    char* foldw = w + p.pad_b + p.y_b + p.hlow_b + p.part_b;
+    float* stats = reinterpret_cast<float*>(foldw + p.fold_b);
     const int B = d->B;
 
     const bool s3 = d->conv_w3 != nullptr;                  // split-operand convolutions: Xp is the act3 buffer (384 B per voxel)
@@ -1053,6 +1311,61 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
     }
     // latent-composed first convolution (conv3d_k3_bf16x3_kernel<.., 1>): its input image is upsample(z), 96 B per voxel
     const bool lat = s3 && d->conv0_lat_w3 != nullptr && g_vae_lat;
+    const int64_t padvox = (int64_t)B * (p.T + 2) * (p.H + 2) * (p.W + 2);
+    const int64_t nvox = (int64_t)B * p.THW;
+    float* consts = reinterpret_cast<float*>(foldw);            // {rstd[8], K[4]} per sample (16 floats each), then to_img_w . gamma [4][64]
+    float* wg = consts + (int64_t)B * 16;
+    float* Pp = Y;                                              // the last conv's to_img partial sums live where the fp32 activations do otherwise
+    // to_img from the last conv's per-group partial sums (every split-operand decoder; "vae_fold" 0 restores gn_apply_toimg)
+    auto toimg_from_p = [&](int blk) -> int {
+        hipLaunchKernelGGL(toimg_consts_kernel, dim3(B), dim3(64), 0, st, stats, d->gn_w[blk], d->gn_b[blk], d->to_img_w, d->to_img_b, consts, d->out_ch);
+        AVD_CHECK_LAUNCH("toimg_consts");
+        static const int tag = prof_tag_id("toimg_from_p_kernel");
+        ProfScope prof(tag, 4.0 * ((double)nvox * VG * 4 + (double)nvox * d->out_ch), st);
+        hipLaunchKernelGGL(toimg_from_p_kernel, dim3((unsigned)((nvox + TOIMG_P_VOX - 1) / TOIMG_P_VOX)), dim3(256), 0, st, Pp, consts, out, (int)p.THW,
+                           d->out_ch, d->out_tanh, nvox);
+        AVD_CHECK_LAUNCH("toimg_from_p");
+        return AVD_OK;
+    };
+    if (lat && !h2 && g_vae_fold && p.fold_img && d->conv0_lat_btab && d->Cv <= 16 && padvox * L16_ROWB <= p.y_b) {
+        // ---- folded route: upsample(z) -> L | conv 0 (L -> act3 image of GELU) | stats | conv 1 with GN 0 folded in (-> to_img partials) |
+        // stats | to_img.  L and the partials P share the region the fp32 activations Y have on the other routes.
+        unsigned char* Lm = reinterpret_cast<unsigned char*>(Y);
+        unsigned char* wimg = reinterpret_cast<unsigned char*>(wg + 4 * VC);
+        float* btab1 = reinterpret_cast<float*>(wimg + (int64_t)B * W3_BYTES);
+        if (int rc = zero_halo(reinterpret_cast<float*>(Lm), B, p.T, p.H, p.W, L16_ROWB, st)) return rc;
+        {
+            static const int tag = prof_tag_id("upsample_lat16_kernel");
+            ProfScope prof(tag, (double)nvox * L16_ROWB, st);
+            hipLaunchKernelGGL(upsample_lat16_kernel<false>, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, z, Lm, d->Cv, d->Tp, d->Hp, d->Wp, p.T, p.H,
+                               p.W, (float)d->Tp / (float)p.T, (float)d->Hp / (float)p.H, (float)d->Wp / (float)p.W, nvox, nullptr);
+            AVD_CHECK_LAUNCH("upsample_lat16");
+        }
+        if (int rc = zero_halo(Xp, B, p.T, p.H, p.W, A3_ROWB, st)) return rc;
+        const int gn_tiles = conv3_tiles(6, p.T, p.H, p.W);
+        {
+            Conv3Args a3{Lm, static_cast<const unsigned char*>(d->conv0_lat_w3), d->conv_b[0], nullptr, part, p.T, p.H, p.W, p.tiles, 1.f, nullptr,
+                         d->conv0_lat_btab, X3, nullptr, nullptr, 0, 0};
+            if (int rc = conv3_launch(a3, 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * 16, st, true, 1)) return rc;
+        }
+        if (int rc = gn_finalize(part, fin, stats, B, gn_tiles, (double)p.THW * (VC / VG), d->gn_eps, st)) return rc;
+        {
+            static const int tag = prof_tag_id("conv3_weight_gn_kernel");
+            ProfScope prof(tag, (double)B * (W3_BYTES + 27.0 * VC * VC * 4), st);
+            hipLaunchKernelGGL(conv3_weight_gn_kernel, dim3(54, B), dim3(256), 0, st, d->conv_w[1], stats, d->gn_w[0], wimg);
+            AVD_CHECK_LAUNCH("conv3_weight_gn");
+            hipLaunchKernelGGL(conv3_gn_btab_kernel, dim3(B), dim3(256), 0, st, d->conv_w[1], stats, d->gn_w[0], d->gn_b[0], btab1);
+            AVD_CHECK_LAUNCH("conv3_gn_btab");
+            hipLaunchKernelGGL(toimg_wg_kernel, dim3(1), dim3(256), 0, st, d->to_img_w, d->gn_w[1], wg, d->out_ch);
+            AVD_CHECK_LAUNCH("toimg_wg");
+        }
+        {
+            Conv3Args a3{X3, wimg, d->conv_b[1], nullptr, part, p.T, p.H, p.W, p.tiles, 1.f, nullptr, btab1, nullptr, Pp, wg, W3_BYTES, 64 * VC};
+            if (int rc = conv3_launch(a3, 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st, false, 2)) return rc;
+        }
+        if (int rc = gn_finalize(part, fin, stats, B, gn_tiles, (double)p.THW * (VC / VG), d->gn_eps, st)) return rc;
+        return toimg_from_p(1);
+    }
     if (lat) {
         AVD_REQUIRE(d->conv0_lat_btab && d->Cv <= 16, AVD_EINVAL, "vae_decode: the latent-composed first conv needs its bias table and Cv <= 16");
         AVD_REQUIRE(!h2 || (d->conv0_lat_w_scale > 0.f && d->conv0_lat_w_scale < __builtin_inff()), AVD_EINVAL,
@@ -1063,7 +1376,6 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
             hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, st, scale_ws);
             AVD_CHECK_LAUNCH("pow2_scale");
         }
-        const int64_t nvox = (int64_t)B * p.THW;
         static const int tag = prof_tag_id("upsample_lat16_kernel");
         ProfScope prof(tag, (double)nvox * L16_ROWB, st);
         const float fst = (float)d->Tp / (float)p.T, fsh = (float)d->Hp / (float)p.H, fsw = (float)d->Wp / (float)p.W;
@@ -1129,20 +1441,31 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
                 a3.ab_inv = blk == 0 ? 1.0f / (lat0 ? d->conv0_lat_w_scale : d->conv_w_scale[0]) : 1.0f / (d->conv_w_scale[blk] * d->conv_a_scale[blk]);
                 a3.a_inv_dev = blk == 0 ? scale_ws + 3 : nullptr;
             }
-            if (int rc = conv3_launch(a3, h2 ? 3 : 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * (lat0 ? 16 : VC), st, lat0)) return rc;
+            // last conv: to_img's per-group partial sums instead of fp32 activations (toimg_from_p below)
+            const bool p_out = g_vae_fold && blk + 1 == d->n_blocks && !lat0;
+            if (p_out) {
+                hipLaunchKernelGGL(toimg_wg_kernel, dim3(1), dim3(256), 0, st, d->to_img_w, d->gn_w[blk], wg, d->out_ch);
+                AVD_CHECK_LAUNCH("toimg_wg");
+                a3.Y = nullptr;
+                a3.P = Pp;
+                a3.wimg_g = wg;
+            }
+            if (int rc = conv3_launch(a3, h2 ? 3 : 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * (lat0 ? 16 : VC), st, lat0, p_out ? 2 : 0)) return rc;
             gn_tiles = conv3_tiles(h2 ? 3 : 6, p.T, p.H, p.W);
             // the act3 buffer of the next conv overlays the latent image: its halo is zeroed now that conv 0 has read the latent image
             if (lat0 && blk + 1 < d->n_blocks)
                 if (int rc = zero_halo(Xp, B, p.T, p.H, p.W, A3_ROWB, st)) return rc;
+            if (p_out) {
+                if (int rc = gn_finalize(part, fin, stats, B, gn_tiles, (double)p.THW * (VC / VG), d->gn_eps, st)) return rc;
+                return toimg_from_p(blk);
+            }
         } else {
             static const int tag = prof_tag_id("conv3d_k3_gelu_stats_kernel<64>");
             ProfScope prof(tag, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st);
             hipLaunchKernelGGL(conv3d_k3_gelu_stats_kernel<64>, dim3((unsigned)(B * p.tiles)), dim3(256), lds, st, a);
             AVD_CHECK_LAUNCH("conv3d");
         }
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(1024), 0, st, part, stats, gn_tiles,
-                           (double)p.THW * (VC / VG), d->gn_eps);
-        AVD_CHECK_LAUNCH("gn_finalize");
+        if (int rc = gn_finalize(part, fin, stats, B, gn_tiles, (double)p.THW * (VC / VG), d->gn_eps, st)) return rc;
         if (blk + 1 < d->n_blocks && s3) {
             const int64_t total8 = (int64_t)B * p.THW * 8;
             static const int tag = prof_tag_id("gn_apply_pad3_kernel");
@@ -1180,7 +1503,7 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
 namespace avd {
 struct VaeEncPlan {
     int tiles;
-    int64_t THW, pad4_b, pad_b, y_b, part_b, stats_b, total;
+    int64_t THW, pad4_b, pad_b, y_b, part_b, part_n, stats_b, total;
 };
 static int vae_enc_plan(const avd_vae_encode_desc* d, VaeEncPlan& p) {
     AVD_REQUIRE(d, AVD_EINVAL, "vae_encode: null descriptor");
@@ -1202,7 +1525,8 @@ static int vae_enc_plan(const avd_vae_encode_desc* d, VaeEncPlan& p) {
     {
         const int t3 = conv3_tiles(3, d->T, d->H, d->W), t6 = conv3_tiles(6, d->T, d->H, d->W);
         const int tmax = p.tiles > t3 ? (p.tiles > t6 ? p.tiles : t6) : (t3 > t6 ? t3 : t6);
-        p.part_b = a256((int64_t)d->B * tmax * 2 * VG * 2 * 4);
+        p.part_n = (int64_t)d->B * tmax * 2 * VG * 2;
+        p.part_b = a256(p.part_n * 4 + gn_fin_bytes(d->B));
     }
     p.stats_b = a256((int64_t)d->B * VG * 2 * 4);
     p.total = p.pad4_b + p.pad_b + p.y_b + p.part_b + p.stats_b;
@@ -1230,6 +1554,7 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
     float* Xp = reinterpret_cast<float*>(w + p.pad4_b);
     float* Y = reinterpret_cast<float*>(w + p.pad4_b + p.pad_b);
     float* part = reinterpret_cast<float*>(w + p.pad4_b + p.pad_b + p.y_b);
+    double* fin = reinterpret_cast<double*>(part + p.part_n);
     float* stats = reinterpret_cast<float*>(w + p.pad4_b + p.pad_b + p.y_b + p.part_b);
     const int B = d->B, T = d->T, H = d->H, W = d->W;
 
@@ -1269,9 +1594,7 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
             hipLaunchKernelGGL(conv3d_k3_gelu_stats_kernel<64>, dim3((unsigned)(B * p.tiles)), dim3(256), lds, st, a);
         }
         AVD_CHECK_LAUNCH("conv3d(enc)");
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(1024), 0, st, part, stats, gn_tiles,
-                           (double)p.THW * (VC / VG), d->gn_eps);
-        AVD_CHECK_LAUNCH("gn_finalize");
+        if (int rc = gn_finalize(part, fin, stats, B, gn_tiles, (double)p.THW * (VC / VG), d->gn_eps, st)) return rc;
         if (blk + 1 < d->n_blocks && s3) {
             const int64_t total8 = (int64_t)B * p.THW * 8;
             static const int tag = prof_tag_id("gn_apply_pad3_kernel");

@@ -3,6 +3,7 @@ reference-generated golden fixtures.  Tolerance: max|Δ| <= 1e-4 *
 per single step; chained trajectory: relative L2 <= 1e-3."""
 import json
 import math
+import re
 
 import numpy as np
 import pytest
@@ -1010,7 +1011,7 @@ def test_vae_decode_latent_composed_first_conv(dev, mode):
         torch.cuda.synchronize()
         L.prof_enable(False)
         used = {k for k, v in L.prof_report().items() if v[0] > 0}
-        assert any(k.endswith(", 1>") and k.startswith("conv3d_k3_bf16x3_kernel") for k in used) == lat, used
+        assert any(re.match(r"conv3d_k3_bf16x3_kernel<\d, 1, \d>", k) for k in used) == lat, used
         assert ("upsample_lat16_kernel" in used) == lat and ("fromlat_kernel" in used) == (not lat), used
         outs[lat] = (x, vae.decode(G(g["z"][:1], dev), out_size=(6, 24, 40)).cpu())
     assert rel_err(outs[True][0], g["x"]) < TOL and rel_err(outs[True][1], g["x_odd"]) < TOL
@@ -1027,6 +1028,57 @@ def test_vae_decode_latent_composed_first_conv(dev, mode):
         v.matmul, v.lat_composed = mode, lat
         errs[lat] = rel_err(v.to(dev).decode(z.to(dev)).cpu(), ref)
     assert errs[True] < TOL and errs[True] < 2.0 * errs[False] + 1e-6, errs
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x2"])
+def test_vae_decode_folded_route(dev, mode):
+    """Round 5 (f16x2: the to_img part only — an fp16 image of conv 0's output would need a bound on values that do not exist yet).
+    bf16x3, two conv blocks, latent-composed first conv: conv 0 writes GELU(y) straight into conv 1's operand image, the
+    GroupNorm between them (vae_video3d.py:81-83) is folded into conv 1's per-sample weights and a border-class bias table, and to_img
+    (:210-214) is finished from per-group partial sums of conv 1's epilogue — no fp32 activation buffer between the kernels
+    (avd_tune_set "vae_fold").  Same operator up to fp32 rounding: against the other route, the golden fixture (two samples = two sets
+    of statistics; the ragged size, whose border voxels take the border rows of the tables), and the fp64 oracle on a decoder built
+    to stress the fold — a conv 0 bias that puts the activations' mean far above their spread (GN's subtraction then happens through
+    the table) with GroupNorm weights and shifts of order one."""
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd import _lib as L
+    g = load_golden("g11_vae_decode.npz")
+    outs = {}
+    try:
+        for fold in (0, 1):
+            _tune("vae_fold", fold)
+            vae = _vae_from(split_weights(g)["w"], dev)
+            vae.matmul = mode
+            L.prof_enable(True)
+            x = vae.decode(G(g["z"], dev)).cpu()
+            torch.cuda.synchronize()
+            L.prof_enable(False)
+            used = {k for k, v in L.prof_report().items() if v[0] > 0}
+            want = {"conv3d_k3_bf16x3_kernel<6, 1, 1>", "conv3d_k3_bf16x3_kernel<6, 4, 2>", "toimg_from_p_kernel"} if mode == "bf16x3" else \
+                   {"conv3d_k3_bf16x3_kernel<3, 4, 2>", "toimg_from_p_kernel"}
+            assert (want <= used) == bool(fold), used
+            assert ("gn_apply_toimg_kernel" in used) == (not fold) and ("gn_apply_pad3_kernel" in used) == (not fold or mode == "f16x2"), used
+            outs[fold] = (x, vae.decode(G(g["z"][:1], dev), out_size=(6, 24, 40)).cpu())
+        assert rel_err(outs[1][0], g["x"]) < TOL and rel_err(outs[1][1], g["x_odd"]) < TOL
+        assert rel_err(outs[1][0], outs[0][0]) < 2e-5 and rel_err(outs[1][1], outs[0][1]) < 2e-5
+        W = R.synth_vae_decoder(seed=7, n_blocks=2)
+        gen = torch.Generator().manual_seed(8)
+        W["dec_net.0.0.bias"] = 1.5 + 0.5 * torch.rand(64, generator=gen)
+        for i in (0, 1):
+            W[f"dec_net.{i}.2.weight"] = torch.randn(64, generator=gen)
+            W[f"dec_net.{i}.2.bias"] = torch.randn(64, generator=gen)
+        z = torch.randn(3, 8, 1, 2, 3, generator=gen)
+        ref = R.vae_decode(z.double(), {k: v.double() for k, v in W.items()}, n_blocks=2)
+        errs = {}
+        for fold in (0, 1):
+            _tune("vae_fold", fold)
+            v = A.VideoVAE(A.VideoVAEConfig(dec_blocks=2)).eval()
+            v.load_state_dict(W, strict=False)
+            v.matmul = mode
+            errs[fold] = rel_err(v.to(dev).decode(z.to(dev)).cpu(), ref)
+        assert errs[1] < TOL and errs[1] < 3.0 * errs[0] + 1e-6, errs
+    finally:
+        _tune("vae_fold", 1)
 
 
 def test_vae_encode_bf16x3(dev):

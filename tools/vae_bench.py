@@ -17,6 +17,7 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--matmul", default="f32", choices=["f32", "bf16x3", "f16x2"])
 ap.add_argument("--lat", type=int, default=1, help="0: from_lat -> upsample -> 64-channel first conv (rounds 1-4); 1: the latent-composed first conv")
+ap.add_argument("--power", type=float, default=0.0, help="loop the decode for this many seconds under bench.py's clock / socket-power sampler")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -44,3 +45,17 @@ for k, (n, ms, w) in L.prof_report().items():
     if n:
         unit = f"{w/ms/1e9:8.1f} TFLOP/s" if "conv3d" in k else f"{w/ms/1e6:8.1f} GB/s"
         print(f"  {k:40s} x{n}  {ms/n:9.3f} ms  {unit}")
+if args.power > 0:
+    from bench import PowerClockSampler
+    smp = PowerClockSampler(0)
+    smp.start()
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < args.power:
+        for _ in range(5):
+            vae.decode(z)
+        torch.cuda.synchronize()
+        n += 5
+    dt = (time.perf_counter() - t0) / n
+    r = smp.stop(settle_s=1.0)
+    print(f"  looped {n} decodes: {dt*1e3:.2f} ms each | sclk {r.get('sclk_mhz_median')} MHz, socket {r.get('socket_power_w_median')} W of {r.get('socket_power_cap_w')} W")
