@@ -15,6 +15,8 @@
 #include "avd_common.h"
 
 #include <stdlib.h>
+#include <type_traits>
+#include <utility>
 
 namespace avd {
 
@@ -805,6 +807,8 @@ __global__ __launch_bounds__(256) void upsample_lat16_kernel(const float* __rest
 //   two planes:   c ^ ((wx >> 1) & 3)          three planes:   (c + 3 ((wx >> 1) & 1)) mod 6
 // — found by exhaustive search: every ds_read_b128 of a 2 x 16-voxel fragment is bank-conflict free at all 27 tap shifts.
 // Weight stage: [plane][64 out][32 B], k-half at slot half ^ ((out >> 3) & 1) (conv3_weight_kernel).
+template <int... I, class F> __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 constexpr int HT_T = 4, HT_W = 16, HT_HW = HT_W + 2;
 template <int TERMS> struct HaloCfg {
     static constexpr int NPL = s3_planes(TERMS);
@@ -836,7 +840,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
     constexpr bool F16 = TERMS == 3;
     constexpr bool LAT = NSLAB == 1;
     constexpr int XROWB = LAT ? L16_ROWB : A3_ROWB, XPLS = LAT ? 32 : 128;      // bytes per voxel / per plane of the input image
-    constexpr int NSTEP = NSLAB * 27;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     unsigned char* halo = smem3;
     unsigned char* wring = smem3 + Cf::HALO_B;
@@ -858,8 +861,46 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
     const int Hp = g.H + 2, Wp = g.W + 2;
     const int THW = g.T * g.H * g.W;
 
-    // ---- halo fill: piece q = 64 consecutive 16-byte chunks of the LDS image; lane -> (voxel, physical chunk) -> source address
+    // ---- halo fill.  Three planes (round 5): by ROWS of the tile — a row (tz, hy) is 18 voxels x 6 chunks = 108 consecutive 16-byte chunks of the
+    // LDS image = two DMA instructions (64 + 44 lanes) whose lane -> (voxel, chunk) -> source offset map does not depend on the row: two
+    // per-lane offsets computed once, a scalar base per row (9 rows per wave, scalar unit), nothing else per refill.  (Rounds 3-4 cut the image into
+    // 1-KiB pieces whatever the rows: ~40 vector instructions of index arithmetic per piece, 16 pieces per wave and slab — with the
+    // per-step address arithmetic a third of the kernel's issue slots, VALUBusy 29 %.)
+    // Two planes: pieces of 64 consecutive chunks, lane -> (voxel, physical chunk) -> source address.
+    constexpr bool ROWFILL = NPL == 3;
+    constexpr int HROWS = (HT_T + 2) * HH, RPW = (HROWS + 3) / 4, ROWCH = HT_HW * NCH;      // 36 rows, 9 per wave, 108 chunks per row
+    [[maybe_unused]] int hsrc[2];
+    if constexpr (ROWFILL) {
+        static_assert(ROWCH > 64 && ROWCH <= 128 && HROWS * ROWCH * 16 <= Cf::HALO_B, "two DMA instructions per halo row");
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            int ci = k2 * 64 + lane;
+            ci = ci < ROWCH ? ci : ROWCH - 1;
+            const int wx = ci / NCH, pc = ci - wx * NCH;
+            int c = pc - 3 * ((wx >> 1) & 1);
+            c = c < 0 ? c + 6 : c;
+            int ww = w0 + wx;
+            ww = ww < Wp ? ww : Wp - 1;             // ragged tiles: clamped to the buffer (those voxels only feed outputs that are never stored)
+            hsrc[k2] = ww * XROWB + (c >> 1) * XPLS + (c & 1) * 16;
+        }
+    }
     auto fill_halo = [&](int slab) {
+        if constexpr (ROWFILL) {
+#pragma unroll
+            for (int k = 0; k < RPW; ++k) {
+                const int r = wave + 4 * k;
+                if (r < HROWS) {                    // wave-uniform; the row's base is scalar arithmetic, redone per refill (registers are scarce)
+                    const int tz = r / HH, hy = r - tz * HH;
+                    int tt = t0 + tz, hh = h0 + hy;
+                    tt = tt < g.T + 2 ? tt : g.T + 1;
+                    hh = hh < Hp ? hh : Hp - 1;
+                    const unsigned char* src = g.X3 + ((((int64_t)smp * (g.T + 2) + tt) * Hp + hh) * Wp) * XROWB + slab * 32;
+                    __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(src + hsrc[0]), AVD_LDS_PTR(halo + r * (ROWCH * 16)), 16, 0, 0);
+                    if (lane < ROWCH - 64)
+                        __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(src + hsrc[1]), AVD_LDS_PTR(halo + r * (ROWCH * 16) + 1024), 16, 0, 0);
+                }
+            }
+        } else {
 #pragma unroll 1
         for (int q = wave; q < Cf::NPIECE; q += 4) {
             int L = q * 64 + lane;
@@ -867,9 +908,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
             const int hv = L / NCH, pc = L - hv * NCH;
             const int tz = hv / (HH * HT_HW), rem = hv - tz * (HH * HT_HW);
             const int hy = rem / HT_HW, wx = rem - hy * HT_HW;
-            int c;
-            if constexpr (NPL == 2) c = pc ^ ((wx >> 1) & 3);
-            else { c = pc - 3 * ((wx >> 1) & 1); c = c < 0 ? c + 6 : c; }
+            const int c = pc ^ ((wx >> 1) & 3);
             // padded coordinates, clamped to the buffer for ragged tiles (those voxels only feed outputs that are never stored)
             int tt = t0 + tz, hh = h0 + hy, ww = w0 + wx;
             tt = tt < g.T + 2 ? tt : g.T + 1;
@@ -879,11 +918,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
             __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(g.X3 + pv * XROWB + (c >> 1) * XPLS + slab * 32 + (c & 1) * 16),
                                              AVD_LDS_PTR(halo + q * 1024), 16, 0, 0);
         }
+        }
     };
     // ---- weight stage kt = 27 slab + tap: NPL pieces of 2 KiB... 1-KiB pieces 2 NPL, dealt over the four waves
     const unsigned char* w3 = g.W3 + (int64_t)smp * g.w3_stride;
-    auto fill_w = [&](int kt) {
-        unsigned char* dst = wring + (kt % NWS) * WST;
+    auto fill_w = [&](int kt, int stage) {
+        unsigned char* dst = wring + stage * WST;
 #pragma unroll
         for (int i = 0; i < (2 * NPL + 3) / 4; ++i) {
             const int pce = wave + 4 * i;
@@ -906,17 +946,29 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
     const int a_vox0 = (wave * HH + h2) * HT_HW + wl;                 // tap (0,0,0), row tile 0
     const int b_off0 = l31 * 32 + ((hi ^ ((l31 >> 3) & 1)) << 4);      // column tile 0 (tile 1: + 1024; (out >> 3) & 1 is the same)
     struct Frag { bf16x8 a[TM][NPL]; bf16x8 b[2][NPL]; };
-    auto load_frags = [&](Frag& f, int dt, int dh, int dw, const unsigned char* wst) {
+    // The 27 taps of a slab are unrolled (round 5): a tap's row shift, its weight stage (27 = 0 mod 3: stage = tap mod 3) and the row tiles'
+    // strides are immediates of the ds_reads; what stays in registers is one byte offset per (tap column dw, plane) — the chunk swizzle
+    // follows the voxel's wx = wl + dw — and the W fragments' lane offset.
+    int aoff[3][NPL];
+#pragma unroll
+    for (int dw = 0; dw < 3; ++dw) {
         const int wx = wl + dw;
-        const int vbase = a_vox0 + (dt * HH + dh) * HT_HW + dw;
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
             int pc;
             if constexpr (NPL == 2) pc = (2 * p + hi) ^ ((wx >> 1) & 3);
             else { pc = 2 * p + hi + 3 * ((wx >> 1) & 1); pc = pc >= 6 ? pc - 6 : pc; }
+            aoff[dw][p] = (a_vox0 + dw) * RB + pc * 16;
+        }
+    }
+    auto load_frags = [&](Frag& f, auto tap_c) {
+        constexpr int TAP = decltype(tap_c)::value, dt = TAP / 9, dh = (TAP / 3) % 3, dw = TAP % 3;
+        const unsigned char* wst = wring + (TAP % NWS) * WST;
+#pragma unroll
+        for (int p = 0; p < NPL; ++p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                f.a[i][p] = *reinterpret_cast<const bf16x8*>(halo + (vbase + 2 * i * HT_HW) * RB + pc * 16);
+                f.a[i][p] = *reinterpret_cast<const bf16x8*>(halo + aoff[dw][p] + ((dt * HH + dh) * HT_HW + 2 * i * HT_HW) * RB);
 #pragma unroll
             for (int j = 0; j < 2; ++j) f.b[j][p] = *reinterpret_cast<const bf16x8*>(wst + p * 2048 + j * 1024 + b_off0);
         }
@@ -935,79 +987,73 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
 
     // prologue: halo of slab 0, weight stages 0 and 1; fragments of step 0
     fill_halo(0);
-    fill_w(0);
-    fill_w(1);
+    fill_w(0, 0);
+    fill_w(1, 1);
     __builtin_amdgcn_s_waitcnt(0x0f70);
     __syncthreads();
     // three planes: 64 accumulator registers leave room for the fragments of TWO steps (those of step q+1 are read under the MFMAs
     // of step q); two planes: 128 accumulator registers, one fragment set, read at the top of its step (the co-resident block covers)
     constexpr bool PREFETCH = NPL == 3;
-    Frag f0, f1;
-    if constexpr (PREFETCH) load_frags(f0, 0, 0, 0, wring);
+    static_assert(NWS == 3, "27 taps = 0 mod the weight ring: a tap's stage is a constant");
+    Frag f[2];
+    using Tap0 = std::integral_constant<int, 0>;
+    if constexpr (PREFETCH) load_frags(f[0], Tap0{});
 
     // step q = 27 slab + tap.  Top of step q: weight stage q+1 has landed (issued a step ago) -> barrier -> stage q+2 is issued into the
     // slot stage q-1 vacated (its last read was the prefetch of step q-1's fragments, during step q-2).  The MFMAs of step q run on
     // registers; the fragments of step q+1 are read meanwhile.  On the last tap of a slab the halo tile is refilled for the next slab:
     // every wave has finished reading it (its last reads were the prefetch of THIS step), the refill is issued behind the barrier, the
     // step's MFMAs run while it is in flight, and only then do the waves wait and read the next step's fragments from the new tile.
-    int dt = 0, dh = 0, dw = 0, slab = 0;
-    auto step = [&](int q, const Frag& cur, Frag& nxt) {
-        __builtin_amdgcn_s_waitcnt(0x0070);                 // vmcnt(0) lgkmcnt(0): this wave's DMA landed, its fragment reads returned
-        __builtin_amdgcn_s_barrier();
-        if (q + 2 < NSTEP) fill_w(q + 2);
-        // position of step q+1
-        int ndw = dw + 1, ndh = dh, ndt = dt, nslab = slab;
-        if (ndw == 3) { ndw = 0; ++ndh; }
-        if (ndh == 3) { ndh = 0; ++ndt; }
-        const bool last_tap = ndt == 3;
-        if (last_tap) { ndt = 0; ++nslab; }
-        const unsigned char* wnext = wring + ((q + 1) % NWS) * WST;
-        if (last_tap && nslab < NSLAB) {
-            fill_halo(nslab);
-            __builtin_amdgcn_sched_barrier(0);
-            mma_step(cur);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0x0f70);
+#pragma unroll 1
+    for (int slab_i = 0; slab_i < NSLAB; ++slab_i) {
+        // an opaque copy of the slab index for the address arithmetic: with the 27 steps unrolled, loop strength reduction otherwise keeps
+        // one 64-bit induction pointer per DMA site alive across the loop (+ ~110 registers: spills)
+        int slab = slab_i;
+        asm volatile("" : "+s"(slab));
+        const bool more = slab_i + 1 < NSLAB;                    // wave-uniform
+        static_for<27>([&](auto tap_c) {
+            constexpr int TAP = decltype(tap_c)::value;
+            using Next = std::integral_constant<int, (TAP + 1) % 27>;
+            __builtin_amdgcn_s_waitcnt(0x0070);                 // vmcnt(0) lgkmcnt(0): this wave's DMA landed, its fragment reads returned
             __builtin_amdgcn_s_barrier();
-            load_frags(nxt, ndt, ndh, ndw, wnext);
-        } else {
-            __builtin_amdgcn_sched_barrier(0);
-            if (q + 1 < NSTEP) load_frags(nxt, ndt, ndh, ndw, wnext);
-            mma_step(cur);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        dt = ndt; dh = ndh; dw = ndw; slab = nslab;
-    };
-    auto step1 = [&](int q, Frag& f) {       // no prefetch: the step's fragments are read at its top
-        __builtin_amdgcn_s_waitcnt(0x0070);
-        __builtin_amdgcn_s_barrier();
-        if (q + 2 < NSTEP) fill_w(q + 2);
-        load_frags(f, dt, dh, dw, wring + (q % NWS) * WST);
-        if (++dw == 3) { dw = 0; ++dh; }
-        if (dh == 3) { dh = 0; ++dt; }
-        if (dt == 3) {                           // last tap of the slab: once every wave holds its fragments the tile is refilled
-            dt = 0;
-            ++slab;
-            if (slab < NSLAB) {
-                __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
-                __builtin_amdgcn_s_barrier();
-                fill_halo(slab);
+            if (TAP + 2 < 27 || more) fill_w(slab * 27 + TAP + 2, (TAP + 2) % NWS);
+            if constexpr (PREFETCH) {
+                Frag& cur = f[TAP & 1];
+                Frag& nxt = f[(TAP & 1) ^ 1];
+                if constexpr (TAP == 26) {
+                    if (more) {
+                        fill_halo(slab + 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma_step(cur);
+                        __builtin_amdgcn_sched_barrier(0);
+                        __builtin_amdgcn_s_waitcnt(0x0f70);
+                        __builtin_amdgcn_s_barrier();
+                        load_frags(f[0], Tap0{});               // (27 is odd: the next slab starts on set 0 again, read after this step's MFMAs)
+                    } else {
+                        __builtin_amdgcn_sched_barrier(0);
+                        mma_step(cur);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+                    __builtin_amdgcn_sched_barrier(0);
+                    load_frags(nxt, Next{});
+                    mma_step(cur);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {       // no prefetch: the step's fragments are read at its top
+                load_frags(f[0], tap_c);
+                if constexpr (TAP == 26) {
+                    if (more) {                  // last tap of the slab: once every wave holds its fragments the tile is refilled
+                        __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
+                        __builtin_amdgcn_s_barrier();
+                        fill_halo(slab + 1);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                mma_step(f[0]);
+                __builtin_amdgcn_sched_barrier(0);
             }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mma_step(f);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    if constexpr (PREFETCH) {
-#pragma unroll 1
-        for (int q = 0; q + 1 < NSTEP; q += 2) {
-            step(q, f0, f1);
-            step(q + 1, f1, f0);
-        }
-        if constexpr (NSTEP & 1) step(NSTEP - 1, f0, f1);
-    } else {
-#pragma unroll 1
-        for (int q = 0; q < NSTEP; ++q) step1(q, f0);
+        });
     }
     __syncthreads();      // slabs overlay the halo tile and the weight ring
 

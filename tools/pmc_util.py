@@ -16,14 +16,18 @@ import tempfile
 ap = argparse.ArgumentParser()
 ap.add_argument("--out", default="profiles/util.json")
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--script", default=None, help="another script of this repo to run instead of bench.py (its arguments after --), e.g. tools/vae_bench.py")
 args, extra = ap.parse_known_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 res = collections.defaultdict(dict)
 for counter in ("MfmaUtil", "LdsUtil", "VALUBusy", "MemUnitStalled"):
     d = tempfile.mkdtemp(prefix=f"pmc_{counter}_", dir=os.path.join(root, "gpurun_out"))
-    cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
-           "python3", os.path.join(root, "bench.py"), "--steps", str(args.steps), "--warmup", "1",
-           "--no-cpu-baseline", "--no-roofline", "--no-alt", "--split-streams", "0"] + [e for e in extra if e != "--"]
+    cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "--", "python3"]
+    if args.script:
+        cmd += [os.path.join(root, args.script)] + [e for e in extra if e != "--"]
+    else:
+        cmd += [os.path.join(root, "bench.py"), "--steps", str(args.steps), "--warmup", "1",
+                "--no-cpu-baseline", "--no-roofline", "--no-alt", "--split-streams", "0"] + [e for e in extra if e != "--"]
     r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     if r.returncode:
         print(f"pass {counter} failed (rc {r.returncode})")
