@@ -87,8 +87,11 @@ for v in AVD_LAB_NODMA AVD_LAB_NOLDS AVD_LAB_NOSTORE; do
 done
 
 step "VAE decode timings, end to end, soak"
-for m in f32 bf16x3 f16x2; do timeout -k 10 200 python3 tools/vae_bench.py --matmul $m 2>&1 | grep -v amdgpu.ids >> $OUT/vae_decode.txt; done
-for m in bf16x3 f16x2; do timeout -k 10 200 python3 tools/vae_bench.py --matmul $m --lat 0 2>&1 | grep -v amdgpu.ids >> $OUT/vae_decode.txt; done      # rounds 1-4: 64-channel first conv
+for m in f32 bf16x3 f16x2; do timeout -k 10 200 python3 tools/vae_bench.py --matmul $m --power 3 2>&1 | grep -v amdgpu.ids >> $OUT/vae_decode.txt; done
+for m in bf16x3 f16x2; do AVD_VAE_FOLD=0 timeout -k 10 200 python3 tools/vae_bench.py --matmul $m --power 3 2>&1 | grep -v amdgpu.ids | sed "s/^\[$m\]/[$m, fold 0]/" >> $OUT/vae_decode.txt; done      # fp32 activations between the kernels
+for m in bf16x3 f16x2; do AVD_VAE_FOLD=0 timeout -k 10 200 python3 tools/vae_bench.py --matmul $m --lat 0 2>&1 | grep -v amdgpu.ids | sed "s/, lat 0\]/, lat 0, fold 0]/" >> $OUT/vae_decode.txt; done      # rounds 1-4: 64-channel first conv
+timeout -k 10 200 python3 tools/vae_bench.py --matmul bf16x3 --batch 8 2>&1 | grep -v amdgpu.ids >> $OUT/vae_decode.txt
+timeout -k 10 300 python3 tools/pmc_util.py --script tools/vae_bench.py --out gpurun_out/$TAG/util_vae3.json -- --matmul bf16x3 --iters 2 > $OUT/util_vae3.txt 2>&1 || echo "vae util failed"
 timeout -k 10 200 python3 tools/vae_bench.py --matmul f16x2 --batch 8 2>&1 | grep -v amdgpu.ids >> $OUT/vae_decode.txt
 timeout -k 10 600 python3 tools/e2e_bench.py > $OUT/e2e.txt 2>&1 || echo "e2e failed"
 step "  e2e done"
