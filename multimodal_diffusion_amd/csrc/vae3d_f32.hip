@@ -866,7 +866,6 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
     // per-lane offsets computed once, a scalar base per row (9 rows per wave, scalar unit), nothing else per refill.  (Rounds 3-4 cut the image into
     // 1-KiB pieces whatever the rows: ~40 vector instructions of index arithmetic per piece, 16 pieces per wave and slab — with the
     // per-step address arithmetic a third of the kernel's issue slots, VALUBusy 29 %.)
-    // Two planes: pieces of 64 consecutive chunks, lane -> (voxel, physical chunk) -> source address.
     constexpr bool ROWFILL = NPL == 3;
     constexpr int HROWS = (HT_T + 2) * HH, RPW = (HROWS + 3) / 4, ROWCH = HT_HW * NCH;      // 36 rows, 9 per wave, 108 chunks per row
     [[maybe_unused]] int hsrc[2];
@@ -882,6 +881,23 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
             int ww = w0 + wx;
             ww = ww < Wp ? ww : Wp - 1;             // ragged tiles: clamped to the buffer (those voxels only feed outputs that are never stored)
             hsrc[k2] = ww * XROWB + (c >> 1) * XPLS + (c & 1) * 16;
+        }
+    }
+    constexpr int SCH = HH * HT_HW * NCH, SNI = (SCH + 63) / 64, SPW = (SNI + 3) / 4;      // chunks / DMA instructions of one t-slice, per wave
+    [[maybe_unused]] int hsl[SPW];
+    if constexpr (!ROWFILL) {
+        static_assert((HT_T + 2) * SCH * 16 <= Cf::HALO_B && (SPW - 1) * 4 * 64 + 3 * 64 + 63 < SCH + 64, "t-slice fill: only the last instruction is partial");
+#pragma unroll
+        for (int k = 0; k < SPW; ++k) {
+            int ci = (wave + 4 * k) * 64 + lane;
+            ci = ci < SCH ? ci : SCH - 1;
+            const int hv = ci / NCH, pc = ci - hv * NCH;
+            const int hy = hv / HT_HW, wx = hv - hy * HT_HW;
+            const int c = pc ^ ((wx >> 1) & 3);
+            int hh = h0 + hy, ww = w0 + wx;        // ragged tiles: clamped to the buffer (those voxels only feed outputs that are never stored)
+            hh = hh < Hp ? hh : Hp - 1;
+            ww = ww < Wp ? ww : Wp - 1;
+            hsl[k] = (hh * Wp + ww) * XROWB + (c >> 1) * XPLS + (c & 1) * 16;
         }
     }
     auto fill_halo = [&](int slab) {
@@ -901,23 +917,20 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
                 }
             }
         } else {
-#pragma unroll 1
-        for (int q = wave; q < Cf::NPIECE; q += 4) {
-            int L = q * 64 + lane;
-            L = L < Cf::HVOX * NCH ? L : Cf::HVOX * NCH - 1;        // tail of the last piece: any valid chunk (lands past the image)
-            const int hv = L / NCH, pc = L - hv * NCH;
-            const int tz = hv / (HH * HT_HW), rem = hv - tz * (HH * HT_HW);
-            const int hy = rem / HT_HW, wx = rem - hy * HT_HW;
-            const int c = pc ^ ((wx >> 1) & 3);
-            // padded coordinates, clamped to the buffer for ragged tiles (those voxels only feed outputs that are never stored)
-            int tt = t0 + tz, hh = h0 + hy, ww = w0 + wx;
-            tt = tt < g.T + 2 ? tt : g.T + 1;
-            hh = hh < Hp ? hh : Hp - 1;
-            ww = ww < Wp ? ww : Wp - 1;
-            const int64_t pv = (((int64_t)smp * (g.T + 2) + tt) * Hp + hh) * Wp + ww;
-            __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(g.X3 + pv * XROWB + (c >> 1) * XPLS + slab * 32 + (c & 1) * 16),
-                                             AVD_LDS_PTR(halo + q * 1024), 16, 0, 0);
-        }
+            // two planes: by t-slices of the tile — HH x 18 voxels x 4 chunks = 720 consecutive chunks = 12 DMA instructions, three per wave,
+            // whose lane -> (hy, wx, chunk) -> source offset map does not depend on the slice: three per-lane offsets, a scalar base per slice
+#pragma unroll
+            for (int tz = 0; tz < HT_T + 2; ++tz) {
+                int tt = t0 + tz;
+                tt = tt < g.T + 2 ? tt : g.T + 1;
+                const unsigned char* src = g.X3 + (((int64_t)smp * (g.T + 2) + tt) * Hp * Wp) * XROWB + slab * 32;
+#pragma unroll
+                for (int k = 0; k < SPW; ++k) {
+                    const int j = wave + 4 * k;
+                    if (j < SNI && (k + 1 < SPW || j * 64 + lane < SCH))
+                        __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(src + hsl[k]), AVD_LDS_PTR(halo + (tz * SCH + j * 64) * 16), 16, 0, 0);
+                }
+            }
         }
     };
     // ---- weight stage kt = 27 slab + tap: NPL pieces of 2 KiB... 1-KiB pieces 2 NPL, dealt over the four waves
