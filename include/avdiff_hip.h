@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define AVD_ABI_VERSION 6
+#define AVD_ABI_VERSION 7
 
 #define AVD_OK            0
 #define AVD_EINVAL       -1   /* bad shape / argument (reference: AssertionError / ValueError) */
@@ -408,6 +408,10 @@ typedef struct {
     const float* conv0_lat_btab;       /* [64 border classes][base]: sum over the taps INSIDE the volume of sum_c conv_w[0][out][c][tap] * from_lat_b[c];
                                         * class bits: t-1 inside, t+1 inside, h-1, h+1, w-1, w+1 (the conv zero-pads u = from_lat(.), not its bias) */
     float conv0_lat_w_scale;           /* conv_terms 3: scale of the conv0_lat_w3 image */
+    /* ABI 7 (round 5): 1 = conv0_lat_w3 is the PACKED image (Cv <= 8): "tap" s of the [out][27][base] tensor handed to avd_conv3_weight_*
+     * holds the composite weights of tap 2 s in channels 0 .. 7 and of tap 2 s + 1 in channels 8 .. 15 (s = 0 .. 13; tap 27 = zeros) — the
+     * kernel then runs 14 k-steps of two taps instead of 27 of one whose upper 8 channels are zero.  0 = one tap per step. */
+    int conv0_lat_packed;
 } avd_vae_decode_desc;
 /* weight image of one 3x3x3 64->64 convolution for the split-operand decoders: w_tap_major is [out][kt][kh][kw][in] fp32 */
 int64_t avd_conv3_weight_bytes(void);

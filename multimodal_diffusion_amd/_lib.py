@@ -74,7 +74,8 @@ class VaeDecodeDesc(C.Structure):
                 ("to_img_w", C.c_void_p), ("to_img_b", C.c_void_p),
                 ("conv_w3", C.POINTER(C.c_void_p)), ("conv_terms", C.c_int),
                 ("conv_w_scale", C.POINTER(C.c_float)), ("conv_a_scale", C.POINTER(C.c_float)),
-                ("conv0_lat_w3", C.c_void_p), ("conv0_lat_btab", C.c_void_p), ("conv0_lat_w_scale", C.c_float)]
+                ("conv0_lat_w3", C.c_void_p), ("conv0_lat_btab", C.c_void_p), ("conv0_lat_w_scale", C.c_float),
+                ("conv0_lat_packed", C.c_int)]
 
 
 class VaeEncodeDesc(C.Structure):
@@ -88,7 +89,7 @@ class VaeEncodeDesc(C.Structure):
                 ("conv_w_scale", C.POINTER(C.c_float)), ("conv_a_scale", C.POINTER(C.c_float))]
 
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); must list every symbol include/avdiff_hip.h declares

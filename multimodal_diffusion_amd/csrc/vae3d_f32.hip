@@ -838,7 +838,11 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
     using Cf = HaloCfg<TERMS>;
     constexpr int NPL = Cf::NPL, TH = Cf::TH, HH = Cf::HH, TM = Cf::TM, NCH = Cf::NCH, RB = Cf::RB, NWS = Cf::NWS, WST = Cf::WST;
     constexpr bool F16 = TERMS == 3;
-    constexpr bool LAT = NSLAB == 1;
+    // NSLAB 0: the latent-composed conv with TWO taps per k-step (lat_ch <= 8): the 32x32x16 MFMA's k-half is a tap, not the upper half of a
+    // 16-channel slab that is zero anyway — lanes of k-half 0 read the voxel of tap 2 s, lanes of k-half 1 the voxel of tap 2 s + 1, both
+    // its channels 0 .. 7; the weight image holds [tap 2 s: 8 ch | tap 2 s + 1: 8 ch] per stage (the host packs it): 14 steps instead of 27
+    constexpr bool LAT = NSLAB <= 1, PK = NSLAB == 0;
+    constexpr int NSL = LAT ? 1 : NSLAB, NTAP = PK ? 14 : 27;
     constexpr int XROWB = LAT ? L16_ROWB : A3_ROWB, XPLS = LAT ? 32 : 128;      // bytes per voxel / per plane of the input image
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     unsigned char* halo = smem3;
@@ -974,14 +978,38 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
             aoff[dw][p] = (a_vox0 + dw) * RB + pc * 16;
         }
     }
+    // packed taps: step S carries taps 2 S (k-half 0) and 2 S + 1 (k-half 1).  The second tap is the next one in the row (types 0, 1), the first
+    // of the next row (type 2) or of the next t-slice (type 3): per type and plane one per-lane offset, hi ? (tap B's) : (tap A's), both on
+    // chunk (plane, k-half 0) of their voxel; the immediate is tap A's row
+    // (type 4: tap 26 has no partner — its k-half 1 meets zero weights, and reads tap 26's own voxel: finite data, never LDS nobody wrote)
+    [[maybe_unused]] int pb[5][NPL];
+    if constexpr (PK) {
+#pragma unroll
+        for (int ty = 0; ty < 5; ++ty) {
+            const int dwa = ty < 2 ? ty : 2, dwb = ty < 2 ? ty + 1 : ty == 4 ? 2 : 0;
+            const int rows = ty == 2 ? 1 : ty == 3 ? HH - 2 : 0;            // tap B's row relative to tap A's
+            const int dwl = hi ? dwb : dwa, wx = wl + dwl;
+#pragma unroll
+            for (int p = 0; p < NPL; ++p) {
+                int pc;
+                if constexpr (NPL == 2) pc = (2 * p) ^ ((wx >> 1) & 3);
+                else { pc = 2 * p + 3 * ((wx >> 1) & 1); pc = pc >= 6 ? pc - 6 : pc; }
+                pb[ty][p] = (a_vox0 + dwl + (hi ? rows * HT_HW : 0)) * RB + pc * 16;
+            }
+        }
+    }
     auto load_frags = [&](Frag& f, auto tap_c) {
-        constexpr int TAP = decltype(tap_c)::value, dt = TAP / 9, dh = (TAP / 3) % 3, dw = TAP % 3;
+        constexpr int TAP = decltype(tap_c)::value;
         const unsigned char* wst = wring + (TAP % NWS) * WST;
+        constexpr int TA = PK ? 2 * TAP : TAP, dt = TA / 9, dh = (TA / 3) % 3, dw = TA % 3;
+        constexpr int ty = dw < 2 ? dw : TA == 26 ? 4 : (dh < 2 ? 2 : 3);
 #pragma unroll
         for (int p = 0; p < NPL; ++p) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                f.a[i][p] = *reinterpret_cast<const bf16x8*>(halo + aoff[dw][p] + ((dt * HH + dh) * HT_HW + 2 * i * HT_HW) * RB);
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (PK) f.a[i][p] = *reinterpret_cast<const bf16x8*>(halo + pb[ty][p] + ((dt * HH + dh) * HT_HW + 2 * i * HT_HW) * RB);
+                else f.a[i][p] = *reinterpret_cast<const bf16x8*>(halo + aoff[dw][p] + ((dt * HH + dh) * HT_HW + 2 * i * HT_HW) * RB);
+            }
 #pragma unroll
             for (int j = 0; j < 2; ++j) f.b[j][p] = *reinterpret_cast<const bf16x8*>(wst + p * 2048 + j * 1024 + b_off0);
         }
@@ -1018,22 +1046,22 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
     // every wave has finished reading it (its last reads were the prefetch of THIS step), the refill is issued behind the barrier, the
     // step's MFMAs run while it is in flight, and only then do the waves wait and read the next step's fragments from the new tile.
 #pragma unroll 1
-    for (int slab_i = 0; slab_i < NSLAB; ++slab_i) {
+    for (int slab_i = 0; slab_i < NSL; ++slab_i) {
         // an opaque copy of the slab index for the address arithmetic: with the 27 steps unrolled, loop strength reduction otherwise keeps
         // one 64-bit induction pointer per DMA site alive across the loop (+ ~110 registers: spills)
         int slab = slab_i;
         asm volatile("" : "+s"(slab));
-        const bool more = slab_i + 1 < NSLAB;                    // wave-uniform
-        static_for<27>([&](auto tap_c) {
+        const bool more = slab_i + 1 < NSL;                      // wave-uniform
+        static_for<NTAP>([&](auto tap_c) {
             constexpr int TAP = decltype(tap_c)::value;
-            using Next = std::integral_constant<int, (TAP + 1) % 27>;
+            using Next = std::integral_constant<int, (TAP + 1) % NTAP>;
             __builtin_amdgcn_s_waitcnt(0x0070);                 // vmcnt(0) lgkmcnt(0): this wave's DMA landed, its fragment reads returned
             __builtin_amdgcn_s_barrier();
-            if (TAP + 2 < 27 || more) fill_w(slab * 27 + TAP + 2, (TAP + 2) % NWS);
+            if (TAP + 2 < NTAP || more) fill_w(slab * NTAP + TAP + 2, (TAP + 2) % NWS);
             if constexpr (PREFETCH) {
                 Frag& cur = f[TAP & 1];
                 Frag& nxt = f[(TAP & 1) ^ 1];
-                if constexpr (TAP == 26) {
+                if constexpr (TAP == NTAP - 1) {
                     if (more) {
                         fill_halo(slab + 1);
                         __builtin_amdgcn_sched_barrier(0);
@@ -1055,7 +1083,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
                 }
             } else {       // no prefetch: the step's fragments are read at its top
                 load_frags(f[0], tap_c);
-                if constexpr (TAP == 26) {
+                if constexpr (TAP == NTAP - 1) {
                     if (more) {                  // last tap of the slab: once every wave holds its fragments the tile is refilled
                         __builtin_amdgcn_s_waitcnt(0xc07f);     // lgkmcnt(0)
                         __builtin_amdgcn_s_barrier();
@@ -1211,8 +1239,25 @@ static LdsAttr g_conv3_lat_attr[2];
 // to_img from per-group partial sums of conv 1's epilogue; 0 = fp32 activations between the kernels (rounds 1-4)
 int g_vae_fold = getenv("AVD_VAE_FOLD") ? atoi(getenv("AVD_VAE_FOLD")) : 1;
 static LdsAttr g_conv3_fold_attr[3];
-static int conv3_launch(Conv3Args a3, int terms, int B, double flops, hipStream_t st, bool lat = false, int out_mode = 0) {
+template <int TERMS, int NSLAB, int OUT>
+static int conv3_launch_as(const Conv3Args& a3, int B, double flops, hipStream_t st, LdsAttr& attr, const char* what) {
+    auto kern = conv3d_k3_bf16x3_kernel<TERMS, NSLAB, OUT>;
+    if (int rc = attr.ensure(reinterpret_cast<const void*>(kern), HaloCfg<TERMS>::LDS, what)) return rc;
+    static const int tag = prof_tag_id("conv3d_k3_bf16x3_kernel<%d, %d, %d>", TERMS, NSLAB, OUT);
+    ProfScope prof(tag, flops, st);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(B * conv3_blocks<TERMS>(a3.T, a3.H, a3.W))), dim3(256), HaloCfg<TERMS>::LDS, st, a3);
+    AVD_CHECK_LAUNCH(what);
+    return AVD_OK;
+}
+static LdsAttr g_conv3_pk_attr[3];
+static int conv3_launch(Conv3Args a3, int terms, int B, double flops, hipStream_t st, bool lat = false, int out_mode = 0, bool packed = false) {
     a3.tiles = conv3_tiles(terms, a3.T, a3.H, a3.W);
+    if (lat && packed) {       // two taps per k-step (conv3d_k3_bf16x3_kernel<.., 0, ..>): 14 / 27 of the MFMA work
+        AVD_REQUIRE(a3.btab && out_mode != 2 && (out_mode == 0 || (terms != 3 && a3.X3out)), AVD_EINVAL, "conv3d (latent-composed, packed taps): bad arguments");
+        if (terms == 3) return conv3_launch_as<3, 0, 0>(a3, B, flops * 14.0 / 27.0, st, g_conv3_pk_attr[0], "conv3d f16x2 (latent, packed taps)");
+        if (out_mode == 1) return conv3_launch_as<6, 0, 1>(a3, B, flops * 14.0 / 27.0, st, g_conv3_pk_attr[1], "conv3d bf16x3 (latent, packed taps, image out)");
+        return conv3_launch_as<6, 0, 0>(a3, B, flops * 14.0 / 27.0, st, g_conv3_pk_attr[2], "conv3d bf16x3 (latent, packed taps)");
+    }
     if (out_mode != 0) {
         AVD_REQUIRE((out_mode == 1 && terms != 3 && lat && a3.X3out) || (out_mode == 2 && !lat && a3.P && a3.wimg_g), AVD_EINVAL, "conv3d (folded route): bad arguments");
         if (out_mode == 2 && terms == 3) {
@@ -1386,7 +1431,7 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
         AVD_CHECK_LAUNCH("toimg_from_p");
         return AVD_OK;
     };
-    if (lat && !h2 && g_vae_fold && p.fold_img && d->conv0_lat_btab && d->Cv <= 16 && padvox * L16_ROWB <= p.y_b) {
+    if (lat && !h2 && g_vae_fold && p.fold_img && d->conv0_lat_btab && d->Cv <= (d->conv0_lat_packed ? 8 : 16) && padvox * L16_ROWB <= p.y_b) {
         // ---- folded route: upsample(z) -> L | conv 0 (L -> act3 image of GELU) | stats | conv 1 with GN 0 folded in (-> to_img partials) |
         // stats | to_img.  L and the partials P share the region the fp32 activations Y have on the other routes.
         unsigned char* Lm = reinterpret_cast<unsigned char*>(Y);
@@ -1405,7 +1450,7 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
         {
             Conv3Args a3{Lm, static_cast<const unsigned char*>(d->conv0_lat_w3), d->conv_b[0], nullptr, part, p.T, p.H, p.W, p.tiles, 1.f, nullptr,
                          d->conv0_lat_btab, X3, nullptr, nullptr, 0, 0};
-            if (int rc = conv3_launch(a3, 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * 16, st, true, 1)) return rc;
+            if (int rc = conv3_launch(a3, 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * 16, st, true, 1, d->conv0_lat_packed != 0)) return rc;
         }
         if (int rc = gn_finalize(part, fin, stats, B, gn_tiles, (double)p.THW * (VC / VG), d->gn_eps, st)) return rc;
         {
@@ -1427,6 +1472,7 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
     }
     if (lat) {
         AVD_REQUIRE(d->conv0_lat_btab && d->Cv <= 16, AVD_EINVAL, "vae_decode: the latent-composed first conv needs its bias table and Cv <= 16");
+        AVD_REQUIRE(!d->conv0_lat_packed || d->Cv <= 8, AVD_EINVAL, "vae_decode: conv0_lat_packed needs Cv <= 8");
         AVD_REQUIRE(!h2 || (d->conv0_lat_w_scale > 0.f && d->conv0_lat_w_scale < __builtin_inff()), AVD_EINVAL,
                     "vae_decode: conv0_lat_w_scale must be positive and finite");
         if (int rc = zero_halo(Xp, B, p.T, p.H, p.W, L16_ROWB, st)) return rc;
@@ -1509,7 +1555,8 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
                 a3.P = Pp;
                 a3.wimg_g = wg;
             }
-            if (int rc = conv3_launch(a3, h2 ? 3 : 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * (lat0 ? 16 : VC), st, lat0, p_out ? 2 : 0)) return rc;
+            if (int rc = conv3_launch(a3, h2 ? 3 : 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * (lat0 ? 16 : VC), st, lat0, p_out ? 2 : 0,
+                                      lat0 && d->conv0_lat_packed != 0)) return rc;
             gn_tiles = conv3_tiles(h2 ? 3 : 6, p.T, p.H, p.W);
             // the act3 buffer of the next conv overlays the latent image: its halo is zeroed now that conv 0 has read the latent image
             if (lat0 && blk + 1 < d->n_blocks)

@@ -80,6 +80,7 @@ class VideoVAE(nn.Module):
         # split-operand modes: run the first decoder convolution on upsample(z) with composite weights (8 input channels instead of 64;
         # _lat_composite) instead of from_lat -> upsample -> 64-channel convolution.  Same operator up to fp32 rounding.
         self.lat_composed = True
+        self.lat_packed = True          # lat_ch <= 8: two taps per k-step of the composed first conv (14 steps instead of 27)
 
     @classmethod
     def from_config(cls, d: Dict) -> "VideoVAE":
@@ -254,7 +255,7 @@ class VideoVAE(nn.Module):
         the conv zero-pads from_lat's OUTPUT, so from_lat's bias reaches a voxel only through the taps inside the volume — one table row
         per combination of (t-1, t+1, h-1, h+1, w-1, w+1 inside).  Composed in fp64, rounded to fp32 once; rebuilt when a parameter changes."""
         w1, wf, bf = self.dec_net[0][0].weight, self.from_lat.weight, self.from_lat.bias
-        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in (w1, wf, bf)) + (f16x2,)
+        key = tuple((p.data_ptr(), p._version, str(p.device)) for p in (w1, wf, bf)) + (f16x2, self.lat_packed)
         hit = self._conv3.get(("lat", f16x2))
         if hit is None or hit[0] != key:
             D, Cv = self.cfg.dec_base, self.cfg.lat_ch
@@ -262,7 +263,14 @@ class VideoVAE(nn.Module):
             Wf = wf.detach().double().reshape(D, Cv)                           # [c, in]
             comp = torch.einsum("octhw,ci->othwi", W1, Wf)                     # [out, kt, kh, kw, in]
             src = torch.zeros(D, 3, 3, 3, D, device=w1.device, dtype=torch.float32)
-            src[..., :Cv] = comp.float()
+            packed = Cv <= 8 and self.lat_packed
+            if packed:
+                # two taps per k-step (ABI 7, conv0_lat_packed): "tap" s of the tensor carries tap 2 s in channels 0 .. 7, tap 2 s + 1 in 8 .. 15
+                c27 = torch.zeros(D, 28, 8, device=w1.device, dtype=torch.float32)
+                c27[:, :27, :Cv] = comp.float().reshape(D, 27, Cv)
+                src.view(D, 27, D)[:, :14, :16] = c27.view(D, 14, 16)
+            else:
+                src[..., :Cv] = comp.float()
             bt = torch.einsum("octhw,c->othw", W1, bf.detach().double())       # [out, kt, kh, kw]: bias through one tap
             tab = torch.zeros(64, D, device=w1.device, dtype=torch.float64)
             for cls in range(64):
@@ -284,9 +292,9 @@ class VideoVAE(nn.Module):
                 L.check(L.lib().avd_conv3_weight_f16x2_f32(src.data_ptr(), img.data_ptr(), scale, L.stream_ptr(w1.device)))
             else:
                 L.check(L.lib().avd_conv3_weight_f32(src.data_ptr(), img.data_ptr(), L.stream_ptr(w1.device)))
-            self._conv3[("lat", f16x2)] = (key, img, tab, scale)
+            self._conv3[("lat", f16x2)] = (key, img, tab, scale, packed)
         hit = self._conv3[("lat", f16x2)]
-        return hit[1], hit[2], hit[3]
+        return hit[1], hit[2], hit[3], hit[4]
 
     def _tap_major(self, i: int) -> torch.Tensor:
         w = self.dec_net[i][0].weight
@@ -336,7 +344,8 @@ class VideoVAE(nn.Module):
         if self.matmul != "f32":
             self._split_conv_desc(d, keep, nb, 0, False, (self.cfg.dec_base // 8) * T * H * W)
             if self.lat_composed and Cv <= 16 and self.cfg.dec_base == 64:
-                img, tab, sc = self._lat_composite(self.matmul == "f16x2")
+                img, tab, sc, packed = self._lat_composite(self.matmul == "f16x2")
+                d.conv0_lat_packed = 1 if packed else 0
                 keep.extend([img, tab])
                 d.conv0_lat_w3, d.conv0_lat_btab, d.conv0_lat_w_scale = img.data_ptr(), tab.data_ptr(), float(sc) if sc else 1.0
         # chunk the batch so the NDHWC activations (2 x 0.85 GB per 48x256x256 sample) stay inside the budget

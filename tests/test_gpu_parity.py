@@ -1003,19 +1003,20 @@ def test_vae_decode_latent_composed_first_conv(dev, mode):
     from multimodal_diffusion_amd import _lib as L
     g = load_golden("g11_vae_decode.npz")
     outs = {}
-    for lat in (False, True):
+    for lat in (False, True, "one tap per step"):           # True: two taps per k-step (lat_ch = 8: ABI 7 conv0_lat_packed), the default
         vae = _vae_from(split_weights(g)["w"], dev)
-        vae.matmul, vae.lat_composed = mode, lat
+        vae.matmul, vae.lat_composed, vae.lat_packed = mode, bool(lat), lat is True
         L.prof_enable(True)
         x = vae.decode(G(g["z"], dev)).cpu()
         torch.cuda.synchronize()
         L.prof_enable(False)
         used = {k for k, v in L.prof_report().items() if v[0] > 0}
-        assert any(re.match(r"conv3d_k3_bf16x3_kernel<\d, 1, \d>", k) for k in used) == lat, used
-        assert ("upsample_lat16_kernel" in used) == lat and ("fromlat_kernel" in used) == (not lat), used
+        assert any(re.match(r"conv3d_k3_bf16x3_kernel<\d, %s, \d>" % ("0" if lat is True else "1"), k) for k in used) == bool(lat), used
+        assert ("upsample_lat16_kernel" in used) == bool(lat) and ("fromlat_kernel" in used) == (not lat), used
         outs[lat] = (x, vae.decode(G(g["z"][:1], dev), out_size=(6, 24, 40)).cpu())
-    assert rel_err(outs[True][0], g["x"]) < TOL and rel_err(outs[True][1], g["x_odd"]) < TOL
-    assert rel_err(outs[True][0], outs[False][0]) < 2e-5 and rel_err(outs[True][1], outs[False][1]) < 2e-5
+    for lat in (True, "one tap per step"):
+        assert rel_err(outs[lat][0], g["x"]) < TOL and rel_err(outs[lat][1], g["x_odd"]) < TOL
+        assert rel_err(outs[lat][0], outs[False][0]) < 2e-5 and rel_err(outs[lat][1], outs[False][1]) < 2e-5
     # a decoder whose from_lat bias dominates: the border table carries real weight (tiny volume: every voxel class occurs)
     W = R.synth_vae_decoder(seed=5, n_blocks=2)
     W["from_lat.bias"] = W["from_lat.bias"] * 0 + torch.linspace(-3.0, 3.0, 64)
@@ -1054,7 +1055,7 @@ def test_vae_decode_folded_route(dev, mode):
             torch.cuda.synchronize()
             L.prof_enable(False)
             used = {k for k, v in L.prof_report().items() if v[0] > 0}
-            want = {"conv3d_k3_bf16x3_kernel<6, 1, 1>", "conv3d_k3_bf16x3_kernel<6, 4, 2>", "toimg_from_p_kernel"} if mode == "bf16x3" else \
+            want = {"conv3d_k3_bf16x3_kernel<6, 0, 1>", "conv3d_k3_bf16x3_kernel<6, 4, 2>", "toimg_from_p_kernel"} if mode == "bf16x3" else \
                    {"conv3d_k3_bf16x3_kernel<3, 4, 2>", "toimg_from_p_kernel"}
             assert (want <= used) == bool(fold), used
             assert ("gn_apply_toimg_kernel" in used) == (not fold) and ("gn_apply_pad3_kernel" in used) == (not fold or mode == "f16x2"), used

@@ -40,7 +40,7 @@ def test_header_symbols_exported_and_bound():
         assert hasattr(lib, name), f"{name} declared in include/avdiff_hip.h but not exported"
         assert name in L.SIGNATURES, f"{name} has no ctypes signature"
     assert set(L.SIGNATURES) <= declared, set(L.SIGNATURES) - declared
-    assert lib.avd_abi_version() == L.ABI_VERSION == 6
+    assert lib.avd_abi_version() == L.ABI_VERSION == 7
 
 
 def test_error_channel_without_gpu():
