@@ -1327,6 +1327,28 @@ def test_vae_decode_256_vs_oracle(dev):
     assert rel_err(x, ref) < TOL
 
 
+def test_vae_decode_512_routes_agree(dev):
+    """The C5 geometry's decode (one sample [1,8,12,64,64] -> [1,3,48,512,512]: 12.6 M voxels, 4.8 GB operand image): the default
+    route (composed + packed first conv, folded GroupNorm, to_img from partial sums) against the three-pass route with fp32 activations
+    between the kernels — same operator up to fp32 rounding, index arithmetic included at four times the headline volume."""
+    import multimodal_diffusion_amd as A
+    W = R.synth_vae_decoder(seed=9, n_blocks=2)
+    z = torch.randn(1, 8, 12, 64, 64, generator=torch.Generator().manual_seed(10)).to(dev)
+    outs = {}
+    try:
+        for route in ("default", "three passes"):
+            _tune("vae_fold", 1 if route == "default" else 0)
+            vae = A.VideoVAE(A.VideoVAEConfig()).eval()
+            vae.load_state_dict(W, strict=False)
+            vae.matmul, vae.lat_composed = "bf16x3", route == "default"
+            outs[route] = vae.to(dev).decode(z)
+            del vae
+    finally:
+        _tune("vae_fold", 1)
+    assert outs["default"].shape == (1, 3, 48, 512, 512) and bool(torch.isfinite(outs["default"]).all())
+    assert float((outs["default"] - outs["three passes"]).abs().max()) < 2e-5
+
+
 def test_add_mode_step_golden(dev, small_model):
     """next-4 pinned: trainer-style embedding (train/trainer.py:36-49) against the G15 fixture made by the reference's own
     helper definitions."""
