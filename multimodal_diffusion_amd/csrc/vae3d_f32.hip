@@ -795,6 +795,65 @@ __global__ __launch_bounds__(256) void upsample_lat16_kernel(const float* __rest
     }
 }
 
+// The same for lat_ch <= 8 from a channel-LAST copy of the latent (lat_cl8_kernel: [B, vol, 8], channels >= Cv zero): a thread's 8 neighbours
+// are 8 x two 16-byte loads instead of 64 four-byte ones, channels 8 .. 15 of the image are stored as zeros without going through the split.
+__global__ __launch_bounds__(256) void lat_cl8_kernel(const float* __restrict__ z, float* __restrict__ zt, int Cv, int vol, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one thread = one (sample, latent voxel)
+    if (i >= total) return;
+    const int64_t smp = i / vol, v = i - smp * vol;
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = c < Cv ? z[(smp * Cv + c) * vol + v] : 0.f;
+    *reinterpret_cast<f32x4*>(zt + i * 8) = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(zt + i * 8 + 4) = f32x4{o[4], o[5], o[6], o[7]};
+}
+template <bool F16>
+__global__ __launch_bounds__(256) void upsample_lat8_kernel(const float* __restrict__ zt, unsigned char* __restrict__ X16, int Tp, int Hp_, int Wp_,
+                                                            int T, int H, int W, float st, float sh, float sw, int64_t nvox,
+                                                            const float* __restrict__ sc_dev) {
+    const int64_t vox = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (vox >= nvox) return;
+    const int THW = T * H * W;
+    const int smp = (int)(vox / THW), v = (int)(vox % THW);
+    const int w = v % W, h = (v / W) % H, t = v / (W * H);
+    int t0, t1, h0, h1, w0, w1;
+    float tl0, tl1, hl0, hl1, wl0, wl1;
+    tri_src(t, st, Tp, t0, t1, tl0, tl1);
+    tri_src(h, sh, Hp_, h0, h1, hl0, hl1);
+    tri_src(w, sw, Wp_, w0, w1, wl0, wl1);
+    const float* b = zt + (int64_t)smp * Tp * Hp_ * Wp_ * 8;
+    const int o00 = (t0 * Hp_ + h0) * Wp_, o01 = (t0 * Hp_ + h1) * Wp_, o10 = (t1 * Hp_ + h0) * Wp_, o11 = (t1 * Hp_ + h1) * Wp_;
+    float o[8];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        auto at = [&](int row, int ww) { return *reinterpret_cast<const f32x4*>(b + (int64_t)(row + ww) * 8 + 4 * q); };
+        // the association of torch's CPU kernel (and of upsample_pad3_kernel)
+        const f32x4 r = tl0 * (hl0 * (wl0 * at(o00, w0) + wl1 * at(o00, w1)) + hl1 * (wl0 * at(o01, w0) + wl1 * at(o01, w1))) +
+                        tl1 * (hl0 * (wl0 * at(o10, w0) + wl1 * at(o10, w1)) + hl1 * (wl0 * at(o11, w0) + wl1 * at(o11, w1)));
+        o[4 * q] = r[0]; o[4 * q + 1] = r[1]; o[4 * q + 2] = r[2]; o[4 * q + 3] = r[3];
+    }
+    const int64_t pv = (((int64_t)smp * (T + 2) + t + 1) * (H + 2) + h + 1) * (W + 2) + w + 1;
+    unsigned char* dst = X16 + pv * L16_ROWB;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    if constexpr (F16) {
+        u32x4 Hh, Lo;
+        split8_h2(o, sc_dev[0], Hh, Lo);
+        *reinterpret_cast<u32x4*>(dst) = Hh;
+        *reinterpret_cast<u32x4*>(dst + 16) = zero;
+        *reinterpret_cast<u32x4*>(dst + 32) = Lo;
+        *reinterpret_cast<u32x4*>(dst + 48) = zero;
+    } else {
+        u32x4 Hh, Mi, Lo;
+        split8(o, Hh, Mi, Lo);
+        *reinterpret_cast<u32x4*>(dst) = Hh;
+        *reinterpret_cast<u32x4*>(dst + 16) = zero;
+        *reinterpret_cast<u32x4*>(dst + 32) = Mi;
+        *reinterpret_cast<u32x4*>(dst + 48) = zero;
+        *reinterpret_cast<u32x4*>(dst + 64) = Lo;
+        *reinterpret_cast<u32x4*>(dst + 80) = zero;
+    }
+}
+
 // conv 3x3x3 64 -> 64 + bias + GELU + GroupNorm partial statistics on the 16-bit matrix pipe — HALO-TILE kernel (round 3).
 // Rounds 1-2 ran this as an implicit GEMM that re-fetched the block's A tile from global memory for every tap (27 x), 12-24 MFMAs
 // per wave between barriers on a 64 x 32 wave tile: 0.30 of the matrix peak, a K stage of ~2,150 cycles of which ~770 were MFMA.
@@ -1323,6 +1382,33 @@ static int check_conv_terms(int terms, const float* w_scale, const float* a_scal
 
 static inline int64_t a256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
+// upsample(z) -> the latent-composed conv's input image: from a channel-last copy of the latent when lat_ch <= 8 (zt = scratch of B x vol x 8 floats)
+static int upsample_lat16(const float* z, float* zt, unsigned char* X16, int B, int Cv, int Tp, int Hp, int Wp, int T, int H, int W, bool f16,
+                          const float* sc_dev, hipStream_t st) {
+    const int64_t nvox = (int64_t)B * T * H * W;
+    const float fst = (float)Tp / (float)T, fsh = (float)Hp / (float)H, fsw = (float)Wp / (float)W;
+    if (Cv <= 8 && zt) {
+        const int vol = Tp * Hp * Wp;
+        const int64_t total = (int64_t)B * vol;
+        hipLaunchKernelGGL(lat_cl8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, z, zt, Cv, vol, total);
+        AVD_CHECK_LAUNCH("lat_cl8");
+        static const int tag = prof_tag_id("upsample_lat8_kernel");
+        ProfScope prof(tag, (double)nvox * L16_ROWB, st);
+        if (f16) hipLaunchKernelGGL(upsample_lat8_kernel<true>, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, zt, X16, Tp, Hp, Wp, T, H, W, fst, fsh, fsw, nvox, sc_dev);
+        else hipLaunchKernelGGL(upsample_lat8_kernel<false>, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, zt, X16, Tp, Hp, Wp, T, H, W, fst, fsh, fsw, nvox, nullptr);
+        AVD_CHECK_LAUNCH("upsample_lat8");
+        return AVD_OK;
+    }
+    static const int tag = prof_tag_id("upsample_lat16_kernel");
+    ProfScope prof(tag, (double)nvox * L16_ROWB, st);
+    if (f16) hipLaunchKernelGGL(upsample_lat16_kernel<true>, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, z, X16, Cv, Tp, Hp, Wp, T, H, W, fst, fsh, fsw, nvox, sc_dev);
+    else hipLaunchKernelGGL(upsample_lat16_kernel<false>, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, z, X16, Cv, Tp, Hp, Wp, T, H, W, fst, fsh, fsw, nvox, nullptr);
+    AVD_CHECK_LAUNCH("upsample_lat16");
+    return AVD_OK;
+}
+
+
+
 struct VaePlan {
     int T, H, W, tiles;
     bool fold_img;
@@ -1438,13 +1524,7 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
         unsigned char* wimg = reinterpret_cast<unsigned char*>(wg + 4 * VC);
         float* btab1 = reinterpret_cast<float*>(wimg + (int64_t)B * W3_BYTES);
         if (int rc = zero_halo(reinterpret_cast<float*>(Lm), B, p.T, p.H, p.W, L16_ROWB, st)) return rc;
-        {
-            static const int tag = prof_tag_id("upsample_lat16_kernel");
-            ProfScope prof(tag, (double)nvox * L16_ROWB, st);
-            hipLaunchKernelGGL(upsample_lat16_kernel<false>, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, z, Lm, d->Cv, d->Tp, d->Hp, d->Wp, p.T, p.H,
-                               p.W, (float)d->Tp / (float)p.T, (float)d->Hp / (float)p.H, (float)d->Wp / (float)p.W, nvox, nullptr);
-            AVD_CHECK_LAUNCH("upsample_lat16");
-        }
+        if (int rc = upsample_lat16(z, hlow, Lm, B, d->Cv, d->Tp, d->Hp, d->Wp, p.T, p.H, p.W, false, nullptr, st)) return rc;
         if (int rc = zero_halo(Xp, B, p.T, p.H, p.W, A3_ROWB, st)) return rc;
         const int gn_tiles = conv3_tiles(6, p.T, p.H, p.W);
         {
@@ -1481,16 +1561,7 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
             hipLaunchKernelGGL(pow2_scale_kernel, dim3(1), dim3(1), 0, st, scale_ws);
             AVD_CHECK_LAUNCH("pow2_scale");
         }
-        static const int tag = prof_tag_id("upsample_lat16_kernel");
-        ProfScope prof(tag, (double)nvox * L16_ROWB, st);
-        const float fst = (float)d->Tp / (float)p.T, fsh = (float)d->Hp / (float)p.H, fsw = (float)d->Wp / (float)p.W;
-        if (h2)
-            hipLaunchKernelGGL(upsample_lat16_kernel<true>, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, z, X3, d->Cv, d->Tp, d->Hp, d->Wp,
-                               p.T, p.H, p.W, fst, fsh, fsw, nvox, scale_ws + 2);
-        else
-            hipLaunchKernelGGL(upsample_lat16_kernel<false>, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, z, X3, d->Cv, d->Tp, d->Hp, d->Wp,
-                               p.T, p.H, p.W, fst, fsh, fsw, nvox, nullptr);
-        AVD_CHECK_LAUNCH("upsample_lat16");
+        if (int rc = upsample_lat16(z, hlow, X3, B, d->Cv, d->Tp, d->Hp, d->Wp, p.T, p.H, p.W, h2, scale_ws + 2, st)) return rc;
     } else {
     // zero halo (interiors are overwritten below by the upsample / GroupNorm-apply passes, the halo stays zero for every conv)
     if (int rc = zero_halo(Xp, B, p.T, p.H, p.W, s3 ? A3_ROWB : VC * 4, st)) return rc;

@@ -1012,7 +1012,7 @@ def test_vae_decode_latent_composed_first_conv(dev, mode):
         L.prof_enable(False)
         used = {k for k, v in L.prof_report().items() if v[0] > 0}
         assert any(re.match(r"conv3d_k3_bf16x3_kernel<\d, %s, \d>" % ("0" if lat is True else "1"), k) for k in used) == bool(lat), used
-        assert ("upsample_lat16_kernel" in used) == bool(lat) and ("fromlat_kernel" in used) == (not lat), used
+        assert ("upsample_lat8_kernel" in used) == bool(lat) and ("fromlat_kernel" in used) == (not lat), used      # lat_ch = 8: channel-last latent
         outs[lat] = (x, vae.decode(G(g["z"][:1], dev), out_size=(6, 24, 40)).cpu())
     for lat in (True, "one tap per step"):
         assert rel_err(outs[lat][0], g["x"]) < TOL and rel_err(outs[lat][1], g["x_odd"]) < TOL
