@@ -442,6 +442,11 @@ typedef struct {
     int conv_terms;                    /* as in the decode descriptor; entries 0 of the scale arrays are unused (block 0 is the fp32 4 -> 64 conv) */
     const float* conv_w_scale;
     const float* conv_a_scale;
+    /* ABI 7 (round 5), optional: the FIRST convolution (in_ch <= 8 -> base) on the matrix pipe with two taps per k-step — the
+     * avd_conv3_weight_f32 image of a [out][27][base] tensor whose "tap" s (s = 0 .. 13) holds enc_net.0.0.weight[out][:, tap 2 s] in
+     * channels 0 .. in_ch-1 and tap 2 s + 1 in channels 8 .. 8+in_ch-1 (everything else zero).  With it set, conv_terms 0 / 6, two conv
+     * blocks and pooling (4, 8, 8), avd_vae_encode_f32 writes no fp32 activation at all (folded route, avd_tune_set "vae_fold"); NULL = fp32 first conv. */
+    const void* conv0_pk_w3;
 } avd_vae_encode_desc;
 int64_t avd_vae_encode_workspace_bytes(const avd_vae_encode_desc* d);
 int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, float* z, void* workspace,

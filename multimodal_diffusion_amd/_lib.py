@@ -86,7 +86,8 @@ class VaeEncodeDesc(C.Structure):
                 ("gn_w", C.POINTER(C.c_void_p)), ("gn_b", C.POINTER(C.c_void_p)),
                 ("to_lat_w", C.c_void_p), ("to_lat_b", C.c_void_p),
                 ("conv_w3", C.POINTER(C.c_void_p)), ("conv_terms", C.c_int),
-                ("conv_w_scale", C.POINTER(C.c_float)), ("conv_a_scale", C.POINTER(C.c_float))]
+                ("conv_w_scale", C.POINTER(C.c_float)), ("conv_a_scale", C.POINTER(C.c_float)),
+                ("conv0_pk_w3", C.c_void_p)]
 
 
 ABI_VERSION = 7

@@ -428,6 +428,31 @@ __global__ __launch_bounds__(256) void rgb_to_ndhwc4_pad_kernel(const float* __r
     *reinterpret_cast<f32x4*>(Xp4 + pv * 4) = o;
 }
 
+// x [B, Cin <= 8, T, H, W] -> interior of the 96-byte-per-voxel image ([plane][16 ch], channels >= Cin zero) the packed-tap form of the
+// halo-tile conv reads (the encoder's first convolution on the matrix pipe, round 5): one thread per voxel, coalesced per channel plane
+__global__ __launch_bounds__(256) void rgb_lat16_kernel(const float* __restrict__ x, unsigned char* __restrict__ X16, int Cin, int T, int H, int W,
+                                                        int64_t nvox) {
+    const int64_t vox = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (vox >= nvox) return;
+    const int THW = T * H * W;
+    const int smp = (int)(vox / THW), v = (int)(vox % THW);
+    const int w = v % W, h = (v / W) % H, t = v / (W * H);
+    float o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) o[c] = c < Cin ? x[((int64_t)smp * Cin + c) * THW + v] : 0.f;
+    const int64_t pv = (((int64_t)smp * (T + 2) + t + 1) * (H + 2) + h + 1) * (W + 2) + w + 1;
+    unsigned char* dst = X16 + pv * 96;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    u32x4 Hh, Mi, Lo;
+    split8(o, Hh, Mi, Lo);
+    *reinterpret_cast<u32x4*>(dst) = Hh;
+    *reinterpret_cast<u32x4*>(dst + 16) = zero;
+    *reinterpret_cast<u32x4*>(dst + 32) = Mi;
+    *reinterpret_cast<u32x4*>(dst + 48) = zero;
+    *reinterpret_cast<u32x4*>(dst + 64) = Lo;
+    *reinterpret_cast<u32x4*>(dst + 80) = zero;
+}
+
 // GroupNorm apply + AvgPool3d(td, sd, sd) + to_lat (1x1x1, 64 -> Cl <= 16): one wave per latent voxel.
 // Pooling and the per-channel GroupNorm affine commute, so the window mean is normalised once.
 __global__ __launch_bounds__(256) void gn_pool_tolat_kernel(const float* __restrict__ Y, const float* __restrict__ stats,
@@ -469,6 +494,44 @@ __global__ __launch_bounds__(256) void gn_pool_tolat_kernel(const float* __restr
         a += __shfl_xor(a, 4, 64);
         a += __shfl_xor(a, 8, 64);
         if (lane == o) z[((int64_t)smp * Cl + o) * vol + r] = a + bl[o];
+    }
+}
+
+// The same from the pooling partial sums of the halo-tile conv's OUT = 3 epilogue (t_down = 4, s_down = 8: a tile of 4 x TH x 16 output
+// voxels is one pooling block in t, TH / 8 in h, two in w): a latent voxel gathers its 8 entries (4 t-slices = waves, 8 / 4 h passes), each
+// [w block][64 channels], normalises the mean with the GroupNorm statistics and applies to_lat.  One wave per latent voxel, lane = channel.
+template <int TH>
+__global__ __launch_bounds__(256) void pool_tolat_from_partials_kernel(const float* __restrict__ P, const float* __restrict__ stats,
+                                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                       const float* __restrict__ Wl, const float* __restrict__ bl,
+                                                                       float* __restrict__ z, int T, int H, int W, int tiles2, int Cl, int64_t nlat) {
+    const int c = threadIdx.x & 63;
+    const int64_t lv = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (lv >= nlat) return;
+    const int Tl = T / 4, Hl = H / 8, Wl_ = W / 8;
+    const int vol = Tl * Hl * Wl_;
+    const int smp = (int)(lv / vol), r = (int)(lv % vol);
+    const int wl = r % Wl_, hl = (r / Wl_) % Hl, tl = r / (Wl_ * Hl);
+    const int nw_t = (W + 15) / 16, nh_t = (H + TH - 1) / TH;
+    constexpr int PASSES = TH / 4;                 // 64-voxel passes (4 h-rows x 16 w) of a wave per tile
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8 / 4; ++k) {             // the two 4-row passes of the 8-row pooling block
+        const int hrow = hl * 8 + 4 * k;           // first output row of the pass
+        const int tile = (tl * nh_t + hrow / TH) * nw_t + wl / 2, ps = (hrow % TH) / 4;
+#pragma unroll
+        for (int wave = 0; wave < 4; ++wave) {
+            const int64_t e = ((int64_t)tile * 4 + wave) * PASSES + ps;
+            sum += P[((((int64_t)smp * tiles2 + e) * 2) + (wl & 1)) * VC + c];
+        }
+    }
+    const float mean = stats[(smp * VG + c / 8) * 2], rstd = stats[(smp * VG + c / 8) * 2 + 1];
+    const float xn = (sum * (1.0f / 256.0f) - mean) * rstd * gamma[c] + beta[c];
+    for (int o = 0; o < Cl; ++o) {
+        float a = xn * Wl[o * VC + c];
+#pragma unroll
+        for (int x = 1; x < 64; x <<= 1) a += __shfl_xor(a, x, 64);
+        if (c == o) z[((int64_t)smp * Cl + o) * vol + r] = a + bl[o];
     }
 }
 
@@ -894,6 +957,7 @@ template <int TERMS> struct HaloCfg {
 template <int TERMS, int NSLAB = 4, int OUT = 0>     // TERMS 6: bf16x3; 3: f16x2 (planes h, l of the same buffers; the third plane is neither moved nor read)
 __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
     static_assert(OUT != 1 || TERMS == 6, "image output: the three-plane mode (an fp16 image needs a bound on the values before they exist)");
+    static_assert(OUT >= 0 && OUT <= 3, "0 fp32 NDHWC, 1 operand image, 2 to_img partial sums, 3 pooling partial sums");
     using Cf = HaloCfg<TERMS>;
     constexpr int NPL = Cf::NPL, TH = Cf::TH, HH = Cf::HH, TM = Cf::TM, NCH = Cf::NCH, RB = Cf::RB, NWS = Cf::NWS, WST = Cf::WST;
     constexpr bool F16 = TERMS == 3;
@@ -1188,6 +1252,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) slab_f[(i * 32 + mfma32_row(r, hi)) * CLD + j * 32 + l31] = acc[ps * 2 + i][j][r];
             float s1 = 0.f, s2 = 0.f;
+            // OUT = 3 (the encoder's last conv): sums of GELU(y) over this pass's 4 h-rows x 8 w of each of its two 8-wide w blocks (it even /
+            // odd) — what AvgPool3d(4, 8, 8) -> to_lat needs of this conv's output (GroupNorm in between is affine per channel, so it
+            // commutes with the mean); the fp32 activations are not written
+            [[maybe_unused]] float pool[2][8];
+            if constexpr (OUT == 3) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { pool[0][e] = 0.f; pool[1][e] = 0.f; }
+            }
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int row = r8 + it * 8;
@@ -1209,6 +1281,9 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
                     if constexpr (OUT == 1) {
                         const int64_t pv = (((int64_t)smp * (g.T + 2) + tt + 1) * Hp + hh + 1) * Wp + ww + 1;
                         store_act3<false>(g.X3out, pv, c8, y, 0.f);
+                    } else if constexpr (OUT == 3) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pool[it & 1][e] += y[e];
                     } else {
                         const int64_t v = ((int64_t)tt * g.H + hh) * g.W + ww;
                         f32x4 pp;
@@ -1228,11 +1303,31 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
             s1 += __shfl_xor(s1, 8, 64);  s2 += __shfl_xor(s2, 8, 64);
             s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
             s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+            if constexpr (OUT == 3) {
+#pragma unroll
+                for (int wb = 0; wb < 2; ++wb)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float a = pool[wb][e];
+                        a += __shfl_xor(a, 8, 64);
+                        a += __shfl_xor(a, 16, 64);
+                        a += __shfl_xor(a, 32, 64);
+                        pool[wb][e] = a;
+                    }
+            }
             if (lane < VG) {
                 const int64_t e = ((int64_t)tile * 4 + wave) * (TM / 2) + ps;
                 float* pp = g.part + (((int64_t)smp * g.tiles * 2 + e) * VG + lane) * 2;
                 pp[0] = s1;
                 pp[1] = s2;
+                if constexpr (OUT == 3) {       // pooling partials: [sample][entry][w block][64 channels]
+                    float* q = g.P + (((int64_t)smp * g.tiles * 2 + e) * 2) * VC + lane * 8;
+#pragma unroll
+                    for (int wb = 0; wb < 2; ++wb) {
+                        *reinterpret_cast<f32x4*>(q + wb * VC) = f32x4{pool[wb][0], pool[wb][1], pool[wb][2], pool[wb][3]};
+                        *reinterpret_cast<f32x4*>(q + wb * VC + 4) = f32x4{pool[wb][4], pool[wb][5], pool[wb][6], pool[wb][7]};
+                    }
+                }
             }
         }
         return;
@@ -1312,10 +1407,17 @@ static LdsAttr g_conv3_pk_attr[3];
 static int conv3_launch(Conv3Args a3, int terms, int B, double flops, hipStream_t st, bool lat = false, int out_mode = 0, bool packed = false) {
     a3.tiles = conv3_tiles(terms, a3.T, a3.H, a3.W);
     if (lat && packed) {       // two taps per k-step (conv3d_k3_bf16x3_kernel<.., 0, ..>): 14 / 27 of the MFMA work
-        AVD_REQUIRE(a3.btab && out_mode != 2 && (out_mode == 0 || (terms != 3 && a3.X3out)), AVD_EINVAL, "conv3d (latent-composed, packed taps): bad arguments");
+        AVD_REQUIRE((a3.btab || out_mode == 1) && out_mode != 2 && (out_mode == 0 || (terms != 3 && a3.X3out)), AVD_EINVAL,
+                    "conv3d (latent-composed, packed taps): bad arguments");
         if (terms == 3) return conv3_launch_as<3, 0, 0>(a3, B, flops * 14.0 / 27.0, st, g_conv3_pk_attr[0], "conv3d f16x2 (latent, packed taps)");
         if (out_mode == 1) return conv3_launch_as<6, 0, 1>(a3, B, flops * 14.0 / 27.0, st, g_conv3_pk_attr[1], "conv3d bf16x3 (latent, packed taps, image out)");
         return conv3_launch_as<6, 0, 0>(a3, B, flops * 14.0 / 27.0, st, g_conv3_pk_attr[2], "conv3d bf16x3 (latent, packed taps)");
+    }
+    if (out_mode == 3) {       // the encoder's last conv: pooling partial sums instead of fp32 activations
+        AVD_REQUIRE(!lat && a3.P, AVD_EINVAL, "conv3d (pooling partials): bad arguments");
+        static LdsAttr attr[2];
+        if (terms == 3) return conv3_launch_as<3, 4, 3>(a3, B, flops, st, attr[0], "conv3d f16x2 (pooling partials out)");
+        return conv3_launch_as<6, 4, 3>(a3, B, flops, st, attr[1], "conv3d bf16x3 (pooling partials out)");
     }
     if (out_mode != 0) {
         AVD_REQUIRE((out_mode == 1 && terms != 3 && lat && a3.X3out) || (out_mode == 2 && !lat && a3.P && a3.wimg_g), AVD_EINVAL, "conv3d (folded route): bad arguments");
@@ -1680,7 +1782,7 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
 namespace avd {
 struct VaeEncPlan {
     int tiles;
-    int64_t THW, pad4_b, pad_b, y_b, part_b, part_n, stats_b, total;
+    int64_t THW, pad4_b, pad_b, y_b, part_b, part_n, fold_b, stats_b, total;
 };
 static int vae_enc_plan(const avd_vae_encode_desc* d, VaeEncPlan& p) {
     AVD_REQUIRE(d, AVD_EINVAL, "vae_encode: null descriptor");
@@ -1706,7 +1808,9 @@ static int vae_enc_plan(const avd_vae_encode_desc* d, VaeEncPlan& p) {
         p.part_b = a256(p.part_n * 4 + gn_fin_bytes(d->B));
     }
     p.stats_b = a256((int64_t)d->B * VG * 2 * 4);
-    p.total = p.pad4_b + p.pad_b + p.y_b + p.part_b + p.stats_b;
+    // folded route (three planes, two blocks, packed first conv): per-sample weight image + bias table of conv 1
+    p.fold_b = d->conv_w3 && d->conv_terms != 3 && d->n_blocks == 2 && d->conv0_pk_w3 ? a256((int64_t)d->B * (W3_BYTES + 64 * VC * 4)) : 0;
+    p.total = p.pad4_b + p.pad_b + p.y_b + p.part_b + p.fold_b + p.stats_b;
     return AVD_OK;
 }
 }  // namespace avd
@@ -1732,7 +1836,8 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
     float* Y = reinterpret_cast<float*>(w + p.pad4_b + p.pad_b);
     float* part = reinterpret_cast<float*>(w + p.pad4_b + p.pad_b + p.y_b);
     double* fin = reinterpret_cast<double*>(part + p.part_n);
-    float* stats = reinterpret_cast<float*>(w + p.pad4_b + p.pad_b + p.y_b + p.part_b);
+    char* foldw = w + p.pad4_b + p.pad_b + p.y_b + p.part_b;
+    float* stats = reinterpret_cast<float*>(foldw + p.fold_b);
     const int B = d->B, T = d->T, H = d->H, W = d->W;
 
     const bool s3 = d->conv_w3 != nullptr && d->n_blocks > 1;     // split operands for the 64 -> 64 convolutions (block 0 is 4 -> 64, fp32)
@@ -1741,6 +1846,53 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
     if (s3) {
         for (int blk = 1; blk < d->n_blocks; ++blk) AVD_REQUIRE(d->conv_w3[blk], AVD_EINVAL, "vae_encode: null conv_w3[%d]", blk);
         if (int rc = check_conv_terms(d->conv_terms, d->conv_w_scale, d->conv_a_scale, d->n_blocks, 1, false)) return rc;
+    }
+    {
+        // ---- folded route (round 5; three planes, two blocks, pooling (4, 8, 8), in_ch <= 8): the first conv on the halo-tile kernel with two taps
+        // per k-step from a 96-byte image of the input, its output straight into conv 1's operand image, GroupNorm 0 folded into conv 1's
+        // per-sample weights, conv 1's epilogue -> pooling partial sums -> GroupNorm 1 + AvgPool + to_lat.  No fp32 activation is written.
+        const int64_t padvox = (int64_t)B * (T + 2) * (H + 2) * (W + 2);
+        if (s3 && !h2 && g_vae_fold && p.fold_b > 0 && d->in_ch <= 8 && d->t_down == 4 && d->s_down == 8 && padvox * L16_ROWB <= p.y_b) {
+            unsigned char* Lm = reinterpret_cast<unsigned char*>(Y);
+            unsigned char* wimg = reinterpret_cast<unsigned char*>(foldw);
+            float* btab1 = reinterpret_cast<float*>(wimg + (int64_t)B * W3_BYTES);
+            const int64_t nvox = (int64_t)B * p.THW;
+            if (int rc = zero_halo(Lm, B, T, H, W, L16_ROWB, st)) return rc;
+            {
+                static const int tag = prof_tag_id("rgb_lat16_kernel");
+                ProfScope prof(tag, (double)nvox * (L16_ROWB + 4.0 * d->in_ch), st);
+                hipLaunchKernelGGL(rgb_lat16_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, x, Lm, d->in_ch, T, H, W, nvox);
+                AVD_CHECK_LAUNCH("rgb_lat16");
+            }
+            if (int rc = zero_halo(Xp, B, T, H, W, A3_ROWB, st)) return rc;
+            const int gn_tiles = conv3_tiles(6, T, H, W);
+            {
+                Conv3Args a3{Lm, static_cast<const unsigned char*>(d->conv0_pk_w3), d->conv_b[0], nullptr, part, T, H, W, p.tiles, 1.f, nullptr, nullptr, X3,
+                             nullptr, nullptr, 0, 0};
+                if (int rc = conv3_launch(a3, 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * 16, st, true, 1, true)) return rc;
+            }
+            if (int rc = gn_finalize(part, fin, stats, B, gn_tiles, (double)p.THW * (VC / VG), d->gn_eps, st)) return rc;
+            {
+                static const int tag = prof_tag_id("conv3_weight_gn_kernel");
+                ProfScope prof(tag, (double)B * (W3_BYTES + 27.0 * VC * VC * 4), st);
+                hipLaunchKernelGGL(conv3_weight_gn_kernel, dim3(54, B), dim3(256), 0, st, d->conv_w[1], stats, d->gn_w[0], wimg);
+                AVD_CHECK_LAUNCH("conv3_weight_gn");
+                hipLaunchKernelGGL(conv3_gn_btab_kernel, dim3(B), dim3(256), 0, st, d->conv_w[1], stats, d->gn_w[0], d->gn_b[0], btab1);
+                AVD_CHECK_LAUNCH("conv3_gn_btab");
+            }
+            {
+                Conv3Args a3{X3, wimg, d->conv_b[1], nullptr, part, T, H, W, p.tiles, 1.f, nullptr, btab1, nullptr, Y, nullptr, W3_BYTES, 64 * VC};
+                if (int rc = conv3_launch(a3, 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st, false, 3)) return rc;
+            }
+            if (int rc = gn_finalize(part, fin, stats, B, gn_tiles, (double)p.THW * (VC / VG), d->gn_eps, st)) return rc;
+            const int64_t nlat = (int64_t)B * (T / 4) * (H / 8) * (W / 8);
+            static const int tag = prof_tag_id("pool_tolat_from_partials_kernel");
+            ProfScope prof(tag, 4.0 * (double)nlat * 8 * VC, st);
+            hipLaunchKernelGGL(pool_tolat_from_partials_kernel<HaloCfg<6>::TH>, dim3((unsigned)((nlat + 3) / 4)), dim3(256), 0, st, Y, stats, d->gn_w[1],
+                               d->gn_b[1], d->to_lat_w, d->to_lat_b, z, T, H, W, gn_tiles * 2, d->lat_ch, nlat);
+            AVD_CHECK_LAUNCH("pool_tolat_from_partials");
+            return AVD_OK;
+        }
     }
     if (int rc = zero_halo(Xp4, B, T, H, W, 16, st)) return rc;
     if (d->n_blocks > 1)
@@ -1756,10 +1908,13 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
     for (int blk = 0; blk < d->n_blocks; ++blk) {
         ConvArgs a{blk == 0 ? Xp4 : Xp, d->conv_w[blk], d->conv_b[blk], Y, part, T, H, W, p.tiles};
         int gn_tiles = p.tiles;
+        // last conv on the halo-tile kernel with the shipped pooling (4, 8, 8): pooling partial sums instead of fp32 activations ("vae_fold")
+        const bool pool_out = blk > 0 && s3 && blk + 1 == d->n_blocks && g_vae_fold && d->t_down == 4 && d->s_down == 8;
         if (blk > 0 && s3) {
             Conv3Args a3{X3, static_cast<const unsigned char*>(d->conv_w3[blk]), d->conv_b[blk], Y, part, T, H, W, p.tiles,
                          h2 ? 1.0f / (d->conv_w_scale[blk] * d->conv_a_scale[blk]) : 1.f, nullptr};
-            if (int rc = conv3_launch(a3, h2 ? 3 : 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st)) return rc;
+            if (pool_out) { a3.Y = nullptr; a3.P = Y; }
+            if (int rc = conv3_launch(a3, h2 ? 3 : 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st, false, pool_out ? 3 : 0)) return rc;
             gn_tiles = conv3_tiles(h2 ? 3 : 6, T, H, W);
         } else if (blk == 0) {
             static const int tag = prof_tag_id("conv3d_k3_gelu_stats_kernel<4>");
@@ -1790,6 +1945,17 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
             hipLaunchKernelGGL(gn_apply_pad_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, st, Y, stats,
                                d->gn_w[blk], d->gn_b[blk], Xp, T, H, W, total4);
             AVD_CHECK_LAUNCH("gn_apply_pad");
+        } else if (pool_out) {
+            const int64_t nlat = (int64_t)B * (T / 4) * (H / 8) * (W / 8);
+            static const int tag = prof_tag_id("pool_tolat_from_partials_kernel");
+            ProfScope prof(tag, 4.0 * (double)nlat * 8 * VC, st);
+            if (h2)
+                hipLaunchKernelGGL(pool_tolat_from_partials_kernel<HaloCfg<3>::TH>, dim3((unsigned)((nlat + 3) / 4)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
+                                   d->gn_b[blk], d->to_lat_w, d->to_lat_b, z, T, H, W, gn_tiles * 2, d->lat_ch, nlat);
+            else
+                hipLaunchKernelGGL(pool_tolat_from_partials_kernel<HaloCfg<6>::TH>, dim3((unsigned)((nlat + 3) / 4)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
+                                   d->gn_b[blk], d->to_lat_w, d->to_lat_b, z, T, H, W, gn_tiles * 2, d->lat_ch, nlat);
+            AVD_CHECK_LAUNCH("pool_tolat_from_partials");
         } else {
             const int64_t nlat = (int64_t)B * (T / d->t_down) * (H / d->s_down) * (W / d->s_down);
             static const int tag = prof_tag_id("gn_pool_tolat_kernel");

@@ -81,6 +81,7 @@ class VideoVAE(nn.Module):
         # _lat_composite) instead of from_lat -> upsample -> 64-channel convolution.  Same operator up to fp32 rounding.
         self.lat_composed = True
         self.lat_packed = True          # lat_ch <= 8: two taps per k-step of the composed first conv (14 steps instead of 27)
+        self.enc_packed = True          # encoder: first conv on the matrix pipe with two taps per k-step -> the folded encode route
 
     @classmethod
     def from_config(cls, d: Dict) -> "VideoVAE":
@@ -167,6 +168,10 @@ class VideoVAE(nn.Module):
             raise ValueError(f"matmul must be 'auto', 'f32', 'bf16x3' or 'f16x2', got {self.matmul!r}")
         if self.matmul != "f32" and nb > 1:
             self._split_conv_desc(d, keep, nb, 1, True, (self.cfg.enc_base // 8) * T2 * H2 * W2)
+            if self.matmul != "f16x2" and nb == 2 and Cin <= 8 and self.cfg.enc_base == 64 and self.enc_packed:
+                img = self._enc_conv0_packed()
+                keep.append(img)
+                d.conv0_pk_w3 = img.data_ptr()
         d.B = 1
         per = L.lib().avd_vae_encode_workspace_bytes(C.byref(d))
         if per < 0:
@@ -295,6 +300,23 @@ class VideoVAE(nn.Module):
             self._conv3[("lat", f16x2)] = (key, img, tab, scale, packed)
         hit = self._conv3[("lat", f16x2)]
         return hit[1], hit[2], hit[3], hit[4]
+
+    def _enc_conv0_packed(self) -> torch.Tensor:
+        """Weight image of the encoder's FIRST convolution (in_ch <= 8 -> 64) for the halo-tile kernel with two taps per k-step (ABI 7
+        conv0_pk_w3): "tap" s of a [out][27][64] tensor holds tap 2 s in channels 0 .. in_ch-1 and tap 2 s + 1 in channels 8 .. 8+in_ch-1."""
+        w = self.enc_net[0][0].weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = self._conv3.get("enc0_pk")
+        if hit is None or hit[0] != key:
+            D, Cin = w.shape[0], w.shape[1]
+            c27 = torch.zeros(D, 28, 8, device=w.device, dtype=torch.float32)
+            c27[:, :27, :Cin] = w.detach().float().permute(0, 2, 3, 4, 1).reshape(D, 27, Cin)
+            src = torch.zeros(D, 27, D, device=w.device, dtype=torch.float32)
+            src[:, :14, :16] = c27.view(D, 14, 16)
+            img = torch.empty(L.lib().avd_conv3_weight_bytes(), dtype=torch.uint8, device=w.device)
+            L.check(L.lib().avd_conv3_weight_f32(src.contiguous().data_ptr(), img.data_ptr(), L.stream_ptr(w.device)))
+            self._conv3["enc0_pk"] = (key, img)
+        return self._conv3["enc0_pk"][1]
 
     def _tap_major(self, i: int) -> torch.Tensor:
         w = self.dec_net[i][0].weight

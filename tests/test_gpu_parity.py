@@ -1101,6 +1101,43 @@ def test_vae_encode_bf16x3(dev):
         assert rel_err(vae.encode(G(g["x_crop"], dev)).cpu(), g["z_crop"]) < TOL
 
 
+def test_vae_encode_folded_route(dev):
+    """Round 5, encoder (bf16x3, two conv blocks, pooling (4, 8, 8)): the first convolution on the halo-tile kernel with two taps per
+    k-step (ABI 7 conv0_pk_w3), its output straight into conv 1's operand image, GroupNorm 0 folded into conv 1's per-sample weights
+    and border table, conv 1's epilogue -> pooling partial sums -> GroupNorm 1 + AvgPool3d + to_lat (vae_video3d.py:164-189): no fp32
+    activation is written.  Against the golden fixture (also its cropped input) and the route with fp32 activations between the kernels;
+    f16x2 takes the pooling part only."""
+    import warnings
+    import multimodal_diffusion_amd as A
+    from multimodal_diffusion_amd import _lib as L
+    g = load_golden("g12_vae_encode.npz")
+    for mode in ("bf16x3", "f16x2"):
+        outs = {}
+        try:
+            for fold in (0, 1):
+                _tune("vae_fold", fold)
+                vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8}}).eval()
+                vae.load_state_dict(split_weights(g)["w"], strict=False)
+                vae = vae.to(dev)
+                vae.matmul = mode
+                L.prof_enable(True)
+                z = vae.encode(G(g["x"], dev)).cpu()
+                torch.cuda.synchronize()
+                L.prof_enable(False)
+                used = {k for k, v in L.prof_report().items() if v[0] > 0}
+                want = {"rgb_lat16_kernel", "conv3d_k3_bf16x3_kernel<6, 0, 1>", "conv3d_k3_bf16x3_kernel<6, 4, 3>", "pool_tolat_from_partials_kernel"} \
+                    if mode == "bf16x3" else {"conv3d_k3_bf16x3_kernel<3, 4, 3>", "pool_tolat_from_partials_kernel"}
+                assert (want <= used) == bool(fold), used
+                assert ("gn_pool_tolat_kernel" in used) == (not fold), used
+                with warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    outs[fold] = (z, vae.encode(G(g["x_crop"], dev)).cpu())
+            assert rel_err(outs[1][0], g["z"]) < TOL and rel_err(outs[1][1], g["z_crop"]) < TOL
+            assert rel_err(outs[1][0], outs[0][0]) < 2e-5 and rel_err(outs[1][1], outs[0][1]) < 2e-5
+        finally:
+            _tune("vae_fold", 1)
+
+
 def test_full_step_v2a_bf16x3(dev, full):
     """Video -> audio direction on the bf16x3 path: 37 target + 384 prompt tokens at 256x256 (the prompt is the long part, the
     target rows come first, the audio head stays on fp32 MFMA), B=10 -> 8,420 rows; oracle on the first two samples."""

@@ -17,6 +17,7 @@ ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--matmul", default="f32", choices=["f32", "bf16x3", "f16x2"])
 ap.add_argument("--lat", type=int, default=1, help="0: from_lat -> upsample -> 64-channel first conv (rounds 1-4); 1: the latent-composed first conv")
+ap.add_argument("--encode", action="store_true", help="time VideoVAE.encode of [B,3,48,size,size] instead of the decode")
 ap.add_argument("--power", type=float, default=0.0, help="loop the decode for this many seconds under bench.py's clock / socket-power sampler")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -25,6 +26,26 @@ vae = A.VideoVAE.from_config({"latent": {"channels": 8, "t_down": 4, "s_down": 8
 vae.matmul = args.matmul
 vae.lat_composed = bool(args.lat)
 z = torch.randn(args.batch, 8, 12, args.size // 8, args.size // 8, device=dev)
+if args.encode:
+    xin = torch.rand(args.batch, 3, 48, args.size, args.size, device=dev) * 2 - 1
+    for _ in range(2):
+        zz = vae.encode(xin)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.iters):
+        zz = vae.encode(xin)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.iters
+    print(f"[{args.matmul}] encode B={args.batch} {args.size}x{args.size}: {dt*1e3:.2f} ms, out {tuple(zz.shape)} finite={bool(torch.isfinite(zz).all())}")
+    L.prof_enable(True)
+    vae.encode(xin)
+    torch.cuda.synchronize()
+    L.prof_enable(False)
+    for k, (n, ms, w) in L.prof_report().items():
+        if n:
+            unit = f"{w/ms/1e9:8.1f} TFLOP/s" if "conv3d" in k else f"{w/ms/1e6:8.1f} GB/s"
+            print(f"  {k:40s} x{n}  {ms/n:9.3f} ms  {unit}")
+    sys.exit(0)
 for _ in range(2):
     x = vae.decode(z)
 torch.cuda.synchronize()
