@@ -54,7 +54,7 @@ int         avd_device_arch(char* buf, int buflen);
  * x 1024 cycles; -1 automatic), "cfg_rows" (1 default: the fused CFG + un-patch + DDIM kernel reads token rows whole and writes whole 128-byte lines of latent through an LDS
  * transpose; 0: one 16-byte gather per lane; bit-identical), "vae_lat" (1 default: avd_vae_decode_f32 takes the latent-composed first convolution when the descriptor
  * carries conv0_lat_w3; 0: from_lat -> upsample -> 64-channel convolution), "vae_fold" (1 default: the three-plane two-block decoder hands conv 0's output to conv 1 as its operand image, folds the GroupNorm
- * between them into conv 1's per-sample weights and finishes to_img from per-group partial sums; 0: fp32 activations between the kernels), "s3_sn" / "s3_super4" / "s3_super8" (super-tile of the split GEMMs' block order — the blocks an XCD runs together: width in column blocks /
+ * between them into conv 1's per-sample weights and finishes to_img from per-group partial sums; 0: fp32 activations between the kernels), "codec_mfma" (1 default: avd_conv1d_act_f32 runs 64 -> 64 layers with k = 7 / 9 on the fp32 matrix pipe; 0: the vector kernel), "s3_sn" / "s3_super4" / "s3_super8" (super-tile of the split GEMMs' block order — the blocks an XCD runs together: width in column blocks /
  * blocks per super-tile of the two-per-CU / one-per-CU kernels; 0 = default; bit-identical, measurement aid of profiles/r05_fetch_ab.txt), "s3_min_rows" (smallest 2B*N that takes the split-operand kernels: -1 default = 2,048 rows for the core in the six-term bf16x3 mode, 6,144 otherwise; >= 0 = that many in every mode), "no_fold" (1 = keep RMSNorm as
  * separate kernels in avd_core_forward_f32, in every mode), "s3_m16" (1 default: bf16x3 GEMMs on v_mfma_f32_16x16x32_bf16 with two product
  * terms per instruction; 0: the 32x32x16 kernel), "s3_rt" (rows per block of the bf16x3 residual + image epilogue: 0 automatic,

@@ -295,6 +295,7 @@ extern int g_s3_deep4;           // 1: residual + image launches whose 4-wave bl
 extern int g_s3_rt;              // rows per 8-wave block of the residual + image epilogue: 0 automatic, 7 = 224 rows, 8 = 256 rows (avd_tune_set "s3_rt")
 extern int g_vae_lat;            // 1 (default): the decoder's first conv composed with from_lat and the upsample when the descriptor allows (vae3d_f32.hip; avd_tune_set "vae_lat")
 extern int g_vae_fold;           // 1 (default): conv 0 -> conv 1 through the operand image with the GroupNorm folded into conv 1's weights, to_img from partial sums (vae3d_f32.hip; avd_tune_set "vae_fold")
+extern int g_codec_mfma;         // 1 (default): the codec's 64 -> 64 conv1d layers on the fp32 matrix pipe (codec_f32.hip; avd_tune_set "codec_mfma")
 extern int g_cfg_rows;           // 1 (default): fused CFG + un-patch + DDIM through whole 128-byte lines (tokens.hip; avd_tune_set "cfg_rows")
 extern int g_s3_sn, g_s3_super4, g_s3_super8;      // super-tile shape overrides of the split GEMMs, 0 = default (avd_tune_set "s3_sn" / "s3_super4" / "s3_super8")
 extern int g_s3_tile;            // -1 = per epilogue; 0 / 1 = 8-wave 256x256 / 4-wave 256x128 blocks (avd_tune_set "s3_tile")

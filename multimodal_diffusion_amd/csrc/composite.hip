@@ -653,6 +653,7 @@ extern "C" int avd_tune_set(const char* key, int64_t value) {
     if (!strcmp(key, "cfg_rows")) { g_cfg_rows = value != 0; return AVD_OK; }
     if (!strcmp(key, "vae_lat")) { g_vae_lat = value != 0; return AVD_OK; }
     if (!strcmp(key, "vae_fold")) { g_vae_fold = value != 0; return AVD_OK; }
+    if (!strcmp(key, "codec_mfma")) { g_codec_mfma = value != 0; return AVD_OK; }
     if (!strcmp(key, "s3_sn")) { g_s3_sn = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_super4")) { g_s3_super4 = (int)value; return AVD_OK; }
     if (!strcmp(key, "s3_super8")) { g_s3_super8 = (int)value; return AVD_OK; }

@@ -646,24 +646,29 @@ __global__ __launch_bounds__(256) void conv3_weight_gn_kernel(const float* __res
 __global__ __launch_bounds__(256) void conv3_gn_btab_kernel(const float* __restrict__ Wt, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float* __restrict__ btab) {
+    // one block per (sample, 8 output channels): 216 dot products of 64, then the 64 classes x 8 outputs (one block per sample walked the
+    // 442 KB of weights through one CU: 34 us)
     __shared__ float shift[VC];
-    __shared__ float S[VC][28];
-    const int smp = blockIdx.x, tid = threadIdx.x;
+    __shared__ float S[8][28];
+    const int smp = blockIdx.x, o0 = blockIdx.y * 8, tid = threadIdx.x;
     if (tid < VC) {
         const float mean = stats[(smp * VG + tid / 8) * 2], rstd = stats[(smp * VG + tid / 8) * 2 + 1];
         shift[tid] = beta[tid] - mean * rstd * gamma[tid];
     }
     __syncthreads();
-    for (int idx = tid; idx < VC * 27; idx += 256) {
-        const int o = idx / 27, tap = idx - o * 27;
-        const float* wr = Wt + ((int64_t)o * 27 + tap) * VC;
+    if (tid < 8 * 27) {
+        const int o = tid / 27, tap = tid - o * 27;
+        const float* wr = Wt + ((int64_t)(o0 + o) * 27 + tap) * VC;
         float a = 0.f;
-        for (int c = 0; c < VC; ++c) a = fmaf(wr[c], shift[c], a);
+        for (int c = 0; c < VC; c += 4) {
+            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + c);
+            a = fmaf(w4[0], shift[c], a); a = fmaf(w4[1], shift[c + 1], a); a = fmaf(w4[2], shift[c + 2], a); a = fmaf(w4[3], shift[c + 3], a);
+        }
         S[o][tap] = a;
     }
     __syncthreads();
-    for (int idx = tid; idx < 64 * VC; idx += 256) {
-        const int cls = idx >> 6, o = idx & 63;
+    for (int idx = tid; idx < 64 * 8; idx += 256) {
+        const int cls = idx >> 3, o = idx & 7;
         float a = 0.f;
         for (int tap = 0; tap < 27; ++tap) {
             const int dt = tap / 9, dh = (tap / 3) % 3, dw = tap % 3;
@@ -671,7 +676,7 @@ __global__ __launch_bounds__(256) void conv3_gn_btab_kernel(const float* __restr
                             (dw != 0 || (cls & 16)) && (dw != 2 || (cls & 32));
             if (in) a += S[o][tap];
         }
-        btab[((int64_t)smp * 64 + cls) * VC + o] = a;
+        btab[((int64_t)smp * 64 + cls) * VC + o0 + o] = a;
     }
 }
 // to_img after the last GroupNorm, from the conv's partial sums: out[o] = sum_g rstd_g P[g][o] + K[o],
@@ -1640,7 +1645,7 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
             ProfScope prof(tag, (double)B * (W3_BYTES + 27.0 * VC * VC * 4), st);
             hipLaunchKernelGGL(conv3_weight_gn_kernel, dim3(54, B), dim3(256), 0, st, d->conv_w[1], stats, d->gn_w[0], wimg);
             AVD_CHECK_LAUNCH("conv3_weight_gn");
-            hipLaunchKernelGGL(conv3_gn_btab_kernel, dim3(B), dim3(256), 0, st, d->conv_w[1], stats, d->gn_w[0], d->gn_b[0], btab1);
+            hipLaunchKernelGGL(conv3_gn_btab_kernel, dim3(B, VC / 8), dim3(256), 0, st, d->conv_w[1], stats, d->gn_w[0], d->gn_b[0], btab1);
             AVD_CHECK_LAUNCH("conv3_gn_btab");
             hipLaunchKernelGGL(toimg_wg_kernel, dim3(1), dim3(256), 0, st, d->to_img_w, d->gn_w[1], wg, d->out_ch);
             AVD_CHECK_LAUNCH("toimg_wg");
@@ -1877,7 +1882,7 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
                 ProfScope prof(tag, (double)B * (W3_BYTES + 27.0 * VC * VC * 4), st);
                 hipLaunchKernelGGL(conv3_weight_gn_kernel, dim3(54, B), dim3(256), 0, st, d->conv_w[1], stats, d->gn_w[0], wimg);
                 AVD_CHECK_LAUNCH("conv3_weight_gn");
-                hipLaunchKernelGGL(conv3_gn_btab_kernel, dim3(B), dim3(256), 0, st, d->conv_w[1], stats, d->gn_w[0], d->gn_b[0], btab1);
+                hipLaunchKernelGGL(conv3_gn_btab_kernel, dim3(B, VC / 8), dim3(256), 0, st, d->conv_w[1], stats, d->gn_w[0], d->gn_b[0], btab1);
                 AVD_CHECK_LAUNCH("conv3_gn_btab");
             }
             {

@@ -521,6 +521,30 @@ def test_audio_codec_golden(dev):
     w = codec.decode(G(g["z_in"], dev)).cpu()
     assert w.shape == (2, 1, 3200) and rel_err(w, g["wav_out"]) < TOL
     assert float(w.abs().max()) <= 1.0
+    # round 5: the 64 -> 64 layers (k = 9 encoder, k = 7 decoder) run on the fp32 matrix pipe by default — v_mfma_f32_32x32x2_f32 is an fp32
+    # FMA chain and the kernel walks (channel, tap) in the vector kernel's order, so the results are BIT-identical (3,200 output positions
+    # = 12.5 blocks of 256: the ragged tail; the x 320 upsample is folded into both)
+    from multimodal_diffusion_amd import _lib as L
+    L.prof_enable(True)
+    codec.decode(G(g["z_in"], dev))
+    torch.cuda.synchronize()
+    L.prof_enable(False)
+    assert L.prof_report()["conv1d_mfma_kernel"][0] == 2
+    try:
+        _tune("codec_mfma", 0)
+        z0, w0 = codec.encode(G(g["wav"], dev)).cpu(), codec.decode(G(g["z_in"], dev)).cpu()
+    finally:
+        _tune("codec_mfma", 1)
+    L.prof_enable(True)
+    try:
+        _tune("codec_mfma", 0)
+        codec.decode(G(g["z_in"], dev))
+        torch.cuda.synchronize()
+    finally:
+        _tune("codec_mfma", 1)
+        L.prof_enable(False)
+    assert L.prof_report()["conv1d_mfma_kernel"][0] == 0 and L.prof_report()["conv1d_ncl_kernel"][0] == 4
+    assert torch.equal(z, z0) and torch.equal(w, w0)
 
 
 def test_sample_one_direction_end_to_end(dev, full):

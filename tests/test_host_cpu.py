@@ -20,11 +20,11 @@ def test_documented_tune_keys_are_accepted():
     block = header[header.index("Measurement / test hooks"):header.index("int         avd_tune_set")]
     keys = sorted(set(re.findall(r'"([a-z0-9_]+)"', block)))
     assert {"gemm_tile", "gemm_stages", "s3_tile", "s3_stagger", "s3_min_rows", "no_fold", "s3_m16", "s3_rt", "s3_rt4", "s3_deep4", "s3_w128", "s3_splitk", "attn_pipe", "core_trim", "mlp_fused", "gemm_splitk",
-            "attn_m16", "cfg_rows", "vae_lat", "vae_fold", "s3_sn", "s3_super4", "s3_super8"} <= set(keys)
+            "attn_m16", "cfg_rows", "vae_lat", "vae_fold", "codec_mfma", "s3_sn", "s3_super4", "s3_super8"} <= set(keys)
     lib = L.lib()
     defaults = {"gemm_tile": -1, "gemm_stages": 0, "s3_tile": -1, "s3_stagger": -1, "s3_min_rows": -1, "no_fold": 0, "s3_m16": 1,
                 "s3_rt": 0, "s3_rt4": 0, "s3_deep4": 1, "s3_w128": 1, "s3_splitk": 4, "attn_pipe": 1, "core_trim": 1, "mlp_fused": 0, "gemm_splitk": 4,
-                "attn_m16": 1, "cfg_rows": 1, "vae_lat": 1, "vae_fold": 1, "s3_sn": 0, "s3_super4": 0, "s3_super8": 0}
+                "attn_m16": 1, "cfg_rows": 1, "vae_lat": 1, "vae_fold": 1, "codec_mfma": 1, "s3_sn": 0, "s3_super4": 0, "s3_super8": 0}
     for k in keys:
         assert lib.avd_tune_set(k.encode(), defaults[k]) == 0, k
     assert lib.avd_tune_set(b"no_such_knob", 1) != 0
