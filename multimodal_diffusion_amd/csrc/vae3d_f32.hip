@@ -701,41 +701,26 @@ __global__ __launch_bounds__(256) void toimg_wg_kernel(const float* __restrict__
     const int i = threadIdx.x, o = i >> 6, c = i & 63;
     wg[i] = o < Cout ? Wimg[o * VC + c] * gamma[c] : 0.f;
 }
-constexpr int TOIMG_P_VOX = 128;
+constexpr int TOIMG_P_VOX = 256;
+// one thread per voxel: its 8 groups x 4 partial sums are one 128-byte line (a wave reads 8 KiB contiguous), the 32 multiply-adds need no
+// cross-lane traffic, and consecutive threads write consecutive positions of each output plane
 __global__ __launch_bounds__(256) void toimg_from_p_kernel(const float* __restrict__ P, const float* __restrict__ consts, float* __restrict__ out,
                                                            int THW, int Cout, int use_tanh, int64_t nvox) {
-    __shared__ float s_out[4][TOIMG_P_VOX];
-    const int tid = threadIdx.x, grp = tid & 7;
-    const int64_t vox0 = (int64_t)blockIdx.x * TOIMG_P_VOX;
+    const int64_t vox = (int64_t)blockIdx.x * TOIMG_P_VOX + threadIdx.x;
+    if (vox >= nvox) return;
+    const int64_t smp = vox / THW;
+    const float* cs = consts + smp * 12;
+    const f32x4* p = reinterpret_cast<const f32x4*>(P + vox * (VG * 4));
+    f32x4 a = {cs[VG], cs[VG + 1], cs[VG + 2], cs[VG + 3]};
 #pragma unroll
-    for (int it = 0; it < TOIMG_P_VOX / 32; ++it) {
-        const int vl = it * 32 + (tid >> 3);
-        const int64_t vox = vox0 + vl;
-        const int64_t vx = vox < nvox ? vox : nvox - 1;
-        const int smp = (int)(vx / THW);
-        const f32x4 pv = *reinterpret_cast<const f32x4*>(P + (vx * VG + grp) * 4);
-        const float rs = consts[smp * 12 + grp];
-        f32x4 a = pv * rs;
+    for (int g = 0; g < VG; ++g) a += p[g] * cs[g];
+    const int64_t v = vox - smp * THW;
 #pragma unroll
-        for (int x = 1; x < 8; x <<= 1)
-#pragma unroll
-            for (int o = 0; o < 4; ++o) a[o] += __shfl_xor(a[o], x, 64);
-        if (grp == 0) {
-#pragma unroll
-            for (int o = 0; o < 4; ++o) s_out[o][vl] = a[o] + consts[smp * 12 + VG + o];
+    for (int o = 0; o < 4; ++o)
+        if (o < Cout) {
+            const float x = a[o];
+            out[(smp * Cout + o) * THW + v] = use_tanh ? tanhf(x) : 1.0f / (1.0f + expf(-x));
         }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < TOIMG_P_VOX * Cout; idx += 256) {
-        const int o = idx / TOIMG_P_VOX, vl = idx % TOIMG_P_VOX;
-        const int64_t vox = vox0 + vl;
-        if (vox < nvox) {
-            float v = s_out[o][vl];
-            v = use_tanh ? tanhf(v) : 1.0f / (1.0f + expf(-v));
-            const int64_t smp = vox / THW;
-            out[(smp * Cout + o) * THW + (vox - smp * THW)] = v;
-        }
-    }
 }
 
 template <bool F16>
