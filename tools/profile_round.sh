@@ -52,6 +52,7 @@ prof f32 $ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-alt --matmu
 prof vae $ROOT/tools/vae_bench.py --iters 5
 prof vae3 $ROOT/tools/vae_bench.py --iters 5 --matmul bf16x3
 prof vae2 $ROOT/tools/vae_bench.py --iters 5 --matmul f16x2
+prof vae3enc $ROOT/tools/vae_bench.py --iters 5 --matmul bf16x3 --encode
 
 step "PMC traffic (separate FETCH_SIZE / WRITE_SIZE passes; single-stream launches as in the roofline pass)"
 timeout -k 10 600 python3 tools/pmc_traffic.py --out gpurun_out/$TAG/traffic_bf16x3.json -- --matmul bf16x3 > $OUT/traffic_bf16x3.txt 2>&1 || exit 1
@@ -93,6 +94,8 @@ for m in bf16x3 f16x2; do AVD_VAE_FOLD=0 timeout -k 10 200 python3 tools/vae_ben
 timeout -k 10 200 python3 tools/vae_bench.py --matmul bf16x3 --batch 8 2>&1 | grep -v amdgpu.ids >> $OUT/vae_decode.txt
 timeout -k 10 300 python3 tools/pmc_util.py --script tools/vae_bench.py --out gpurun_out/$TAG/util_vae3.json -- --matmul bf16x3 --iters 2 > $OUT/util_vae3.txt 2>&1 || echo "vae util failed"
 timeout -k 10 200 python3 tools/vae_bench.py --matmul f16x2 --batch 8 2>&1 | grep -v amdgpu.ids >> $OUT/vae_decode.txt
+for m in f32 bf16x3 f16x2; do timeout -k 10 200 python3 tools/vae_bench.py --encode --matmul $m 2>&1 | grep -v amdgpu.ids >> $OUT/vae_encode.txt; done
+for m in bf16x3 f16x2; do AVD_VAE_FOLD=0 timeout -k 10 200 python3 tools/vae_bench.py --encode --matmul $m 2>&1 | grep -v amdgpu.ids | sed "s/^\[$m\]/[$m, fold 0]/" >> $OUT/vae_encode.txt; done
 timeout -k 10 600 python3 tools/e2e_bench.py > $OUT/e2e.txt 2>&1 || echo "e2e failed"
 step "  e2e done"
 timeout -k 10 600 python3 tools/soak.py > $OUT/soak.txt 2>&1 || echo "soak failed"
