@@ -569,6 +569,9 @@ struct Conv3Args {
     const float* wimg_g;       // [4][64] = to_img_w[o][c] gamma[c], rows >= out_ch zero
     int64_t w3_stride;         // bytes between the samples' weight images (0: one image for all samples)
     int btab_stride;           // floats between the samples' bias tables (0: one table)
+    // slab-major operand images (see the kernel): bytes between the four 96-byte-per-voxel slab images of the INPUT (64-channel convs) /
+    // of the image OUT = 1 writes; 0 = voxel-major act3 rows of 384 B
+    int64_t x_slab_stride, out_slab_stride;
 };
 
 // scale slot in the workspace: [0] max |x|, [1] (max row norm, unused), [2] s, [3] 1 / s
@@ -723,20 +726,24 @@ __global__ __launch_bounds__(256) void toimg_from_p_kernel(const float* __restri
         }
 }
 
+// slab_stride != 0: the slab-major form (conv3d_k3_bf16x3_kernel) — four images of 96 B per voxel = [plane][16 ch] (two planes: 64 B, so that
+// every byte of a row is written: rows with holes cost the memory side a read-modify-write), slab c8 / 2, its channels 8 (c8 % 2) .. + 7;
+// 0: voxel-major rows of 384 B = [plane][64 ch]
 template <bool F16>
-__device__ __forceinline__ void store_act3(unsigned char* X3, int64_t pv, int c8, const float* v, float sc) {
-    unsigned char* dst = X3 + pv * A3_ROWB + c8 * 16;
+__device__ __forceinline__ void store_act3(unsigned char* X3, int64_t pv, int c8, const float* v, float sc, int64_t slab_stride = 0) {
+    unsigned char* dst = slab_stride ? X3 + (int64_t)(c8 >> 1) * slab_stride + pv * (F16 ? 64 : 96) + (c8 & 1) * 16 : X3 + pv * A3_ROWB + c8 * 16;
+    const int pls = slab_stride ? 32 : 128;
     if constexpr (F16) {
         u32x4 Hh, Lo;
         split8_h2(v, sc, Hh, Lo);
         *reinterpret_cast<u32x4*>(dst) = Hh;
-        *reinterpret_cast<u32x4*>(dst + 128) = Lo;
+        *reinterpret_cast<u32x4*>(dst + pls) = Lo;
     } else {
         u32x4 Hh, Mi, Lo;
         split8(v, Hh, Mi, Lo);
         *reinterpret_cast<u32x4*>(dst) = Hh;
-        *reinterpret_cast<u32x4*>(dst + 128) = Mi;
-        *reinterpret_cast<u32x4*>(dst + 256) = Lo;
+        *reinterpret_cast<u32x4*>(dst + pls) = Mi;
+        *reinterpret_cast<u32x4*>(dst + 2 * pls) = Lo;
     }
 }
 
@@ -744,7 +751,7 @@ __device__ __forceinline__ void store_act3(unsigned char* X3, int64_t pv, int c8
 template <bool F16>      // F16: the image scale is read from the device (sc_dev[0], written by pow2_scale_kernel)
 __global__ __launch_bounds__(256) void upsample_pad3_kernel(const float* __restrict__ hlow, unsigned char* __restrict__ X3,
                                                             int Tp, int Hp_, int Wp_, int T, int H, int W, float st,
-                                                            float sh, float sw, int64_t total8, const float* __restrict__ sc_dev) {
+                                                            float sh, float sw, int64_t total8, const float* __restrict__ sc_dev, int64_t slab_stride) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total8) return;
     const int c8 = (int)(i & 7);
@@ -769,33 +776,40 @@ __global__ __launch_bounds__(256) void upsample_pad3_kernel(const float* __restr
         o[4 * q] = r[0]; o[4 * q + 1] = r[1]; o[4 * q + 2] = r[2]; o[4 * q + 3] = r[3];
     }
     const int64_t pv = (((int64_t)smp * (T + 2) + t + 1) * (H + 2) + h + 1) * (W + 2) + w + 1;
-    store_act3<F16>(X3, pv, c8, o, F16 ? sc_dev[0] : 0.f);
+    store_act3<F16>(X3, pv, c8, o, F16 ? sc_dev[0] : 0.f, slab_stride);
 }
 
-// GroupNorm apply: Y (NDHWC fp32) -> interior of the act3 buffer feeding the next conv (a chunk of 8 channels = one group)
+// GroupNorm apply: Y (NDHWC fp32) -> interior of the act3 buffer feeding the next conv.  One thread = one (voxel, 16-channel slab) = two
+// GroupNorm groups: four consecutive threads read one voxel's 256 bytes, and in the slab-major image (slab_stride != 0) a thread's three plane
+// pieces are 32 contiguous bytes each, 16 consecutive voxels of a slab 1.5 KiB (with one thread per 8 channels the 16-byte stores of
+// neighbouring threads went to different slab images: 0.30 -> 0.72 ms)
 template <bool F16>
 __global__ __launch_bounds__(256) void gn_apply_pad3_kernel(const float* __restrict__ Y, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            unsigned char* __restrict__ X3, int T, int H, int W, int64_t total8, float sc) {
+                                                            unsigned char* __restrict__ X3, int T, int H, int W, int64_t total4, float sc, int64_t slab_stride) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total8) return;
-    const int c8 = (int)(i & 7);
-    const int64_t vox = i >> 3;
+    if (i >= total4) return;
+    const int slab = (int)(i & 3);
+    const int64_t vox = i >> 2;
     const int THW = T * H * W;
     const int smp = (int)(vox / THW), v = (int)(vox % THW);
     const int w = v % W, h = (v / W) % H, t = v / (W * H);
-    const float mean = stats[(smp * VG + c8) * 2], rstd = stats[(smp * VG + c8) * 2 + 1];
-    float y[8], gm[8], bt[8], o[8];
-    *reinterpret_cast<f32x4*>(y) = *reinterpret_cast<const f32x4*>(Y + vox * VC + c8 * 8);
-    *reinterpret_cast<f32x4*>(y + 4) = *reinterpret_cast<const f32x4*>(Y + vox * VC + c8 * 8 + 4);
-    *reinterpret_cast<f32x4*>(gm) = *reinterpret_cast<const f32x4*>(gamma + c8 * 8);
-    *reinterpret_cast<f32x4*>(gm + 4) = *reinterpret_cast<const f32x4*>(gamma + c8 * 8 + 4);
-    *reinterpret_cast<f32x4*>(bt) = *reinterpret_cast<const f32x4*>(beta + c8 * 8);
-    *reinterpret_cast<f32x4*>(bt + 4) = *reinterpret_cast<const f32x4*>(beta + c8 * 8 + 4);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (y[e] - mean) * rstd * gm[e] + bt[e];
     const int64_t pv = (((int64_t)smp * (T + 2) + t + 1) * (H + 2) + h + 1) * (W + 2) + w + 1;
-    store_act3<F16>(X3, pv, c8, o, sc);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const int c8 = slab * 2 + half;
+        const float mean = stats[(smp * VG + c8) * 2], rstd = stats[(smp * VG + c8) * 2 + 1];
+        float y[8], gm[8], bt[8], o[8];
+        *reinterpret_cast<f32x4*>(y) = *reinterpret_cast<const f32x4*>(Y + vox * VC + c8 * 8);
+        *reinterpret_cast<f32x4*>(y + 4) = *reinterpret_cast<const f32x4*>(Y + vox * VC + c8 * 8 + 4);
+        *reinterpret_cast<f32x4*>(gm) = *reinterpret_cast<const f32x4*>(gamma + c8 * 8);
+        *reinterpret_cast<f32x4*>(gm + 4) = *reinterpret_cast<const f32x4*>(gamma + c8 * 8 + 4);
+        *reinterpret_cast<f32x4*>(bt) = *reinterpret_cast<const f32x4*>(beta + c8 * 8);
+        *reinterpret_cast<f32x4*>(bt + 4) = *reinterpret_cast<const f32x4*>(beta + c8 * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (y[e] - mean) * rstd * gm[e] + bt[e];
+        store_act3<F16>(X3, pv, c8, o, sc, slab_stride);
+    }
 }
 
 // ---- input image of the latent-composed first decoder conv: per padded voxel 96 B = [plane h | m | l][16 ch bf16] (f16x2: planes h, l at
@@ -956,7 +970,14 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
     // its channels 0 .. 7; the weight image holds [tap 2 s: 8 ch | tap 2 s + 1: 8 ch] per stage (the host packs it): 14 steps instead of 27
     constexpr bool LAT = NSLAB <= 1, PK = NSLAB == 0;
     constexpr int NSL = LAT ? 1 : NSLAB, NTAP = PK ? 14 : 27;
-    constexpr int XROWB = LAT ? L16_ROWB : A3_ROWB, XPLS = LAT ? 32 : 128;      // bytes per voxel / per plane of the input image
+    // bytes per voxel / per plane of the input image, and where slab s of it starts.  Voxel-major act3 rows (384 B = [plane][64 ch]) give a
+    // slab 32 bytes of each 128-byte plane line: a block touches every line of its tile four times, ~27 steps apart, and the L2 does not
+    // hold 64 blocks' tiles that long — FETCH_SIZE of the 64 -> 64 conv at 256 x 256: 9.6 GB per launch for a 1.2 GB image (x 2.5 halo
+    // overlap x 4).  SLAB-major (round 5, x_slab_stride != 0): four images of 96 B per voxel ([plane][16 ch], the latent image's form), one per
+    // 16-channel slab — a refill streams dense rows of its slab's image.
+    const bool xslab = !LAT && g.x_slab_stride != 0;
+    const int XROWB = LAT ? L16_ROWB : xslab ? NPL * 32 : A3_ROWB, XPLS = LAT || xslab ? 32 : 128;
+    auto slab_off = [&](int slab) -> int64_t { return xslab ? (int64_t)slab * g.x_slab_stride : (int64_t)slab * 32; };
     extern __shared__ __attribute__((aligned(16))) unsigned char smem3[];
     unsigned char* halo = smem3;
     unsigned char* wring = smem3 + Cf::HALO_B;
@@ -1027,7 +1048,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
                     int tt = t0 + tz, hh = h0 + hy;
                     tt = tt < g.T + 2 ? tt : g.T + 1;
                     hh = hh < Hp ? hh : Hp - 1;
-                    const unsigned char* src = g.X3 + ((((int64_t)smp * (g.T + 2) + tt) * Hp + hh) * Wp) * XROWB + slab * 32;
+                    const unsigned char* src = g.X3 + ((((int64_t)smp * (g.T + 2) + tt) * Hp + hh) * Wp) * XROWB + slab_off(slab);
                     __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(src + hsrc[0]), AVD_LDS_PTR(halo + r * (ROWCH * 16)), 16, 0, 0);
                     if (lane < ROWCH - 64)
                         __builtin_amdgcn_global_load_lds(AVD_GLB_PTR(src + hsrc[1]), AVD_LDS_PTR(halo + r * (ROWCH * 16) + 1024), 16, 0, 0);
@@ -1040,7 +1061,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
             for (int tz = 0; tz < HT_T + 2; ++tz) {
                 int tt = t0 + tz;
                 tt = tt < g.T + 2 ? tt : g.T + 1;
-                const unsigned char* src = g.X3 + (((int64_t)smp * (g.T + 2) + tt) * Hp * Wp) * XROWB + slab * 32;
+                const unsigned char* src = g.X3 + (((int64_t)smp * (g.T + 2) + tt) * Hp * Wp) * XROWB + slab_off(slab);
 #pragma unroll
                 for (int k = 0; k < SPW; ++k) {
                     const int j = wave + 4 * k;
@@ -1270,7 +1291,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_k3_bf16x3_kernel(Conv3Args g) {
                 if (tt < g.T && hh < g.H && ww < g.W) {
                     if constexpr (OUT == 1) {
                         const int64_t pv = (((int64_t)smp * (g.T + 2) + tt + 1) * Hp + hh + 1) * Wp + ww + 1;
-                        store_act3<false>(g.X3out, pv, c8, y, 0.f);
+                        store_act3<false>(g.X3out, pv, c8, y, 0.f, g.out_slab_stride);
                     } else if constexpr (OUT == 3) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) pool[it & 1][e] += y[e];
@@ -1594,6 +1615,8 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
     // latent-composed first convolution (conv3d_k3_bf16x3_kernel<.., 1>): its input image is upsample(z), 96 B per voxel
     const bool lat = s3 && d->conv0_lat_w3 != nullptr && g_vae_lat;
     const int64_t padvox = (int64_t)B * (p.T + 2) * (p.H + 2) * (p.W + 2);
+    const int act_rowb = d->conv_w3 && d->conv_terms == 3 ? 64 : L16_ROWB;      // bytes per voxel of one slab image: planes x 32
+    const int64_t act_slab = padvox * act_rowb;       // bytes between the four slab images of a split-operand conv's input (slab-major act3)
     const int64_t nvox = (int64_t)B * p.THW;
     float* consts = reinterpret_cast<float*>(foldw);            // {rstd[8], K[4]} per sample (16 floats each), then to_img_w . gamma [4][64]
     float* wg = consts + (int64_t)B * 16;
@@ -1617,11 +1640,13 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
         float* btab1 = reinterpret_cast<float*>(wimg + (int64_t)B * W3_BYTES);
         if (int rc = zero_halo(reinterpret_cast<float*>(Lm), B, p.T, p.H, p.W, L16_ROWB, st)) return rc;
         if (int rc = upsample_lat16(z, hlow, Lm, B, d->Cv, d->Tp, d->Hp, d->Wp, p.T, p.H, p.W, false, nullptr, st)) return rc;
-        if (int rc = zero_halo(Xp, B, p.T, p.H, p.W, A3_ROWB, st)) return rc;
+        // conv 1's operand image is SLAB-major (four 96-byte-per-voxel images, one per 16 channels: conv3d_k3_bf16x3_kernel) = 4 B "samples" of halo
+        const int64_t slab_stride = act_slab;
+        if (int rc = zero_halo(Xp, 4 * B, p.T, p.H, p.W, L16_ROWB, st)) return rc;
         const int gn_tiles = conv3_tiles(6, p.T, p.H, p.W);
         {
             Conv3Args a3{Lm, static_cast<const unsigned char*>(d->conv0_lat_w3), d->conv_b[0], nullptr, part, p.T, p.H, p.W, p.tiles, 1.f, nullptr,
-                         d->conv0_lat_btab, X3, nullptr, nullptr, 0, 0};
+                         d->conv0_lat_btab, X3, nullptr, nullptr, 0, 0, 0, slab_stride};
             if (int rc = conv3_launch(a3, 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * 16, st, true, 1, d->conv0_lat_packed != 0)) return rc;
         }
         if (int rc = gn_finalize(part, fin, stats, B, gn_tiles, (double)p.THW * (VC / VG), d->gn_eps, st)) return rc;
@@ -1636,7 +1661,7 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
             AVD_CHECK_LAUNCH("toimg_wg");
         }
         {
-            Conv3Args a3{X3, wimg, d->conv_b[1], nullptr, part, p.T, p.H, p.W, p.tiles, 1.f, nullptr, btab1, nullptr, Pp, wg, W3_BYTES, 64 * VC};
+            Conv3Args a3{X3, wimg, d->conv_b[1], nullptr, part, p.T, p.H, p.W, p.tiles, 1.f, nullptr, btab1, nullptr, Pp, wg, W3_BYTES, 64 * VC, slab_stride, 0};
             if (int rc = conv3_launch(a3, 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st, false, 2)) return rc;
         }
         if (int rc = gn_finalize(part, fin, stats, B, gn_tiles, (double)p.THW * (VC / VG), d->gn_eps, st)) return rc;
@@ -1655,8 +1680,9 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
         }
         if (int rc = upsample_lat16(z, hlow, X3, B, d->Cv, d->Tp, d->Hp, d->Wp, p.T, p.H, p.W, h2, scale_ws + 2, st)) return rc;
     } else {
-    // zero halo (interiors are overwritten below by the upsample / GroupNorm-apply passes, the halo stays zero for every conv)
-    if (int rc = zero_halo(Xp, B, p.T, p.H, p.W, s3 ? A3_ROWB : VC * 4, st)) return rc;
+    // zero halo (interiors are overwritten below by the upsample / GroupNorm-apply passes, the halo stays zero for every conv); the operand
+    // image of the split-operand convs is slab-major: 4 B "samples" of 96-byte rows
+    if (int rc = s3 ? zero_halo(Xp, 4 * B, p.T, p.H, p.W, act_rowb, st) : zero_halo(Xp, B, p.T, p.H, p.W, VC * 4, st)) return rc;
     {   // from_lat on the latent grid, then trilinear upsample into the padded conv input
         const int vol = d->Tp * d->Hp * d->Wp;
         const int64_t total = (int64_t)B * vol * VC;
@@ -1680,11 +1706,11 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
         if (h2)
             hipLaunchKernelGGL(upsample_pad3_kernel<true>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, hlow, X3, d->Tp, d->Hp,
                                d->Wp, p.T, p.H, p.W, (float)d->Tp / (float)p.T, (float)d->Hp / (float)p.H, (float)d->Wp / (float)p.W, total8,
-                               scale_ws + 2);
+                               scale_ws + 2, act_slab);
         else
             hipLaunchKernelGGL(upsample_pad3_kernel<false>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, hlow, X3, d->Tp, d->Hp,
                                d->Wp, p.T, p.H, p.W, (float)d->Tp / (float)p.T, (float)d->Hp / (float)p.H, (float)d->Wp / (float)p.W, total8,
-                               nullptr);
+                               nullptr, act_slab);
         AVD_CHECK_LAUNCH("upsample_pad3");
     } else {
         const int64_t total4 = (int64_t)B * p.THW * (VC / 4);
@@ -1705,6 +1731,7 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
             const bool lat0 = lat && blk == 0;
             Conv3Args a3{X3, static_cast<const unsigned char*>(lat0 ? d->conv0_lat_w3 : d->conv_w3[blk]), d->conv_b[blk], Y, part, p.T, p.H, p.W, p.tiles,
                          1.f, nullptr, lat0 ? d->conv0_lat_btab : nullptr};
+            if (!lat0) a3.x_slab_stride = act_slab;
             if (h2) {
                 a3.ab_inv = blk == 0 ? 1.0f / (lat0 ? d->conv0_lat_w_scale : d->conv_w_scale[0]) : 1.0f / (d->conv_w_scale[blk] * d->conv_a_scale[blk]);
                 a3.a_inv_dev = blk == 0 ? scale_ws + 3 : nullptr;
@@ -1723,7 +1750,7 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
             gn_tiles = conv3_tiles(h2 ? 3 : 6, p.T, p.H, p.W);
             // the act3 buffer of the next conv overlays the latent image: its halo is zeroed now that conv 0 has read the latent image
             if (lat0 && blk + 1 < d->n_blocks)
-                if (int rc = zero_halo(Xp, B, p.T, p.H, p.W, A3_ROWB, st)) return rc;
+                if (int rc = zero_halo(Xp, 4 * B, p.T, p.H, p.W, act_rowb, st)) return rc;
             if (p_out) {
                 if (int rc = gn_finalize(part, fin, stats, B, gn_tiles, (double)p.THW * (VC / VG), d->gn_eps, st)) return rc;
                 return toimg_from_p(blk);
@@ -1736,15 +1763,15 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
         }
         if (int rc = gn_finalize(part, fin, stats, B, gn_tiles, (double)p.THW * (VC / VG), d->gn_eps, st)) return rc;
         if (blk + 1 < d->n_blocks && s3) {
-            const int64_t total8 = (int64_t)B * p.THW * 8;
+            const int64_t total8 = (int64_t)B * p.THW * 4;       // threads: (voxel, 16-channel slab)
             static const int tag = prof_tag_id("gn_apply_pad3_kernel");
             ProfScope prof(tag, 10.0 * (double)B * p.THW * VC, st);
             if (h2)
                 hipLaunchKernelGGL(gn_apply_pad3_kernel<true>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
-                                   d->gn_b[blk], X3, p.T, p.H, p.W, total8, d->conv_a_scale[blk + 1]);
+                                   d->gn_b[blk], X3, p.T, p.H, p.W, total8, d->conv_a_scale[blk + 1], act_slab);
             else
                 hipLaunchKernelGGL(gn_apply_pad3_kernel<false>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
-                                   d->gn_b[blk], X3, p.T, p.H, p.W, total8, 0.f);
+                                   d->gn_b[blk], X3, p.T, p.H, p.W, total8, 0.f, act_slab);
             AVD_CHECK_LAUNCH("gn_apply_pad3");
         } else if (blk + 1 < d->n_blocks) {
             const int64_t total4 = (int64_t)B * p.THW * (VC / 4);
@@ -1854,11 +1881,12 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
                 hipLaunchKernelGGL(rgb_lat16_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, x, Lm, d->in_ch, T, H, W, nvox);
                 AVD_CHECK_LAUNCH("rgb_lat16");
             }
-            if (int rc = zero_halo(Xp, B, T, H, W, A3_ROWB, st)) return rc;
+            const int64_t slab_stride = padvox * L16_ROWB;       // conv 1's operand image: slab-major (conv3d_k3_bf16x3_kernel)
+            if (int rc = zero_halo(Xp, 4 * B, T, H, W, L16_ROWB, st)) return rc;
             const int gn_tiles = conv3_tiles(6, T, H, W);
             {
                 Conv3Args a3{Lm, static_cast<const unsigned char*>(d->conv0_pk_w3), d->conv_b[0], nullptr, part, T, H, W, p.tiles, 1.f, nullptr, nullptr, X3,
-                             nullptr, nullptr, 0, 0};
+                             nullptr, nullptr, 0, 0, 0, slab_stride};
                 if (int rc = conv3_launch(a3, 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * 16, st, true, 1, true)) return rc;
             }
             if (int rc = gn_finalize(part, fin, stats, B, gn_tiles, (double)p.THW * (VC / VG), d->gn_eps, st)) return rc;
@@ -1871,7 +1899,7 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
                 AVD_CHECK_LAUNCH("conv3_gn_btab");
             }
             {
-                Conv3Args a3{X3, wimg, d->conv_b[1], nullptr, part, T, H, W, p.tiles, 1.f, nullptr, btab1, nullptr, Y, nullptr, W3_BYTES, 64 * VC};
+                Conv3Args a3{X3, wimg, d->conv_b[1], nullptr, part, T, H, W, p.tiles, 1.f, nullptr, btab1, nullptr, Y, nullptr, W3_BYTES, 64 * VC, slab_stride, 0};
                 if (int rc = conv3_launch(a3, 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st, false, 3)) return rc;
             }
             if (int rc = gn_finalize(part, fin, stats, B, gn_tiles, (double)p.THW * (VC / VG), d->gn_eps, st)) return rc;
@@ -1884,9 +1912,11 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
             return AVD_OK;
         }
     }
+    const int act_rowb = h2 ? 64 : L16_ROWB;
+    const int64_t act_slab = (int64_t)B * (T + 2) * (H + 2) * (W + 2) * act_rowb;      // slab-major operand image of the split-operand convs
     if (int rc = zero_halo(Xp4, B, T, H, W, 16, st)) return rc;
     if (d->n_blocks > 1)
-        if (int rc = zero_halo(Xp, B, T, H, W, s3 ? A3_ROWB : VC * 4, st)) return rc;
+        if (int rc = s3 ? zero_halo(Xp, 4 * B, T, H, W, act_rowb, st) : zero_halo(Xp, B, T, H, W, VC * 4, st)) return rc;
     {
         const int64_t nvox = (int64_t)B * p.THW;
         hipLaunchKernelGGL(rgb_to_ndhwc4_pad_kernel, dim3((unsigned)((nvox + 255) / 256)), dim3(256), 0, st, x, Xp4, d->in_ch,
@@ -1903,6 +1933,7 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
         if (blk > 0 && s3) {
             Conv3Args a3{X3, static_cast<const unsigned char*>(d->conv_w3[blk]), d->conv_b[blk], Y, part, T, H, W, p.tiles,
                          h2 ? 1.0f / (d->conv_w_scale[blk] * d->conv_a_scale[blk]) : 1.f, nullptr};
+            a3.x_slab_stride = act_slab;
             if (pool_out) { a3.Y = nullptr; a3.P = Y; }
             if (int rc = conv3_launch(a3, h2 ? 3 : 6, B, 2.0 * (double)B * p.THW * VC * 27.0 * VC, st, false, pool_out ? 3 : 0)) return rc;
             gn_tiles = conv3_tiles(h2 ? 3 : 6, T, H, W);
@@ -1918,15 +1949,15 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
         AVD_CHECK_LAUNCH("conv3d(enc)");
         if (int rc = gn_finalize(part, fin, stats, B, gn_tiles, (double)p.THW * (VC / VG), d->gn_eps, st)) return rc;
         if (blk + 1 < d->n_blocks && s3) {
-            const int64_t total8 = (int64_t)B * p.THW * 8;
+            const int64_t total8 = (int64_t)B * p.THW * 4;       // threads: (voxel, 16-channel slab)
             static const int tag = prof_tag_id("gn_apply_pad3_kernel");
             ProfScope prof(tag, 10.0 * (double)B * p.THW * VC, st);
             if (h2)
                 hipLaunchKernelGGL(gn_apply_pad3_kernel<true>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
-                                   d->gn_b[blk], X3, T, H, W, total8, d->conv_a_scale[blk + 1]);
+                                   d->gn_b[blk], X3, T, H, W, total8, d->conv_a_scale[blk + 1], act_slab);
             else
                 hipLaunchKernelGGL(gn_apply_pad3_kernel<false>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
-                                   d->gn_b[blk], X3, T, H, W, total8, 0.f);
+                                   d->gn_b[blk], X3, T, H, W, total8, 0.f, act_slab);
             AVD_CHECK_LAUNCH("gn_apply_pad3");
         } else if (blk + 1 < d->n_blocks) {
             const int64_t total4 = (int64_t)B * p.THW * (VC / 4);

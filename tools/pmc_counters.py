@@ -19,14 +19,18 @@ ap.add_argument("--out", default="profiles/counters.json")
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--sets", nargs="+", default=["TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"])
 ap.add_argument("--match", default="avd::", help="keep kernels whose name contains this")
+ap.add_argument("--script", default=None, help="another script of this repo to run instead of bench.py (its arguments after --), e.g. tools/vae_bench.py")
 args, extra = ap.parse_known_args()
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 res = collections.defaultdict(dict)
 for cset in args.sets:
     d = tempfile.mkdtemp(prefix="pmc_set_", dir=os.path.join(root, "gpurun_out"))
-    cmd = ["rocprofv3", "--pmc"] + cset.split() + ["--output-format", "csv", "-d", d, "--",
-           "python3", os.path.join(root, "bench.py"), "--steps", str(args.steps), "--warmup", "1",
-           "--no-cpu-baseline", "--no-roofline", "--no-alt", "--split-streams", "0"] + [e for e in extra if e != "--"]
+    cmd = ["rocprofv3", "--pmc"] + cset.split() + ["--output-format", "csv", "-d", d, "--", "python3"]
+    if args.script:
+        cmd += [os.path.join(root, args.script)] + [e for e in extra if e != "--"]
+    else:
+        cmd += [os.path.join(root, "bench.py"), "--steps", str(args.steps), "--warmup", "1",
+                "--no-cpu-baseline", "--no-roofline", "--no-alt", "--split-streams", "0"] + [e for e in extra if e != "--"]
     r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
     if r.returncode:
         print(f"pass [{cset}] failed (rc {r.returncode}): {r.stderr[-400:]}")
