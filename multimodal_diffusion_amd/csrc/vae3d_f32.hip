@@ -779,36 +779,61 @@ __global__ __launch_bounds__(256) void upsample_pad3_kernel(const float* __restr
     store_act3<F16>(X3, pv, c8, o, F16 ? sc_dev[0] : 0.f, slab_stride);
 }
 
-// GroupNorm apply: Y (NDHWC fp32) -> interior of the act3 buffer feeding the next conv.  One thread = one (voxel, 16-channel slab) = two
-// GroupNorm groups: four consecutive threads read one voxel's 256 bytes, and in the slab-major image (slab_stride != 0) a thread's three plane
-// pieces are 32 contiguous bytes each, 16 consecutive voxels of a slab 1.5 KiB (with one thread per 8 channels the 16-byte stores of
-// neighbouring threads went to different slab images: 0.30 -> 0.72 ms)
+// GroupNorm apply: Y (NDHWC fp32) -> interior of the act3 buffer feeding the next conv.  A block takes 64 consecutive voxels: one thread
+// = one (voxel, 16-channel slab) = two GroupNorm groups reads 64 bytes (four neighbouring threads: one voxel's 256), normalises, splits, and
+// parks its row of the slab-major image — [plane][16 ch], 96 / 64 bytes — in LDS as [slab][voxel][piece]; then the four slab images are
+// written out 16 bytes per lane in row order: 64 consecutive voxels of a slab are one 6 / 4 KiB run (rows of one w-line are contiguous).
+// (Written straight from the registers, a store instruction scattered 16-byte pieces over four images: 0.30 -> 0.46 ms for two planes.)
 template <bool F16>
 __global__ __launch_bounds__(256) void gn_apply_pad3_kernel(const float* __restrict__ Y, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                            unsigned char* __restrict__ X3, int T, int H, int W, int64_t total4, float sc, int64_t slab_stride) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= total4) return;
-    const int slab = (int)(i & 3);
-    const int64_t vox = i >> 2;
+                                                            unsigned char* __restrict__ X3, int T, int H, int W, int64_t nvox, float sc, int64_t slab_stride) {
+    constexpr int NP = F16 ? 4 : 6, ROWB = NP * 16;            // 16-byte pieces / bytes of a slab row: (plane, 8-channel half)
+    __shared__ u32x4 stage[4][64][NP];
+    __shared__ int64_t spv[64];
+    const int tid = threadIdx.x, vl = tid >> 2, slab = tid & 3;
+    const int64_t vox0 = (int64_t)blockIdx.x * 64, vox = vox0 + vl;
     const int THW = T * H * W;
-    const int smp = (int)(vox / THW), v = (int)(vox % THW);
-    const int w = v % W, h = (v / W) % H, t = v / (W * H);
-    const int64_t pv = (((int64_t)smp * (T + 2) + t + 1) * (H + 2) + h + 1) * (W + 2) + w + 1;
+    if (vox < nvox) {
+        const int smp = (int)(vox / THW), v = (int)(vox % THW);
+        const int w = v % W, h = (v / W) % H, t = v / (W * H);
+        if (slab == 0) spv[vl] = (((int64_t)smp * (T + 2) + t + 1) * (H + 2) + h + 1) * (W + 2) + w + 1;
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-        const int c8 = slab * 2 + half;
-        const float mean = stats[(smp * VG + c8) * 2], rstd = stats[(smp * VG + c8) * 2 + 1];
-        float y[8], gm[8], bt[8], o[8];
-        *reinterpret_cast<f32x4*>(y) = *reinterpret_cast<const f32x4*>(Y + vox * VC + c8 * 8);
-        *reinterpret_cast<f32x4*>(y + 4) = *reinterpret_cast<const f32x4*>(Y + vox * VC + c8 * 8 + 4);
-        *reinterpret_cast<f32x4*>(gm) = *reinterpret_cast<const f32x4*>(gamma + c8 * 8);
-        *reinterpret_cast<f32x4*>(gm + 4) = *reinterpret_cast<const f32x4*>(gamma + c8 * 8 + 4);
-        *reinterpret_cast<f32x4*>(bt) = *reinterpret_cast<const f32x4*>(beta + c8 * 8);
-        *reinterpret_cast<f32x4*>(bt + 4) = *reinterpret_cast<const f32x4*>(beta + c8 * 8 + 4);
+        for (int half = 0; half < 2; ++half) {
+            const int c8 = slab * 2 + half;
+            const float mean = stats[(smp * VG + c8) * 2], rstd = stats[(smp * VG + c8) * 2 + 1];
+            float y[8], gm[8], bt[8], o[8];
+            *reinterpret_cast<f32x4*>(y) = *reinterpret_cast<const f32x4*>(Y + vox * VC + c8 * 8);
+            *reinterpret_cast<f32x4*>(y + 4) = *reinterpret_cast<const f32x4*>(Y + vox * VC + c8 * 8 + 4);
+            *reinterpret_cast<f32x4*>(gm) = *reinterpret_cast<const f32x4*>(gamma + c8 * 8);
+            *reinterpret_cast<f32x4*>(gm + 4) = *reinterpret_cast<const f32x4*>(gamma + c8 * 8 + 4);
+            *reinterpret_cast<f32x4*>(bt) = *reinterpret_cast<const f32x4*>(beta + c8 * 8);
+            *reinterpret_cast<f32x4*>(bt + 4) = *reinterpret_cast<const f32x4*>(beta + c8 * 8 + 4);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (y[e] - mean) * rstd * gm[e] + bt[e];
-        store_act3<F16>(X3, pv, c8, o, sc, slab_stride);
+            for (int e = 0; e < 8; ++e) o[e] = (y[e] - mean) * rstd * gm[e] + bt[e];
+            if constexpr (F16) {
+                u32x4 Hh, Lo;
+                split8_h2(o, sc, Hh, Lo);
+                stage[slab][vl][half] = Hh;
+                stage[slab][vl][2 + half] = Lo;
+            } else {
+                u32x4 Hh, Mi, Lo;
+                split8(o, Hh, Mi, Lo);
+                stage[slab][vl][half] = Hh;
+                stage[slab][vl][2 + half] = Mi;
+                stage[slab][vl][4 + half] = Lo;
+            }
+        }
+    }
+    __syncthreads();
+    const int nv = nvox - vox0 < 64 ? (int)(nvox - vox0) : 64;
+    for (int idx = tid; idx < 4 * 64 * NP; idx += 256) {
+        const int sl = idx / (64 * NP), rem = idx - sl * (64 * NP), vv = rem / NP, pc = rem - vv * NP;
+        if (vv < nv) {
+            unsigned char* dst = slab_stride ? X3 + (int64_t)sl * slab_stride + spv[vv] * ROWB + pc * 16
+                                             : X3 + spv[vv] * A3_ROWB + (pc >> 1) * 128 + (sl * 2 + (pc & 1)) * 16;
+            *reinterpret_cast<u32x4*>(dst) = stage[sl][vv][pc];
+        }
     }
 }
 
@@ -1768,10 +1793,10 @@ extern "C" int avd_vae_decode_f32(const avd_vae_decode_desc* d, const float* z, 
             ProfScope prof(tag, 10.0 * (double)B * p.THW * VC, st);
             if (h2)
                 hipLaunchKernelGGL(gn_apply_pad3_kernel<true>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
-                                   d->gn_b[blk], X3, p.T, p.H, p.W, total8, d->conv_a_scale[blk + 1], act_slab);
+                                   d->gn_b[blk], X3, p.T, p.H, p.W, total8 / 4, d->conv_a_scale[blk + 1], act_slab);
             else
                 hipLaunchKernelGGL(gn_apply_pad3_kernel<false>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
-                                   d->gn_b[blk], X3, p.T, p.H, p.W, total8, 0.f, act_slab);
+                                   d->gn_b[blk], X3, p.T, p.H, p.W, total8 / 4, 0.f, act_slab);
             AVD_CHECK_LAUNCH("gn_apply_pad3");
         } else if (blk + 1 < d->n_blocks) {
             const int64_t total4 = (int64_t)B * p.THW * (VC / 4);
@@ -1954,10 +1979,10 @@ extern "C" int avd_vae_encode_f32(const avd_vae_encode_desc* d, const float* x, 
             ProfScope prof(tag, 10.0 * (double)B * p.THW * VC, st);
             if (h2)
                 hipLaunchKernelGGL(gn_apply_pad3_kernel<true>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
-                                   d->gn_b[blk], X3, T, H, W, total8, d->conv_a_scale[blk + 1], act_slab);
+                                   d->gn_b[blk], X3, T, H, W, total8 / 4, d->conv_a_scale[blk + 1], act_slab);
             else
                 hipLaunchKernelGGL(gn_apply_pad3_kernel<false>, dim3((unsigned)((total8 + 255) / 256)), dim3(256), 0, st, Y, stats, d->gn_w[blk],
-                                   d->gn_b[blk], X3, T, H, W, total8, 0.f, act_slab);
+                                   d->gn_b[blk], X3, T, H, W, total8 / 4, 0.f, act_slab);
             AVD_CHECK_LAUNCH("gn_apply_pad3");
         } else if (blk + 1 < d->n_blocks) {
             const int64_t total4 = (int64_t)B * p.THW * (VC / 4);
